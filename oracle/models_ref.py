@@ -1,0 +1,127 @@
+"""NumPy restatement of the per-datapoint (beta-)likelihood formulas and the
+weighted Gaussian posterior (oracle; tests only).
+
+Expression order is kept identical to the reference so that, given the same
+BLAS, results are bit-identical:
+  examples/common/model_linreg.py:4-10,25-34      linreg log-lik, weighted_post
+  examples/common/model_neurlinr.py:90-97,102-110 same log-lik, beta-likelihood
+  examples/common/model_lr.py:72-86               logistic log-lik, beta-likelihood
+  examples/common/gaussian.py:7-15,28-62          Gaussian-location model
+"""
+import numpy as np
+import scipy.linalg as sl
+
+
+def _split_xy(z):
+    z = np.atleast_2d(z)
+    return z[:, :-1], z[:, -1]
+
+
+def linreg_loglik(z, th, sigsq):
+    """model_linreg.py:4-10 == model_neurlinr.py:90-97 (expanded square kept)."""
+    x, y = _split_xy(z)
+    th = np.atleast_2d(th)
+    p = x.dot(th.T)
+    yc = y[:, np.newaxis]
+    return -1. / 2. * np.log(2. * np.pi * sigsq) - 1. / (2. * sigsq) * (yc ** 2 - 2 * p * yc + p ** 2)
+
+
+def linreg_beta_lik(z, th, beta, sigsq):
+    """model_neurlinr.py:102-110 (loss-signed)."""
+    x, y = _split_xy(z)
+    th = np.atleast_2d(th)
+    p = x.dot(th.T)
+    yc = y[:, np.newaxis]
+    return 1. / (2 * np.pi * sigsq) ** (beta / 2.) * (
+        -(beta + 1.) / beta * np.exp(-beta / (2. * sigsq) * (yc ** 2 - 2 * p * yc + p ** 2))
+        + 1. / np.sqrt(1. + beta))
+
+
+def logistic_loglik(z, th):
+    """model_lr.py:72-79 (branch at m < 100 kept)."""
+    z = np.atleast_2d(z)
+    th = np.atleast_2d(th)
+    m = -z.dot(th.T)
+    small = m < 100
+    m[small] = -np.log1p(np.exp(m[small]))
+    m[np.logical_not(small)] = -m[np.logical_not(small)]
+    return m
+
+
+def logistic_beta_lik(z, th, beta):
+    """model_lr.py:81-86 (relies on IEEE inf -> 0 limits)."""
+    z = np.atleast_2d(z)
+    th = np.atleast_2d(th)
+    m = -z.dot(th.T)
+    with np.errstate(over='ignore'):
+        m = -(((beta + 1.) / beta) * (1 + np.exp(m)) ** (-beta)
+              - ((1 + np.exp(m)) ** (-beta - 1.) + (1 + np.exp(-m)) ** (-beta - 1.)))
+    return m
+
+
+def _gauss_quadratic(x, th, Siginv):
+    x = np.atleast_2d(x)
+    th = np.atleast_2d(th)
+    xSx = (x * (x.dot(Siginv))).sum(axis=1)
+    tSt = (th * (th.dot(Siginv))).sum(axis=1)
+    xSt = x.dot(Siginv.dot(th.T))
+    return x, th, xSx, tSt, xSt
+
+
+def gauss_loglik(x, th, Siginv, logdetSig):
+    """gaussian.py:7-15 (without the stray print)."""
+    x, th, xSx, tSt, xSt = _gauss_quadratic(x, th, Siginv)
+    return -x.shape[1] / 2 * np.log(2 * np.pi) - 1. / 2. * logdetSig - 1. / 2. * (xSx[:, np.newaxis] + tSt - 2 * xSt)
+
+
+def gauss_beta_lik(x, th, beta, Siginv, logdetSig):
+    """gaussian.py:34-44 (gain-signed; the unused normaliser is not formed)."""
+    x, th, xSx, tSt, xSt = _gauss_quadratic(x, th, Siginv)
+    d = float(x.shape[1])
+    t1 = (1. / beta) * np.exp(-.5 * beta * (xSx[:, np.newaxis] + tSt - 2 * xSt))
+    t2 = (1 + beta) ** (-.5 * d - 1)
+    return t1 - t2
+
+
+def gauss_beta_grad(x, th, beta, Siginv, logdetSig):
+    """gaussian.py:46-62 (d/d beta of the beta-likelihood)."""
+    x, th, xSx, tSt, xSt = _gauss_quadratic(x, th, Siginv)
+    d = float(x.shape[1])
+    logc = np.log((2 * np.pi) ** (-.5 * d) * (np.exp(logdetSig) ** (-.5)))
+    q = xSx[:, np.newaxis] + tSt - 2 * xSt
+    gq = np.exp(-.5 * beta * q)
+    t11 = (1. / beta) * gq
+    t12 = (1 + beta) ** (-.5 * d - 1.)
+    t1 = logc * (t11 - t12)
+    t2 = 1. / (beta) ** 2 * gq
+    t3 = 1. / (2. * beta) * q * gq
+    t4 = (1 + beta) ** (-.5 * d - 1.) * np.log(1. + beta)
+    return t1 - t2 - t3 - t4
+
+
+def linreg_weighted_post(th0, Sig0inv, sigsq, z, w):
+    """model_linreg.py:25-34 == model_neurlinr.py:115-122.
+
+    NOTE: returns LSigp @ LSigp.T @ (...), i.e. C^-1 C^-T rather
+    than the true C^-T C^-1 -- reproduced on purpose, parity target is the
+    reference's output."""
+    X, Y = _split_xy(z)
+    C = np.linalg.cholesky(Sig0inv + (w[:, np.newaxis] * X).T.dot(X) / sigsq)
+    Ci = sl.solve_triangular(C, np.eye(C.shape[0]), lower=True, overwrite_b=True, check_finite=False)
+    mu = np.dot(Ci.dot(Ci.T), np.dot(Sig0inv, th0) + (w[:, np.newaxis] * Y[:, np.newaxis] * X).sum(axis=0) / sigsq)
+    return mu, Ci, C
+
+
+def gauss_weighted_post(th0, Sig0inv, Siginv, x, w):
+    """gaussian.py:28-32 (closed form, isotropic-safe)."""
+    C = np.linalg.cholesky(Sig0inv + w.sum() * Siginv)
+    Ci = sl.solve_triangular(C, np.eye(C.shape[0]), lower=True, overwrite_b=True, check_finite=False)
+    mu = np.dot(Ci.dot(Ci.T), np.dot(Sig0inv, th0) + np.dot(Siginv, (w[:, np.newaxis] * x).sum(axis=0)))
+    return mu, Ci, C
+
+
+def linreg_xtwx(z, w):
+    """The two row-reductions inside weighted_post (model_linreg.py:29,31):
+    X^T diag(w) X  and  X^T (w*y).  Kernel K4's outputs."""
+    X, Y = _split_xy(z)
+    return (w[:, np.newaxis] * X).T.dot(X), (w[:, np.newaxis] * Y[:, np.newaxis] * X).sum(axis=0)
