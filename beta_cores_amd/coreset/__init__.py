@@ -1,0 +1,6 @@
+"""Exports of bayesiancoresets/coreset/__init__.py:1-7 that are on the SNNLS / beta path
+(BatchPSVI, DiffPrivBatchPSVI and UniformSamplingCoreset are out of scope: SURVEY section 2 #12)."""
+from .coreset import Coreset
+from .hilbert import HilbertCoreset
+from .greedy_vi import BetaCoreset, SparseVICoreset
+from .projector import (Projector, BlackBoxProjector, BetaBlackBoxProjector, DeviceProjector, DeviceBetaProjector)

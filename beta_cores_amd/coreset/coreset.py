@@ -1,0 +1,75 @@
+import numpy as np
+
+from .. import util
+from ..util.errors import NumericalPrecisionError
+from ..util.log import make_logger
+
+
+class Coreset(object):
+    """Coreset state (weights, indices, points) and the build/optimize guards.
+
+    Protocol of bayesiancoresets/coreset/coreset.py:7-71: `build(itrs, sz)` never
+    returns more than sz points and raises ValueError when asked to shrink;
+    `optimize()` reverts and sets `reached_numeric_limit` when the error grows by
+    more than a factor 1+TOL; `get()` returns the strictly positive entries.
+
+    Fenced quirk: the reference shares its default `wts/idcs/pts` arrays between
+    instances (mutable default arguments, coreset.py:8) and BetaCoreset grows them in
+    place, so state leaks across instances.  Here every instance gets fresh arrays."""
+
+    def __init__(self, initial_sz=10, wts=None, idcs=None, pts=None):
+        self.alg_name, self.log = make_logger(self)
+        self.reached_numeric_limit = False
+        self.wts = np.array([]) if wts is None else wts
+        self.idcs = np.array([], dtype=np.int64) if idcs is None else idcs
+        self.pts = np.array([]) if pts is None else pts
+
+    def reset(self):
+        self.wts = np.array([])
+        self.idcs = np.array([], dtype=np.int64)
+        self.pts = np.array([])
+        self.reached_numeric_limit = False
+
+    def size(self):
+        return (self.wts > 0).sum()
+
+    def get(self):
+        keep = self.wts > 0
+        return self.wts[keep], self.pts[keep, :], self.idcs[keep]
+
+    def error(self):
+        raise NotImplementedError()
+
+    def build(self, itrs, sz):
+        if self.reached_numeric_limit:
+            return
+        if sz < self.size():
+            raise ValueError(self.alg_name + '.build(): requested coreset of size < the current size, but cannot '
+                             'shrink coresets; returning. Requested size = ' + str(sz) + ' current size = '
+                             + str(self.size()))
+        self._build(itrs, sz)
+        if self.reached_numeric_limit:
+            self.log.warning('the numeric limit has been reached. No more points will be added. size = '
+                             + str(self.size()) + ', error = ' + str(self.error()))
+
+    def optimize(self):
+        try:
+            cost0 = self.error()
+            saved = (self.wts.copy(), self.idcs.copy(), self.pts.copy())
+            self._optimize()
+            cost1 = self.error()
+            if cost1 > cost0 * (1. + util.TOL):
+                raise NumericalPrecisionError(
+                    'self.optimize() returned a solution with increasing error. Numeric limit possibly reached: '
+                    'preverr = ' + str(cost0) + ' err = ' + str(cost1) + '.')
+        except NumericalPrecisionError as e:
+            self.log.warning(e)
+            self.wts, self.idcs, self.pts = saved
+            self.reached_numeric_limit = True
+            return
+
+    def _optimize(self):
+        raise NotImplementedError
+
+    def _build(self, itrs, sz):
+        raise NotImplementedError

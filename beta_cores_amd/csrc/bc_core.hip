@@ -1,0 +1,503 @@
+// libbeta_cores: context, Phi storage (row tiles), layout kernels, K2 (column
+// sums / norms) and K3 (fused score + argmax sweep).  gfx950 only.
+#include "bc_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <climits>
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void bc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int bc_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  bc_set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  return -(int)e - 1000;
+}
+
+extern "C" const char* bc_last_error(void) { return g_err; }
+extern "C" int bc_version(void) { return 100; }
+
+// ------------------------------------------------------------------ context
+extern "C" int bc_ctx_create(int device, void* stream, bc_ctx** out) {
+  if (!out) { bc_set_error("bc_ctx_create: out is NULL"); return BC_INVALID_ARGUMENT; }
+  *out = nullptr;
+  int ndev = 0;
+  BC_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    bc_set_error("bc_ctx_create: device %d out of range (%d visible)", device, ndev);
+    return BC_INVALID_ARGUMENT;
+  }
+  BC_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  BC_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    bc_set_error("bc_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return BC_INVALID_ARGUMENT;
+  }
+  bc_ctx* c = new bc_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return bc_hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    c->own_stream = true;
+  }
+  c->pinned_doubles = 1 << 16;
+  hipError_t e = hipHostMalloc((void**)&c->pinned, c->pinned_doubles * sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) { delete c; return bc_hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
+  *out = c;
+  return BC_OK;
+}
+
+static void timer_free(bc_timer& t) {
+  for (auto ev : t.start) (void)hipEventDestroy(ev);
+  for (auto ev : t.stop) (void)hipEventDestroy(ev);
+  t.start.clear();
+  t.stop.clear();
+  t.used = 0;
+}
+
+extern "C" int bc_ctx_destroy(bc_ctx* ctx) {
+  if (!ctx) return BC_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& t : ctx->timers) timer_free(t);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return BC_OK;
+}
+
+extern "C" int bc_ctx_sync(bc_ctx* ctx) {
+  if (!ctx) { bc_set_error("bc_ctx_sync: NULL context"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  return BC_OK;
+}
+
+extern "C" int bc_ctx_enable_timing(bc_ctx* ctx, int on) {
+  if (!ctx) return BC_INVALID_ARGUMENT;
+  ctx->timing = on != 0;
+  return BC_OK;
+}
+
+int bc_timer_begin(bc_ctx* ctx, int which) {
+  if (!ctx->timing) return BC_OK;
+  bc_timer& t = ctx->timers[which];
+  if (t.used == t.start.size()) {
+    hipEvent_t a, b;
+    BC_HIP(hipEventCreate(&a));
+    BC_HIP(hipEventCreate(&b));
+    t.start.push_back(a);
+    t.stop.push_back(b);
+  }
+  BC_HIP(hipEventRecord(t.start[t.used], ctx->stream));
+  return BC_OK;
+}
+
+int bc_timer_end(bc_ctx* ctx, int which) {
+  if (!ctx->timing) return BC_OK;
+  bc_timer& t = ctx->timers[which];
+  BC_HIP(hipEventRecord(t.stop[t.used], ctx->stream));
+  t.used++;
+  t.launches++;
+  return BC_OK;
+}
+
+static int timer_collect(bc_ctx* ctx, bc_timer& t) {
+  if (t.used == 0) return BC_OK;
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < t.used; ++i) {
+    float ms = 0.f;
+    BC_HIP(hipEventElapsedTime(&ms, t.start[i], t.stop[i]));
+    t.acc_ms += ms;
+  }
+  t.used = 0;
+  return BC_OK;
+}
+
+extern "C" int bc_ctx_kernel_time(bc_ctx* ctx, int which, double* total_ms, int64_t* launches) {
+  if (!ctx || which < 0 || which > 2) { bc_set_error("bc_ctx_kernel_time: bad argument"); return BC_INVALID_ARGUMENT; }
+  int rc = timer_collect(ctx, ctx->timers[which]);
+  if (rc) return rc;
+  if (total_ms) *total_ms = ctx->timers[which].acc_ms;
+  if (launches) *launches = ctx->timers[which].launches;
+  return BC_OK;
+}
+
+extern "C" int bc_ctx_kernel_time_reset(bc_ctx* ctx) {
+  if (!ctx) return BC_INVALID_ARGUMENT;
+  for (auto& t : ctx->timers) {
+    int rc = timer_collect(ctx, t);
+    if (rc) return rc;
+    t.acc_ms = 0.0;
+    t.launches = 0;
+  }
+  return BC_OK;
+}
+
+// ------------------------------------------------------------------ data rows
+extern "C" int bc_data_from_host(bc_ctx* ctx, const double* z, int64_t n_rows, int32_t dz, bc_data** out) {
+  if (!ctx || !out || n_rows < 0 || dz <= 0 || (n_rows > 0 && !z)) {
+    bc_set_error("bc_data_from_host: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  bc_data* d = new bc_data();
+  d->ctx = ctx;
+  d->n_rows = n_rows;
+  d->dz = dz;
+  size_t bytes = (size_t)n_rows * dz * sizeof(double);
+  if (bytes) {
+    hipError_t e = hipMalloc((void**)&d->z, bytes);
+    if (e != hipSuccess) { delete d; return bc_hip_fail(e, "hipMalloc(data)", __FILE__, __LINE__); }
+    e = hipMemcpyAsync(d->z, z, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d->z); delete d; return bc_hip_fail(e, "hipMemcpy(data)", __FILE__, __LINE__); }
+  }
+  *out = d;
+  return BC_OK;
+}
+
+extern "C" int bc_data_from_device(bc_ctx* ctx, const void* z_dev, int64_t n_rows, int32_t dz, bc_data** out) {
+  if (!ctx || !out || n_rows < 0 || dz <= 0 || (n_rows > 0 && !z_dev)) {
+    bc_set_error("bc_data_from_device: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  bc_data* d = new bc_data();
+  d->ctx = ctx;
+  d->n_rows = n_rows;
+  d->dz = dz;
+  d->z = (double*)z_dev;
+  d->owned = false;
+  *out = d;
+  return BC_OK;
+}
+
+extern "C" int bc_data_destroy(bc_data* d) {
+  if (!d) return BC_OK;
+  if (d->owned && d->z) (void)hipFree(d->z);
+  delete d;
+  return BC_OK;
+}
+
+// ------------------------------------------------------------------ Phi storage
+int bc_sweep_grid(const bc_phi* phi) {
+  // memory-bound sweep: at most 8 blocks (32 waves) per CU, one wave per tile
+  long long want = (phi->ntiles + 3) / 4;
+  long long cap = (long long)phi->ctx->n_cu * 8;
+  long long g = want < cap ? want : cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out) {
+  bc_phi* p = new bc_phi();
+  p->ctx = ctx;
+  p->n_rows = n_rows;
+  p->s = s;
+  p->row_offset = row_offset;
+  p->ntiles = (n_rows + BC_TILE - 1) / BC_TILE;
+  size_t nt = (size_t)(p->ntiles > 0 ? p->ntiles : 1);
+  p->sweep_blocks = bc_sweep_grid(p);
+  hipError_t e = hipSuccess;
+  auto A = [&](void** ptr, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+  };
+  A((void**)&p->tiles, nt * s * BC_TILE * sizeof(double));
+  A((void**)&p->norms, nt * BC_TILE * sizeof(double));
+  A((void**)&p->colsum, (size_t)s * sizeof(double));
+  A((void**)&p->tile_part, nt * s * sizeof(double));
+  A((void**)&p->stats, 4 * sizeof(double));
+  p->stat_blocks = (int)(nt < 512 ? nt : 512);
+  A((void**)&p->part2, (size_t)p->stat_blocks * s * sizeof(double));
+  A((void**)&p->nstat, (size_t)p->stat_blocks * 2 * sizeof(double));
+  A((void**)&p->blk_val, (size_t)p->sweep_blocks * sizeof(double));
+  A((void**)&p->blk_idx, (size_t)p->sweep_blocks * sizeof(long long));
+  A((void**)&p->vbuf, (size_t)2 * s * sizeof(double));
+  A((void**)&p->rec, (size_t)(s + BC_REC_HDR) * sizeof(double));
+  if (e != hipSuccess) {
+    bc_phi_destroy(p);
+    return bc_hip_fail(e, "hipMalloc(phi)", __FILE__, __LINE__);
+  }
+  *out = p;
+  return BC_OK;
+}
+
+extern "C" int bc_phi_destroy(bc_phi* p) {
+  if (!p) return BC_OK;
+  void* ptrs[] = {p->tiles, p->norms, p->colsum, p->tile_part, p->stats, p->part2, p->nstat, p->blk_val, p->blk_idx, p->vbuf, p->rec};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  delete p;
+  return BC_OK;
+}
+
+// row-major (rows x s) -> tile layout, plus row norms and per-tile column partial sums.
+// One block per tile; rows are staged through LDS so both sides stay coalesced.
+__global__ __launch_bounds__(256) void k_layout_from_rowmajor(const double* __restrict__ src, long long n_rows, int s,
+                                                             double* __restrict__ tiles, double* __restrict__ norms,
+                                                             double* __restrict__ tile_part) {
+  extern __shared__ double lds[];  // [chunk_k][129]
+  const long long t = blockIdx.x;
+  const long long r0 = t * BC_TILE;
+  const int rows = (int)((n_rows - r0) < BC_TILE ? (n_rows - r0) : BC_TILE);
+  const int KC = 32;  // samples per pass
+  const int tid = threadIdx.x;
+  double nrm = 0.0;   // threads 0..127 own one row each for the norm
+  for (int k0 = 0; k0 < s; k0 += KC) {
+    const int kc = (s - k0) < KC ? (s - k0) : KC;
+    // load rows x kc block: thread -> (row = idx / kc, k = idx % kc), coalesced along k
+    for (int idx = tid; idx < BC_TILE * kc; idx += blockDim.x) {
+      int r = idx / kc, k = idx - r * kc;
+      double v = (r < rows) ? src[(size_t)(r0 + r) * s + k0 + k] : 0.0;
+      lds[k * (BC_TILE + 1) + r] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BC_TILE * kc; idx += blockDim.x) {
+      int k = idx >> 7, r = idx & (BC_TILE - 1);
+      tiles[(size_t)t * s * BC_TILE + (size_t)(k0 + k) * BC_TILE + r] = lds[k * (BC_TILE + 1) + r];
+    }
+    if (tid < BC_TILE) {
+      for (int k = 0; k < kc; ++k) {
+        double v = lds[k * (BC_TILE + 1) + tid];
+        nrm = fma(v, v, nrm);
+      }
+    } else if (tid - BC_TILE < kc) {
+      // threads 128.. : one sample each, column partial over the tile's rows (fixed order)
+      int k = tid - BC_TILE;
+      double acc = 0.0;
+      for (int r = 0; r < BC_TILE; ++r) acc += lds[k * (BC_TILE + 1) + r];
+      tile_part[(size_t)t * s + k0 + k] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid < BC_TILE) norms[r0 + tid] = sqrt(nrm);
+}
+
+// tile layout -> row-major
+__global__ __launch_bounds__(256) void k_layout_to_rowmajor(const double* __restrict__ tiles, long long n_rows, int s,
+                                                           double* __restrict__ dst) {
+  extern __shared__ double lds[];
+  const long long t = blockIdx.x;
+  const long long r0 = t * BC_TILE;
+  const int rows = (int)((n_rows - r0) < BC_TILE ? (n_rows - r0) : BC_TILE);
+  const int KC = 32;
+  const int tid = threadIdx.x;
+  for (int k0 = 0; k0 < s; k0 += KC) {
+    const int kc = (s - k0) < KC ? (s - k0) : KC;
+    for (int idx = tid; idx < BC_TILE * kc; idx += blockDim.x) {
+      int k = idx >> 7, r = idx & (BC_TILE - 1);
+      lds[k * (BC_TILE + 1) + r] = tiles[(size_t)t * s * BC_TILE + (size_t)(k0 + k) * BC_TILE + r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BC_TILE * kc; idx += blockDim.x) {
+      int r = idx / kc, k = idx - r * kc;
+      if (r < rows) dst[(size_t)(r0 + r) * s + k0 + k] = lds[k * (BC_TILE + 1) + r];
+    }
+    __syncthreads();
+  }
+}
+
+// K2 tail, stage 1: block b reduces a fixed contiguous range of tiles (per-tile column
+// partials, row norms) -> part2[b][s], nstat[b][2].  Fixed assignment => deterministic.
+__global__ __launch_bounds__(256) void k_stats_stage1(const double* __restrict__ tile_part, long long ntiles, int s,
+                                                     const double* __restrict__ norms, long long n_rows,
+                                                     long long chunk, double* __restrict__ part2,
+                                                     double* __restrict__ nstat) {
+  __shared__ double red[32];
+  __shared__ double part[256];
+  const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63;
+  const long long t0 = (long long)blockIdx.x * chunk;
+  long long t1 = t0 + chunk;
+  if (t1 > ntiles) t1 = ntiles;
+  for (int k0 = 0; k0 < s; k0 += 64) {
+    const int k = k0 + lane;
+    double acc = 0.0;
+    if (k < s)
+      for (long long t = t0 + g; t < t1; t += 4) acc += tile_part[(size_t)t * s + k];
+    part[tid] = acc;
+    __syncthreads();
+    if (g == 0 && k < s) part2[(size_t)blockIdx.x * s + k] = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
+    __syncthreads();
+  }
+  double ns = 0.0, nz = 0.0;
+  long long r1 = t1 * BC_TILE;
+  if (r1 > n_rows) r1 = n_rows;
+  for (long long r = t0 * BC_TILE + tid; r < r1; r += blockDim.x) {
+    double v = norms[r];
+    ns += v;
+    nz += (v == 0.0) ? 1.0 : 0.0;
+  }
+  ns = bc_block_sum(ns, red);
+  nz = bc_block_sum(nz, red);
+  if (tid == 0) {
+    nstat[2 * blockIdx.x] = ns;
+    nstat[2 * blockIdx.x + 1] = nz;
+  }
+}
+
+// stage 2: single block, partials combined in block order.
+__global__ __launch_bounds__(256) void k_stats_stage2(const double* __restrict__ part2, const double* __restrict__ nstat,
+                                                     int nb, int s, double* __restrict__ colsum,
+                                                     double* __restrict__ stats) {
+  for (int k = threadIdx.x; k < s; k += blockDim.x) {
+    double acc = 0.0;
+    for (int b = 0; b < nb; ++b) acc += part2[(size_t)b * s + k];
+    colsum[k] = acc;
+  }
+  if (threadIdx.x == 0) {
+    double ns = 0.0, nz = 0.0;
+    for (int b = 0; b < nb; ++b) {
+      ns += nstat[2 * b];
+      nz += nstat[2 * b + 1];
+    }
+    stats[0] = ns;
+    stats[1] = nz;
+  }
+}
+
+int bc_phi_finish_stats(bc_phi* p) {
+  bc_ctx* ctx = p->ctx;
+  const int nb = p->stat_blocks;
+  const long long chunk = (p->ntiles + nb - 1) / nb;
+  hipLaunchKernelGGL(k_stats_stage1, dim3(nb), dim3(256), 0, ctx->stream, p->tile_part, (long long)p->ntiles, p->s,
+                     p->norms, (long long)p->n_rows, chunk > 0 ? chunk : 1, p->part2, p->nstat);
+  BC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_stats_stage2, dim3(1), dim3(256), 0, ctx->stream, p->part2, p->nstat, nb, p->s, p->colsum,
+                     p->stats);
+  BC_HIP(hipGetLastError());
+  BC_HIP(hipMemcpyAsync(ctx->pinned, p->stats, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  p->norm_sum = ctx->pinned[0];
+  p->zero_rows = (int64_t)ctx->pinned[1];
+  p->stats_valid = true;
+  return BC_OK;
+}
+
+extern "C" int bc_phi_from_host(bc_ctx* ctx, const double* src, int64_t n_rows, int32_t s, int64_t row_offset,
+                                bc_phi** out) {
+  if (!ctx || !out || n_rows < 0 || s <= 0 || (n_rows > 0 && !src)) {
+    bc_set_error("bc_phi_from_host: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  BC_HIP(hipSetDevice(ctx->device));
+  bc_phi* p = nullptr;
+  int rc = bc_phi_alloc(ctx, n_rows, s, row_offset, &p);
+  if (rc) return rc;
+  if (n_rows > 0) {
+    double* stage = nullptr;
+    size_t bytes = (size_t)n_rows * s * sizeof(double);
+    hipError_t e = hipMalloc((void**)&stage, bytes);
+    if (e != hipSuccess) { bc_phi_destroy(p); return bc_hip_fail(e, "hipMalloc(stage)", __FILE__, __LINE__); }
+    e = hipMemcpyAsync(stage, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      size_t lds = (size_t)32 * (BC_TILE + 1) * sizeof(double);
+      hipLaunchKernelGGL(k_layout_from_rowmajor, dim3((unsigned)p->ntiles), dim3(256), lds, ctx->stream, stage,
+                         (long long)n_rows, s, p->tiles, p->norms, p->tile_part);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) { bc_phi_destroy(p); return bc_hip_fail(e, "upload/layout", __FILE__, __LINE__); }
+  } else {
+    BC_HIP(hipMemsetAsync(p->norms, 0, BC_TILE * sizeof(double), ctx->stream));
+  }
+  rc = bc_phi_finish_stats(p);
+  if (rc) { bc_phi_destroy(p); return rc; }
+  *out = p;
+  return BC_OK;
+}
+
+extern "C" int bc_phi_shape(const bc_phi* p, int64_t* n_rows, int32_t* s, int64_t* row_offset) {
+  if (!p) { bc_set_error("bc_phi_shape: NULL phi"); return BC_INVALID_ARGUMENT; }
+  if (n_rows) *n_rows = p->n_rows;
+  if (s) *s = p->s;
+  if (row_offset) *row_offset = p->row_offset;
+  return BC_OK;
+}
+
+extern "C" int bc_phi_colsum(bc_phi* p, double* out) {
+  if (!p || !out) { bc_set_error("bc_phi_colsum: bad argument"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipMemcpyAsync(out, p->colsum, (size_t)p->s * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+  BC_HIP(hipStreamSynchronize(p->ctx->stream));
+  return BC_OK;
+}
+
+extern "C" int bc_phi_norms(bc_phi* p, double* out) {
+  if (!p || (!out && p->n_rows)) { bc_set_error("bc_phi_norms: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (p->n_rows)
+    BC_HIP(hipMemcpyAsync(out, p->norms, (size_t)p->n_rows * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+  BC_HIP(hipStreamSynchronize(p->ctx->stream));
+  return BC_OK;
+}
+
+extern "C" int bc_phi_norm_stats(bc_phi* p, int64_t* zero_rows, double* norm_sum) {
+  if (!p) { bc_set_error("bc_phi_norm_stats: NULL phi"); return BC_INVALID_ARGUMENT; }
+  if (!p->stats_valid) {
+    int rc = bc_phi_finish_stats(p);
+    if (rc) return rc;
+  }
+  if (zero_rows) *zero_rows = p->zero_rows;
+  if (norm_sum) *norm_sum = p->norm_sum;
+  return BC_OK;
+}
+
+extern "C" int bc_phi_to_host(bc_phi* p, double* out) {
+  if (!p || (!out && p->n_rows)) { bc_set_error("bc_phi_to_host: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (p->n_rows == 0) return BC_OK;
+  bc_ctx* ctx = p->ctx;
+  double* stage = nullptr;
+  size_t bytes = (size_t)p->n_rows * p->s * sizeof(double);
+  BC_HIP(hipMalloc((void**)&stage, bytes));
+  size_t lds = (size_t)32 * (BC_TILE + 1) * sizeof(double);
+  hipLaunchKernelGGL(k_layout_to_rowmajor, dim3((unsigned)p->ntiles), dim3(256), lds, ctx->stream, p->tiles,
+                     (long long)p->n_rows, p->s, stage);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, stage, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(stage);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_phi_to_host", __FILE__, __LINE__);
+  return BC_OK;
+}
+
+__global__ void k_gather_rows(const double* __restrict__ tiles, int s, const long long* __restrict__ idx, long long m,
+                              double* __restrict__ out) {
+  long long j = blockIdx.x;
+  if (j >= m) return;
+  long long r = idx[j];
+  for (int k = threadIdx.x; k < s; k += blockDim.x) out[(size_t)j * s + k] = tiles[bc_tile_off(r, k, s)];
+}
+
+extern "C" int bc_phi_gather_rows(bc_phi* p, const int64_t* local_idx, int64_t m, double* out) {
+  if (!p || m < 0 || (m > 0 && (!local_idx || !out))) { bc_set_error("bc_phi_gather_rows: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (m == 0) return BC_OK;
+  for (int64_t j = 0; j < m; ++j)
+    if (local_idx[j] < 0 || local_idx[j] >= p->n_rows) {
+      bc_set_error("bc_phi_gather_rows: index %lld out of range [0,%lld)", (long long)local_idx[j], (long long)p->n_rows);
+      return BC_INVALID_ARGUMENT;
+    }
+  bc_ctx* ctx = p->ctx;
+  long long* didx = nullptr;
+  double* dout = nullptr;
+  BC_HIP(hipMalloc((void**)&didx, (size_t)m * sizeof(long long)));
+  hipError_t e = hipMalloc((void**)&dout, (size_t)m * p->s * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(didx, local_idx, (size_t)m * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)m), dim3(128), 0, ctx->stream, p->tiles, p->s, didx, (long long)m, dout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)m * p->s * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(didx);
+  if (dout) (void)hipFree(dout);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_phi_gather_rows", __FILE__, __LINE__);
+  return BC_OK;
+}

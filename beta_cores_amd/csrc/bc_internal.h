@@ -1,0 +1,139 @@
+// Internal definitions shared by the HIP translation units of libbeta_cores.
+// gfx950 (MI355X, CDNA4) only: wave = 64 lanes, fp64 throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/beta_cores.h"
+
+#define BC_WAVE 64
+#define BC_TILE BC_TILE_ROWS          // rows per Phi tile
+#define BC_REC_HDR 4                  // candidate record header doubles: score, gidx(bits), norm, valid
+
+void bc_set_error(const char* fmt, ...);
+int bc_hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define BC_HIP(call)                                                        \
+  do {                                                                      \
+    hipError_t _e = (call);                                                 \
+    if (_e != hipSuccess) return bc_hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+struct bc_timer {
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+  double acc_ms = 0.0;     // folded-in time of already collected events
+  int64_t launches = 0;
+};
+
+struct bc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool timing = false;
+  bc_timer timers[3];
+  int n_cu = 256;
+  double* pinned = nullptr;      // small pinned staging area (host)
+  size_t pinned_doubles = 0;
+};
+
+int bc_timer_begin(bc_ctx* ctx, int which);
+int bc_timer_end(bc_ctx* ctx, int which);
+
+struct bc_data {
+  bc_ctx* ctx = nullptr;
+  int64_t n_rows = 0;
+  int32_t dz = 0;
+  double* z = nullptr;           // row-major n_rows x dz
+  bool owned = true;
+};
+
+struct bc_phi {
+  bc_ctx* ctx = nullptr;
+  int64_t n_rows = 0;
+  int32_t s = 0;
+  int64_t row_offset = 0;
+  int64_t ntiles = 0;
+  double* tiles = nullptr;       // [ntiles][s][128]
+  double* norms = nullptr;       // [ntiles*128]
+  double* colsum = nullptr;      // [s]   (valid when stats_valid)
+  double* tile_part = nullptr;   // [ntiles][s] per-tile column partial sums (scratch)
+  double* stats = nullptr;       // device: {norm_sum, zero_rows}
+  double* part2 = nullptr;       // [stat_blocks][s] second-level column partials
+  double* nstat = nullptr;       // [stat_blocks][2]
+  int stat_blocks = 1;
+  bool stats_valid = false;
+  double norm_sum = 0.0;
+  int64_t zero_rows = 0;
+  // scratch for standalone argmax sweeps
+  double* blk_val = nullptr;
+  long long* blk_idx = nullptr;
+  int sweep_blocks = 0;
+  double* vbuf = nullptr;        // [2*s]
+  double* rec = nullptr;         // one candidate record
+};
+
+int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out);
+int bc_phi_finish_stats(bc_phi* phi);   // tile_part -> colsum, norm stats (device), then host copy
+int bc_sweep_grid(const bc_phi* phi);
+
+// ------------------------------------------------------------------ device helpers
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ bool bc_better(double av, long long ai, double bv, long long bi) {
+  // np.argmax semantics: NaN beats everything, first occurrence wins ties.
+  const bool an = av != av, bn = bv != bv;
+  if (an | bn) {
+    if (an & bn) return ai < bi;
+    return an;
+  }
+  if (av > bv) return true;
+  if (av < bv) return false;
+  return ai < bi;
+}
+
+__device__ __forceinline__ long long bc_shfl_down_ll(long long v, int d) {
+  int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);
+  lo = __shfl_down(lo, d, BC_WAVE);
+  hi = __shfl_down(hi, d, BC_WAVE);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+__device__ __forceinline__ void bc_wave_argmax(double& v, long long& i) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    double ov = __shfl_down(v, d, BC_WAVE);
+    long long oi = bc_shfl_down_ll(i, d);
+    if (bc_better(ov, oi, v, i)) { v = ov; i = oi; }
+  }
+}
+
+__device__ __forceinline__ double bc_wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, BC_WAVE);
+  return v;
+}
+
+// block-wide sum, result broadcast to every thread; red must hold >= 17 doubles
+__device__ __forceinline__ double bc_block_sum(double v, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = bc_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    red[16] = t;
+  }
+  __syncthreads();
+  return red[16];
+}
+
+// element (row r, sample k) of a tiled Phi
+__device__ __forceinline__ size_t bc_tile_off(long long r, int k, int s) {
+  return (size_t)(r >> 7) * (size_t)s * BC_TILE + (size_t)k * BC_TILE + (size_t)(r & (BC_TILE - 1));
+}
+
+#endif  // __HIPCC__

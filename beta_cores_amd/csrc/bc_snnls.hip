@@ -1,0 +1,987 @@
+// Sparse-NNLS solver state on the device: the guarded greedy loop of
+// bayesiancoresets/snnls/snnls.py:31-79 run WITHOUT a host round trip per iteration,
+// plus the step-wise (_select / _reweight) protocol of snnls.py:102-106.
+//
+// Per iteration:   K3 sweep (bc_sweep.hip)  ->  k_local_winner  -> [host all-gather when
+// world > 1]  ->  k_step_finish (single block): global winner, closed-form reweight
+// (giga.py:40-64 / frankwolfe.py:19-40), monotone-error guard with revert, the
+// retry-once-then-stop state machine, and the S-vector prep for the next sweep
+// (giga.py:20-30 / frankwolfe.py:16).  All replicated state (sparse w, selected
+// columns, xw = A.w) lives in device memory; every rank runs the identical finish
+// kernel on identical gathered records, so ranks stay bit-identical.
+#include "bc_internal.h"
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev);
+
+struct SnnlsState {
+  long long nnz;        // length of the (idx, val) list, selection order; val may be 0
+  long long npos;       // count(val > 0)  == SparseNNLS.size()
+  long long iter;       // consumed iterations since reset (trace length)
+  long long sel_f;      // last picked global index, -1 if none
+  double sel_score;
+  double sel_norm;
+  double err_cur;       // ||A.w - b||_2 for the current w
+  int skip;             // select_fail | reached_limit : makes the next sweep a no-op
+  int reached_limit;
+  int retried;
+  int select_fail;      // the reference's _select would raise (giga.py:28-29)
+  int sel_valid;
+  int last_status;      // status of the last step-wise call
+  int overflow;         // list capacity exceeded (host bug guard)
+  int pad;
+};
+
+struct SnnlsDev {
+  SnnlsState* st;
+  long long* idx;
+  double* val;
+  double* prev_val;
+  double* cols;       // [cap][s]
+  double* colnorm;    // [cap]
+  long long cap;
+  double* b;
+  double* bn;
+  double* xw;
+  double* xw_prev;
+  double* v;          // sweep vectors: GIGA [s][2], else [s]
+  double* xf;         // picked column
+  const double* cand_all;
+  const double* tiles;
+  const double* norms;
+  long long n_rows, row_offset;
+  long long* tr_f;
+  int* tr_status;
+  double* tr_err;
+  long long tr_cap;
+  double bnorm, tol, norm_sum;
+  int s, world, rec_len;
+};
+
+struct bc_snnls {
+  bc_ctx* ctx = nullptr;
+  bc_phi* phi = nullptr;
+  int alg = 0;
+  SnnlsDev d;
+  // second buffer set for set_weights (swapped in after the rebuild kernel)
+  long long* idx2 = nullptr;
+  double* val2 = nullptr;
+  double* cols2 = nullptr;
+  double* colnorm2 = nullptr;
+  double* cand_send = nullptr;     // this rank's candidate record (S + 4 doubles)
+  bool cand_send_owned = true;     // false once the host bound its own exchange buffers
+  long long nnz_upper = 0;   // host-side upper bound on the list length
+  long long iter_upper = 0;
+};
+
+// ------------------------------------------------------------------ device building blocks (single block)
+__device__ __forceinline__ double dev_dot(const double* a, const double* b, int s, double* red) {
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < s; k += blockDim.x) acc = fma(a[k], b[k], acc);
+  return bc_block_sum(acc, red);
+}
+
+// xw = sum_j val[j] * cols[j], err = ||xw - b||
+__device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
+  const int s = P.s;
+  double e = 0.0;
+  for (int k = threadIdx.x; k < s; k += blockDim.x) {
+    double acc = 0.0;
+    for (long long j = 0; j < S.nnz; ++j) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
+    P.xw[k] = acc;
+    const double d = acc - P.b[k];
+    e += d * d;
+  }
+  e = bc_block_sum(e, red);
+  if (threadIdx.x == 0) {
+    S.err_cur = sqrt(e);
+    long long np = 0;
+    for (long long j = 0; j < S.nnz; ++j) np += (P.val[j] > 0.) ? 1 : 0;
+    S.npos = np;
+  }
+  __syncthreads();
+}
+
+// vectors for the next sweep.  GIGA: giga.py:21-30 ; FW / OMP: residual b - A.w
+template <int ALG>
+__device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
+  const int s = P.s;
+  if (ALG == BC_ALG_GIGA) {
+    double nw = sqrt(dev_dot(P.xw, P.xw, s, red));
+    nw = (nw == 0.) ? 1. : nw;
+    double bd = 0.0;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      const double xn = P.xw[k] / nw;
+      P.v[2 * k + 1] = xn;
+      bd = fma(P.bn[k], xn, bd);
+    }
+    bd = bc_block_sum(bd, red);
+    double cn = 0.0;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      const double c = P.bn[k] - bd * P.v[2 * k + 1];
+      P.v[2 * k] = c;
+      cn = fma(c, c, cn);
+    }
+    cn = sqrt(bc_block_sum(cn, red));
+    const bool fail = cn < P.tol;
+    if (!fail)
+      for (int k = threadIdx.x; k < s; k += blockDim.x) P.v[2 * k] = P.v[2 * k] / cn;
+    if (threadIdx.x == 0) S.select_fail = fail ? 1 : 0;
+  } else {
+    for (int k = threadIdx.x; k < s; k += blockDim.x) P.v[k] = P.b[k] - P.xw[k];
+    if (threadIdx.x == 0) S.select_fail = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) S.skip = S.select_fail | S.reached_limit;
+  __syncthreads();
+}
+
+// winner over the gathered candidate records: max score, lowest global index on ties.
+// OMP additionally weighs the active set's negative direction (orthopursuit.py:25-35).
+template <int ALG>
+__device__ void dev_pick(const SnnlsDev& P, SnnlsState& S, double* red) {
+  __shared__ int src_rec;
+  __shared__ long long src_list;
+  const int s = P.s;
+  if (threadIdx.x == 0) {
+    double bv = -INFINITY;
+    long long bi = LLONG_MAX;
+    int br = -1;
+    for (int r = 0; r < P.world; ++r) {
+      const double* rec = P.cand_all + (size_t)r * P.rec_len;
+      if (rec[3] == 0.0) continue;
+      const long long gi = reinterpret_cast<const long long*>(rec)[1];
+      if (bc_better(rec[0], gi, bv, bi)) { bv = rec[0]; bi = gi; br = r; }
+    }
+    src_rec = br;
+    src_list = -1;
+    S.sel_valid = br >= 0 ? 1 : 0;
+    S.sel_f = br >= 0 ? bi : -1;
+    S.sel_score = bv;
+    S.sel_norm = br >= 0 ? P.cand_all[(size_t)br * P.rec_len + 2] : 0.0;
+  }
+  __syncthreads();
+  if (ALG == BC_ALG_OMP && S.sel_valid && S.npos > 0) {
+    // neg = max over active j of -(An[:,j] . residual)
+    __shared__ double nv[4];
+    __shared__ long long ni[4], nj[4];
+    double bv = -INFINITY;
+    long long bi = LLONG_MAX, bj = -1;
+    for (long long j = threadIdx.x; j < S.nnz; j += blockDim.x) {
+      if (!(P.val[j] > 0.)) continue;
+      double acc = 0.0;
+      for (int k = 0; k < s; ++k) acc = fma(P.cols[(size_t)j * s + k], P.v[k], acc);
+      const double d = -(acc / P.colnorm[j]);
+      if (bc_better(d, P.idx[j], bv, bi)) { bv = d; bi = P.idx[j]; bj = j; }
+    }
+    // block argmax carrying the list slot
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      const double ov = __shfl_down(bv, dlt, BC_WAVE);
+      const long long oi = bc_shfl_down_ll(bi, dlt), oj = bc_shfl_down_ll(bj, dlt);
+      if (bc_better(ov, oi, bv, bi)) { bv = ov; bi = oi; bj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { nv[wave] = bv; ni[wave] = bi; nj[wave] = bj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nwv = (blockDim.x + 63) >> 6;
+      for (int w = 1; w < nwv; ++w)
+        if (bc_better(nv[w], ni[w], bv, bi)) { bv = nv[w]; bi = ni[w]; bj = nj[w]; }
+      if (!(S.sel_score >= bv)) {   // orthopursuit.py:31 `if pos >= neg` else take the active point
+        S.sel_f = bi;
+        S.sel_score = bv;
+        S.sel_norm = P.colnorm[bj];
+        src_rec = -1;
+        src_list = bj;
+      }
+    }
+    __syncthreads();
+  }
+  if (S.sel_valid) {
+    const double* src = (src_rec >= 0) ? P.cand_all + (size_t)src_rec * P.rec_len + BC_REC_HDR
+                                       : P.cols + (size_t)src_list * s;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) P.xf[k] = src[k];
+  }
+  __syncthreads();
+}
+
+// closed-form step sizes.  Returns 1 when the reference would raise NumericalPrecisionError
+// (w untouched), else 0 with (alpha, beta) set.
+template <int ALG>
+__device__ int dev_step_sizes(const SnnlsDev& P, const SnnlsState& S, double* red, double& alpha, double& beta) {
+  const int s = P.s;
+  if (ALG == BC_ALG_GIGA) {   // giga.py:42-61
+    double nw = sqrt(dev_dot(P.xw, P.xw, s, red));
+    nw = (nw == 0.) ? 1. : nw;
+    const double nf = sqrt(dev_dot(P.xf, P.xf, s, red));
+    double bxf = 0., bxw = 0., xwxf = 0.;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      const double fn = P.xf[k] / nf, wn = P.xw[k] / nw;
+      bxf = fma(P.bn[k], fn, bxf);
+      bxw = fma(P.bn[k], wn, bxw);
+      xwxf = fma(wn, fn, xwxf);
+    }
+    bxf = bc_block_sum(bxf, red);
+    bxw = bc_block_sum(bxw, red);
+    xwxf = bc_block_sum(xwxf, red);
+    const double gA = bxf - bxw * xwxf;
+    const double gB = bxw - bxf * xwxf;
+    if (gA <= 0. || gB < 0.) return 1;
+    const double a = gB / (gA + gB) / nw;
+    const double b = gA / (gA + gB) / nf;
+    double nx = 0.;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      const double x = a * P.xw[k] + b * P.xf[k];
+      nx = fma(x, x, nx);
+    }
+    nx = sqrt(bc_block_sum(nx, red));
+    double xb = 0.;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      const double x = a * P.xw[k] + b * P.xf[k];
+      xb = fma(x / nx, P.bn[k], xb);
+    }
+    xb = bc_block_sum(xb, red);
+    const double scale = P.bnorm / nx * xb;
+    alpha = a * scale;
+    beta = b * scale;
+    return 0;
+  } else {                    // frankwolfe.py:20-37
+    const double nf = S.sel_norm;
+    if (S.npos == 0) {
+      alpha = 0.;
+      beta = P.norm_sum / nf;
+      return 0;
+    }
+    const double c = P.norm_sum / nf;
+    double num = 0., den = 0.;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      const double d = c * P.xf[k] - P.xw[k];
+      num = fma(d, P.b[k] - P.xw[k], num);
+      den = fma(d, d, den);
+    }
+    num = bc_block_sum(num, red);
+    den = bc_block_sum(den, red);
+    if (num < 0. || den == 0. || num > den) return 1;
+    alpha = 1. - num / den;
+    beta = c * num / den;
+    return 0;
+  }
+}
+
+// w = alpha*w ; w[f] = max(0, w[f] + beta)   (giga.py:63-64, frankwolfe.py:39-40)
+__device__ void dev_apply(const SnnlsDev& P, SnnlsState& S, double alpha, double beta) {
+  __shared__ long long slot;
+  const int s = P.s;
+  const long long f = S.sel_f;
+  for (long long j = threadIdx.x; j < S.nnz; j += blockDim.x) P.val[j] = alpha * P.val[j];
+  if (threadIdx.x == 0) {
+    long long at = -1;
+    for (long long j = 0; j < S.nnz; ++j)
+      if (P.idx[j] == f) { at = j; break; }
+    slot = at;
+  }
+  __syncthreads();
+  long long at = slot;
+  if (at >= 0) {
+    if (threadIdx.x == 0) {
+      const double nv = P.val[at] + beta;
+      P.val[at] = nv > 0. ? nv : 0.;
+    }
+  } else {
+    const double nv = (0. + beta) > 0. ? (0. + beta) : 0.;
+    if (nv > 0.) {
+      if (S.nnz < P.cap) {
+        at = S.nnz;
+        for (int k = threadIdx.x; k < s; k += blockDim.x) P.cols[(size_t)at * s + k] = P.xf[k];
+        if (threadIdx.x == 0) {
+          P.idx[at] = f;
+          P.val[at] = nv;
+          P.colnorm[at] = S.sel_norm;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) S.nnz = at + 1;
+      } else if (threadIdx.x == 0) {
+        S.overflow = 1;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void dev_trace(const SnnlsDev& P, SnnlsState& S, long long f, int status) {
+  if (threadIdx.x == 0) {
+    if (S.iter < P.tr_cap) {
+      P.tr_f[S.iter] = f;
+      P.tr_status[S.iter] = status;
+      P.tr_err[S.iter] = S.err_cur;
+    }
+    S.iter += 1;
+  }
+}
+
+// ------------------------------------------------------------------ kernels (grid = 1 block)
+template <int ALG>
+__global__ __launch_bounds__(256) void k_prep(SnnlsDev P, int reset_retry) {
+  __shared__ SnnlsState S;
+  __shared__ double red[32];
+  if (threadIdx.x == 0) {
+    S = *P.st;
+    if (reset_retry) S.retried = 0;
+  }
+  __syncthreads();
+  dev_prep<ALG>(P, S, red);
+  if (threadIdx.x == 0) *P.st = S;
+}
+
+// one guarded greedy iteration, snnls.py:41-74
+template <int ALG>
+__global__ __launch_bounds__(256) void k_step_finish(SnnlsDev P) {
+  __shared__ SnnlsState S;
+  __shared__ double red[32];
+  __shared__ int sh_fail;
+  if (threadIdx.x == 0) S = *P.st;
+  __syncthreads();
+  if (S.reached_limit) return;                       // snnls.py:32-34 / :73-74
+  const int s = P.s;
+  const bool guard = S.npos > 0;                     // snnls.py:44-45 (check_error_monotone is True for GIGA/FW)
+  int fail = S.select_fail;                          // _select raised
+  long long f = -1;
+  if (!fail) {
+    dev_pick<ALG>(P, S, red);
+    if (!S.sel_valid) fail = 1;
+    f = S.sel_f;
+  }
+  if (!fail) {
+    double alpha = 0., beta = 0.;
+    fail = dev_step_sizes<ALG>(P, S, red, alpha, beta);
+    if (!fail) {
+      // keep what is needed to revert (snnls.py:46-47)
+      const long long nnz0 = S.nnz, npos0 = S.npos;
+      const double err0 = S.err_cur;
+      for (long long j = threadIdx.x; j < nnz0; j += blockDim.x) P.prev_val[j] = P.val[j];
+      for (int k = threadIdx.x; k < s; k += blockDim.x) P.xw_prev[k] = P.xw[k];
+      __syncthreads();
+      dev_apply(P, S, alpha, beta);
+      dev_xw_err(P, S, red);
+      if (guard) {
+        if (S.err_cur > err0) {                      // snnls.py:58-61
+          for (long long j = threadIdx.x; j < nnz0; j += blockDim.x) P.val[j] = P.prev_val[j];
+          for (int k = threadIdx.x; k < s; k += blockDim.x) P.xw[k] = P.xw_prev[k];
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            S.nnz = nnz0;
+            S.npos = npos0;
+            S.err_cur = err0;
+          }
+          fail = 1;
+        } else if (threadIdx.x == 0) {
+          S.retried = 0;                             // snnls.py:62
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (fail) {                                      // snnls.py:63-72
+      if (S.retried) S.reached_limit = 1;
+      else S.retried = 1;
+    }
+    sh_fail = fail;
+  }
+  __syncthreads();
+  dev_trace(P, S, f, sh_fail);
+  __syncthreads();
+  dev_prep<ALG>(P, S, red);
+  if (threadIdx.x == 0) *P.st = S;
+}
+
+template <int ALG>
+__global__ __launch_bounds__(256) void k_pick(SnnlsDev P) {
+  __shared__ SnnlsState S;
+  __shared__ double red[32];
+  if (threadIdx.x == 0) S = *P.st;
+  __syncthreads();
+  if (!S.select_fail) dev_pick<ALG>(P, S, red);
+  if (threadIdx.x == 0) {
+    S.last_status = S.select_fail ? BC_NUMERICAL_PRECISION : (S.sel_valid ? BC_OK : BC_INVALID_ARGUMENT);
+    *P.st = S;
+  }
+}
+
+// step-wise _reweight(f): no guard here, the host loop owns it (snnls.py:53-61)
+template <int ALG>
+__global__ __launch_bounds__(256) void k_reweight(SnnlsDev P, long long f) {
+  __shared__ SnnlsState S;
+  __shared__ double red[32];
+  __shared__ int found;
+  const int s = P.s;
+  if (threadIdx.x == 0) {
+    S = *P.st;
+    int fd = 0;   // 0: not found, 1: xf already holds it, 2+r: record r, -1: local shard
+    if (S.sel_valid && S.sel_f == f) fd = 1;
+    if (!fd)
+      for (int r = 0; r < P.world; ++r) {
+        const double* rec = P.cand_all + (size_t)r * P.rec_len;
+        if (rec[3] != 0.0 && reinterpret_cast<const long long*>(rec)[1] == f) { fd = 2 + r; break; }
+      }
+    if (!fd && f >= P.row_offset && f < P.row_offset + P.n_rows) fd = -1;
+    found = fd;
+  }
+  __syncthreads();
+  if (found == 0) {
+    if (threadIdx.x == 0) { S.last_status = BC_INVALID_ARGUMENT; *P.st = S; }
+    return;
+  }
+  if (found >= 2) {
+    const double* rec = P.cand_all + (size_t)(found - 2) * P.rec_len;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) P.xf[k] = rec[BC_REC_HDR + k];
+    if (threadIdx.x == 0) S.sel_norm = rec[2];
+  } else if (found == -1) {
+    const long long r = f - P.row_offset;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) P.xf[k] = P.tiles[bc_tile_off(r, k, s)];
+    if (threadIdx.x == 0) S.sel_norm = P.norms[r];
+  }
+  if (threadIdx.x == 0) { S.sel_f = f; S.sel_valid = 1; }
+  __syncthreads();
+  double alpha = 0., beta = 0.;
+  const int fail = dev_step_sizes<ALG>(P, S, red, alpha, beta);
+  if (!fail) {
+    dev_apply(P, S, alpha, beta);
+    dev_xw_err(P, S, red);
+  }
+  if (threadIdx.x == 0) {
+    S.last_status = fail ? BC_NUMERICAL_PRECISION : BC_OK;
+    *P.st = S;
+  }
+}
+
+// rebuild the sparse list from (idx, val[, cols]); columns not supplied are looked up in the
+// old list, then in the last candidate records, then in the local shard.
+__global__ __launch_bounds__(256) void k_set_weights(SnnlsDev P, long long n, const long long* __restrict__ nidx,
+                                                    const double* __restrict__ nval, const double* __restrict__ ncols,
+                                                    long long* idx2, double* val2, double* cols2, double* colnorm2) {
+  __shared__ SnnlsState S;
+  __shared__ double red[32];
+  __shared__ int kind;
+  __shared__ long long where;
+  const int s = P.s;
+  if (threadIdx.x == 0) { S = *P.st; S.last_status = BC_OK; }
+  __syncthreads();
+  for (long long j = 0; j < n; ++j) {
+    const long long f = nidx[j];
+    if (threadIdx.x == 0) {
+      int kd = 0;
+      long long w = -1;
+      if (ncols) { kd = 1; }
+      if (!kd)
+        for (long long q = 0; q < S.nnz; ++q)
+          if (P.idx[q] == f) { kd = 2; w = q; break; }
+      if (!kd)
+        for (int r = 0; r < P.world; ++r) {
+          const double* rec = P.cand_all + (size_t)r * P.rec_len;
+          if (rec[3] != 0.0 && reinterpret_cast<const long long*>(rec)[1] == f) { kd = 3; w = r; break; }
+        }
+      if (!kd && f >= P.row_offset && f < P.row_offset + P.n_rows) { kd = 4; w = f - P.row_offset; }
+      if (!kd) S.last_status = BC_INVALID_ARGUMENT;
+      kind = kd;
+      where = w;
+    }
+    __syncthreads();
+    const int kd = kind;
+    const long long w = where;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      double v = 0.0;
+      if (kd == 1) v = ncols[(size_t)j * s + k];
+      else if (kd == 2) v = P.cols[(size_t)w * s + k];
+      else if (kd == 3) v = P.cand_all[(size_t)w * P.rec_len + BC_REC_HDR + k];
+      else if (kd == 4) v = P.tiles[bc_tile_off(w, k, s)];
+      cols2[(size_t)j * s + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double nrm = 0.0;
+      for (int k = 0; k < s; ++k) nrm = fma(cols2[(size_t)j * s + k], cols2[(size_t)j * s + k], nrm);
+      colnorm2[j] = sqrt(nrm);
+      idx2[j] = f;
+      val2[j] = nval[j];
+    }
+    __syncthreads();
+  }
+  // from here on the new buffers are the list
+  SnnlsDev Q = P;
+  Q.idx = idx2;
+  Q.val = val2;
+  Q.cols = cols2;
+  Q.colnorm = colnorm2;
+  if (threadIdx.x == 0) { S.nnz = n; S.sel_valid = 0; }
+  __syncthreads();
+  dev_xw_err(Q, S, red);
+  if (threadIdx.x == 0) *P.st = S;
+}
+
+__global__ void k_reset(SnnlsDev P) {
+  __shared__ double red[32];
+  __shared__ SnnlsState S;
+  if (threadIdx.x == 0) {
+    memset(&S, 0, sizeof(S));
+    S.sel_f = -1;
+  }
+  __syncthreads();
+  dev_xw_err(P, S, red);   // nnz = 0 -> xw = 0, err = ||b||
+  if (threadIdx.x == 0) *P.st = S;
+}
+
+// ------------------------------------------------------------------ host side
+static int fetch_state(bc_snnls* h, SnnlsState* out) {
+  bc_ctx* ctx = h->ctx;
+  BC_HIP(hipMemcpyAsync(ctx->pinned, h->d.st, sizeof(SnnlsState), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(out, ctx->pinned, sizeof(SnnlsState));
+  if (out->overflow) {
+    bc_set_error("bc_snnls: active-list capacity exceeded on device (internal error)");
+    return BC_INVALID_ARGUMENT;
+  }
+  return BC_OK;
+}
+
+static void free_lists(bc_snnls* h) {
+  void* ptrs[] = {h->d.idx, h->d.val, h->d.prev_val, h->d.cols, h->d.colnorm, h->idx2, h->val2, h->cols2, h->colnorm2};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  h->d.idx = h->idx2 = nullptr;
+  h->d.val = h->val2 = h->d.prev_val = nullptr;
+  h->d.cols = h->cols2 = nullptr;
+  h->d.colnorm = h->colnorm2 = nullptr;
+}
+
+static int ensure_capacity(bc_snnls* h, long long need) {
+  if (need <= h->d.cap) return BC_OK;
+  bc_ctx* ctx = h->ctx;
+  long long ncap = std::max<long long>(need, std::max<long long>(256, h->d.cap * 2));
+  const int s = h->d.s;
+  long long *idx = nullptr, *idx2 = nullptr;
+  double *val = nullptr, *pv = nullptr, *cols = nullptr, *cn = nullptr, *val2 = nullptr, *cols2 = nullptr, *cn2 = nullptr;
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+  A((void**)&idx, ncap * sizeof(long long));
+  A((void**)&idx2, ncap * sizeof(long long));
+  A((void**)&val, ncap * sizeof(double));
+  A((void**)&pv, ncap * sizeof(double));
+  A((void**)&val2, ncap * sizeof(double));
+  A((void**)&cn, ncap * sizeof(double));
+  A((void**)&cn2, ncap * sizeof(double));
+  A((void**)&cols, (size_t)ncap * s * sizeof(double));
+  A((void**)&cols2, (size_t)ncap * s * sizeof(double));
+  if (e != hipSuccess) return bc_hip_fail(e, "hipMalloc(active list)", __FILE__, __LINE__);
+  if (h->d.cap > 0) {
+    BC_HIP(hipStreamSynchronize(ctx->stream));
+    BC_HIP(hipMemcpy(idx, h->d.idx, h->d.cap * sizeof(long long), hipMemcpyDeviceToDevice));
+    BC_HIP(hipMemcpy(val, h->d.val, h->d.cap * sizeof(double), hipMemcpyDeviceToDevice));
+    BC_HIP(hipMemcpy(cn, h->d.colnorm, h->d.cap * sizeof(double), hipMemcpyDeviceToDevice));
+    BC_HIP(hipMemcpy(cols, h->d.cols, (size_t)h->d.cap * s * sizeof(double), hipMemcpyDeviceToDevice));
+  }
+  free_lists(h);
+  h->d.idx = idx; h->idx2 = idx2;
+  h->d.val = val; h->d.prev_val = pv; h->val2 = val2;
+  h->d.colnorm = cn; h->colnorm2 = cn2;
+  h->d.cols = cols; h->cols2 = cols2;
+  h->d.cap = ncap;
+  return BC_OK;
+}
+
+static int ensure_trace(bc_snnls* h, long long need) {
+  if (need <= h->d.tr_cap) return BC_OK;
+  long long ncap = std::max<long long>(need, std::max<long long>(1024, h->d.tr_cap * 2));
+  long long* f = nullptr;
+  int* st = nullptr;
+  double* er = nullptr;
+  BC_HIP(hipMalloc((void**)&f, ncap * sizeof(long long)));
+  BC_HIP(hipMalloc((void**)&st, ncap * sizeof(int)));
+  BC_HIP(hipMalloc((void**)&er, ncap * sizeof(double)));
+  if (h->d.tr_cap > 0) {
+    BC_HIP(hipStreamSynchronize(h->ctx->stream));
+    BC_HIP(hipMemcpy(f, h->d.tr_f, h->d.tr_cap * sizeof(long long), hipMemcpyDeviceToDevice));
+    BC_HIP(hipMemcpy(st, h->d.tr_status, h->d.tr_cap * sizeof(int), hipMemcpyDeviceToDevice));
+    BC_HIP(hipMemcpy(er, h->d.tr_err, h->d.tr_cap * sizeof(double), hipMemcpyDeviceToDevice));
+    (void)hipFree(h->d.tr_f); (void)hipFree(h->d.tr_status); (void)hipFree(h->d.tr_err);
+  }
+  h->d.tr_f = f; h->d.tr_status = st; h->d.tr_err = er; h->d.tr_cap = ncap;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_destroy(bc_snnls* h) {
+  if (!h) return BC_OK;
+  (void)hipStreamSynchronize(h->ctx->stream);
+  free_lists(h);
+  void* ptrs[] = {h->d.st, h->d.b, h->d.bn, h->d.xw, h->d.xw_prev, h->d.v, h->d.xf,
+                  h->cand_send_owned ? h->cand_send : nullptr, h->d.tr_f, h->d.tr_status, h->d.tr_err};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+  return BC_OK;
+}
+
+#define LAUNCH1(kern, ...)                                                         \
+  do {                                                                             \
+    hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, h->ctx->stream, __VA_ARGS__);   \
+    BC_HIP(hipGetLastError());                                                     \
+  } while (0)
+
+#define BY_ALG(kern, ...)                                                          \
+  do {                                                                             \
+    if (h->alg == BC_ALG_GIGA) LAUNCH1(kern<BC_ALG_GIGA>, __VA_ARGS__);             \
+    else if (h->alg == BC_ALG_FW) LAUNCH1(kern<BC_ALG_FW>, __VA_ARGS__);            \
+    else LAUNCH1(kern<BC_ALG_OMP>, __VA_ARGS__);                                    \
+  } while (0)
+
+extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int alg, double norm_sum,
+                               int allow_zero_rows, bc_snnls** out) {
+  if (!ctx || !phi || !b || !out || alg < 0 || alg > 2) { bc_set_error("bc_snnls_create: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (phi->ctx != ctx) { bc_set_error("bc_snnls_create: phi belongs to another context"); return BC_INVALID_ARGUMENT; }
+  int64_t zr = 0;
+  int rc = bc_phi_norm_stats(phi, &zr, nullptr);
+  if (rc) return rc;
+  if (zr > 0 && !allow_zero_rows) {
+    bc_set_error("A must not have any 0 columns (%lld zero-norm rows)", (long long)zr);   // giga.py:11-12
+    return BC_INVALID_ARGUMENT;
+  }
+  const int s = phi->s;
+  double bnorm = 0.0;
+  for (int k = 0; k < s; ++k) bnorm += b[k] * b[k];
+  bnorm = sqrt(bnorm);
+  if (alg == BC_ALG_GIGA && bnorm == 0.) {
+    bc_set_error("norm of b must be > 0");   // giga.py:16-17
+    return BC_NUMERICAL_PRECISION;
+  }
+  bc_snnls* h = new bc_snnls();
+  h->ctx = ctx;
+  h->phi = phi;
+  h->alg = alg;
+  memset(&h->d, 0, sizeof(h->d));
+  SnnlsDev& d = h->d;
+  d.s = s;
+  d.world = 1;
+  d.rec_len = s + BC_REC_HDR;
+  d.bnorm = bnorm;
+  d.tol = 1e-12;
+  d.norm_sum = norm_sum;
+  d.tiles = phi->tiles;
+  d.norms = phi->norms;
+  d.n_rows = phi->n_rows;
+  d.row_offset = phi->row_offset;
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+  A((void**)&d.st, sizeof(SnnlsState));
+  A((void**)&d.b, s * sizeof(double));
+  A((void**)&d.bn, s * sizeof(double));
+  A((void**)&d.xw, s * sizeof(double));
+  A((void**)&d.xw_prev, s * sizeof(double));
+  A((void**)&d.v, 2 * s * sizeof(double));
+  A((void**)&d.xf, s * sizeof(double));
+  A((void**)&h->cand_send, d.rec_len * sizeof(double));
+  if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "hipMalloc(snnls)", __FILE__, __LINE__); }
+  d.cand_all = h->cand_send;
+  rc = ensure_capacity(h, 256);
+  if (!rc) rc = ensure_trace(h, 1024);
+  if (rc) { bc_snnls_destroy(h); return rc; }
+  // bn = b / ||b|| element-wise like giga.py:18
+  std::vector<double> tmp(2 * s);
+  for (int k = 0; k < s; ++k) {
+    tmp[k] = b[k];
+    tmp[s + k] = bnorm != 0. ? b[k] / bnorm : 0.;
+  }
+  e = hipMemcpyAsync(d.b, tmp.data(), s * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d.bn, tmp.data() + s, s * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(h->cand_send, 0, d.rec_len * sizeof(double), ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(256), 0, ctx->stream, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "snnls init", __FILE__, __LINE__); }
+  *out = h;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_set_tolerance(bc_snnls* h, double tol) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  h->d.tol = tol;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_record_doubles(const bc_snnls* h, int32_t* n) {
+  if (!h || !n) return BC_INVALID_ARGUMENT;
+  *n = h->d.rec_len;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_bind_exchange(bc_snnls* h, int world, void* cand_send_dev, void* cand_all_dev) {
+  if (!h || world < 1 || (world > 1 && (!cand_send_dev || !cand_all_dev))) {
+    bc_set_error("bc_snnls_bind_exchange: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  if (cand_send_dev && cand_all_dev) {
+    if (h->cand_send_owned && h->cand_send) (void)hipFree(h->cand_send);
+    h->cand_send = (double*)cand_send_dev;      // borrowed (typically torch tensors)
+    h->cand_send_owned = false;
+    h->d.cand_all = (const double*)cand_all_dev;
+  } else {
+    h->d.cand_all = h->cand_send;
+  }
+  h->d.world = world;
+  return BC_OK;
+}
+
+static int mode_of(const bc_snnls* h) { return h->alg == BC_ALG_GIGA ? 0 : 1; }
+
+static int launch_prep(bc_snnls* h, int reset_retry) {
+  BY_ALG(k_prep, h->d, reset_retry);
+  return BC_OK;
+}
+
+static int launch_sweep(bc_snnls* h) {
+  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, h->cand_send);
+}
+
+// ---- fused loop
+extern "C" int bc_snnls_build_begin(bc_snnls* h, int itrs) {
+  if (!h || itrs < 0) { bc_set_error("bc_snnls_build_begin: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (h->alg == BC_ALG_OMP) {
+    bc_set_error("bc_snnls_build*: OrthoPursuit refits with a host NNLS every step; use the step-wise protocol");
+    return BC_INVALID_ARGUMENT;
+  }
+  int rc = ensure_capacity(h, h->nnz_upper + itrs);
+  if (!rc) rc = ensure_trace(h, h->iter_upper + itrs);
+  if (rc) return rc;
+  return launch_prep(h, 1);
+}
+
+extern "C" int bc_snnls_step_local(bc_snnls* h) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  return launch_sweep(h);
+}
+
+extern "C" int bc_snnls_step_finish(bc_snnls* h) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  if (h->alg == BC_ALG_GIGA) LAUNCH1(k_step_finish<BC_ALG_GIGA>, h->d);
+  else LAUNCH1(k_step_finish<BC_ALG_FW>, h->d);
+  h->nnz_upper += 1;
+  h->iter_upper += 1;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* iterations_consumed) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  h->nnz_upper = st.nnz;
+  h->iter_upper = st.iter;
+  if (reached_numeric_limit) *reached_numeric_limit = st.reached_limit;
+  if (iterations_consumed) *iterations_consumed = (int)st.iter;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_build(bc_snnls* h, int itrs, int* reached_numeric_limit) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  if (h->d.world != 1) {
+    bc_set_error("bc_snnls_build: world > 1 needs the host to all-gather between step_local and step_finish");
+    return BC_INVALID_ARGUMENT;
+  }
+  int rc = bc_snnls_build_begin(h, itrs);
+  for (int i = 0; i < itrs && !rc; ++i) {
+    rc = bc_snnls_step_local(h);
+    if (!rc) rc = bc_snnls_step_finish(h);
+  }
+  if (rc) return rc;
+  return bc_snnls_build_end(h, reached_numeric_limit, nullptr);
+}
+
+// ---- step-wise protocol
+extern "C" int bc_snnls_select_local(bc_snnls* h) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  int rc = launch_prep(h, 0);
+  if (rc) return rc;
+  return launch_sweep(h);
+}
+
+extern "C" int bc_snnls_select_pick(bc_snnls* h, int64_t* f) {
+  if (!h || !f) return BC_INVALID_ARGUMENT;
+  BY_ALG(k_pick, h->d);
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  *f = st.sel_f;
+  if (st.last_status == BC_NUMERICAL_PRECISION) bc_set_error("cdirnrm < TOL");   // giga.py:28-29
+  if (st.last_status == BC_INVALID_ARGUMENT) bc_set_error("bc_snnls_select: no selectable row");
+  return st.last_status;
+}
+
+extern "C" int bc_snnls_select(bc_snnls* h, int64_t* f) {
+  if (!h || !f) return BC_INVALID_ARGUMENT;
+  if (h->d.world != 1) {
+    bc_set_error("bc_snnls_select: world > 1: use select_local / all-gather / select_pick");
+    return BC_INVALID_ARGUMENT;
+  }
+  int rc = bc_snnls_select_local(h);
+  if (rc) return rc;
+  return bc_snnls_select_pick(h, f);
+}
+
+extern "C" int bc_snnls_reweight(bc_snnls* h, int64_t f) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  if (h->alg == BC_ALG_OMP) {
+    bc_set_error("bc_snnls_reweight: OrthoPursuit reweights on the host (orthopursuit.py:37-42); use set_weights");
+    return BC_INVALID_ARGUMENT;
+  }
+  int rc = ensure_capacity(h, h->nnz_upper + 1);
+  if (rc) return rc;
+  if (h->alg == BC_ALG_GIGA) LAUNCH1(k_reweight<BC_ALG_GIGA>, h->d, (long long)f);
+  else LAUNCH1(k_reweight<BC_ALG_FW>, h->d, (long long)f);
+  SnnlsState st;
+  rc = fetch_state(h, &st);
+  if (rc) return rc;
+  h->nnz_upper = st.nnz;
+  if (st.last_status == BC_NUMERICAL_PRECISION) bc_set_error("precision loss in the closed-form step");
+  if (st.last_status == BC_INVALID_ARGUMENT) bc_set_error("bc_snnls_reweight: column %lld is not available on this rank", (long long)f);
+  return st.last_status;
+}
+
+extern "C" int bc_snnls_error(bc_snnls* h, double* err) {
+  if (!h || !err) return BC_INVALID_ARGUMENT;
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  *err = st.err_cur;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_size(bc_snnls* h, int64_t* n) {
+  if (!h || !n) return BC_INVALID_ARGUMENT;
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  *n = st.npos;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_weights(bc_snnls* h, int64_t cap, int64_t* idx, double* val, int64_t* n) {
+  if (!h || !n) return BC_INVALID_ARGUMENT;
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  *n = st.nnz;
+  if (st.nnz == 0 || (!idx && !val)) return BC_OK;
+  if (cap < st.nnz) { bc_set_error("bc_snnls_weights: capacity %lld < nnz %lld", (long long)cap, (long long)st.nnz); return BC_INVALID_ARGUMENT; }
+  if (idx) BC_HIP(hipMemcpyAsync(idx, h->d.idx, st.nnz * sizeof(long long), hipMemcpyDeviceToHost, h->ctx->stream));
+  if (val) BC_HIP(hipMemcpyAsync(val, h->d.val, st.nnz * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_columns(bc_snnls* h, int64_t cap, double* cols, int64_t* n) {
+  if (!h || !n) return BC_INVALID_ARGUMENT;
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  *n = st.nnz;
+  if (st.nnz == 0 || !cols) return BC_OK;
+  if (cap < st.nnz) { bc_set_error("bc_snnls_columns: capacity too small"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipMemcpyAsync(cols, h->d.cols, (size_t)st.nnz * h->d.s * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_set_weights(bc_snnls* h, int64_t n, const int64_t* idx, const double* val, const double* cols) {
+  if (!h || n < 0 || (n > 0 && (!idx || !val))) { bc_set_error("bc_snnls_set_weights: bad argument"); return BC_INVALID_ARGUMENT; }
+  bc_ctx* ctx = h->ctx;
+  int rc = ensure_capacity(h, std::max<long long>(n, h->nnz_upper));
+  if (rc) return rc;
+  const int s = h->d.s;
+  long long* didx = nullptr;
+  double *dval = nullptr, *dcols = nullptr;
+  hipError_t e = hipSuccess;
+  if (n > 0) {
+    e = hipMalloc((void**)&didx, n * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&dval, n * sizeof(double));
+    if (e == hipSuccess && cols) e = hipMalloc((void**)&dcols, (size_t)n * s * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, n * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dval, val, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && cols) e = hipMemcpyAsync(dcols, cols, (size_t)n * s * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_set_weights, dim3(1), dim3(256), 0, ctx->stream, h->d, (long long)n, didx, dval, dcols, h->idx2,
+                       h->val2, h->cols2, h->colnorm2);
+    e = hipGetLastError();
+  }
+  SnnlsState st;
+  if (e == hipSuccess) rc = fetch_state(h, &st);
+  if (didx) (void)hipFree(didx);
+  if (dval) (void)hipFree(dval);
+  if (dcols) (void)hipFree(dcols);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_snnls_set_weights", __FILE__, __LINE__);
+  if (rc) return rc;
+  std::swap(h->d.idx, h->idx2);
+  std::swap(h->d.val, h->val2);
+  std::swap(h->d.cols, h->cols2);
+  std::swap(h->d.colnorm, h->colnorm2);
+  h->nnz_upper = n;
+  if (st.last_status != BC_OK) {
+    bc_set_error("bc_snnls_set_weights: a column was not supplied and is not available on this rank");
+    return st.last_status;
+  }
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_reset(bc_snnls* h) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_reset, dim3(1), dim3(256), 0, h->ctx->stream, h->d);
+  BC_HIP(hipGetLastError());
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  h->nnz_upper = 0;
+  h->iter_upper = 0;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_get_flags(bc_snnls* h, int* reached_numeric_limit) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  if (reached_numeric_limit) *reached_numeric_limit = st.reached_limit;
+  return BC_OK;
+}
+
+__global__ void k_set_flag(SnnlsState* st, int reached) {
+  st->reached_limit = reached;
+  st->skip = st->select_fail | reached;
+}
+
+extern "C" int bc_snnls_set_flags(bc_snnls* h, int reached_numeric_limit) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, h->ctx->stream, h->d.st, reached_numeric_limit ? 1 : 0);
+  BC_HIP(hipGetLastError());
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_trace(bc_snnls* h, int64_t cap, int64_t* f, int32_t* status, double* err, int64_t* n) {
+  if (!h || !n) return BC_INVALID_ARGUMENT;
+  SnnlsState st;
+  int rc = fetch_state(h, &st);
+  if (rc) return rc;
+  long long m = std::min<long long>(st.iter, h->d.tr_cap);
+  *n = m;
+  if (m == 0 || (!f && !status && !err)) return BC_OK;
+  if (cap < m) { bc_set_error("bc_snnls_trace: capacity too small"); return BC_INVALID_ARGUMENT; }
+  hipStream_t sm = h->ctx->stream;
+  if (f) BC_HIP(hipMemcpyAsync(f, h->d.tr_f, m * sizeof(long long), hipMemcpyDeviceToHost, sm));
+  if (status) BC_HIP(hipMemcpyAsync(status, h->d.tr_status, m * sizeof(int), hipMemcpyDeviceToHost, sm));
+  if (err) BC_HIP(hipMemcpyAsync(err, h->d.tr_err, m * sizeof(double), hipMemcpyDeviceToHost, sm));
+  BC_HIP(hipStreamSynchronize(sm));
+  return BC_OK;
+}

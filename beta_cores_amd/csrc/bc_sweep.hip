@@ -1,0 +1,231 @@
+// K3: fused score + argmax sweep over the tiled Phi (the per-iteration hot kernel).
+//
+// Replaces, in one streaming pass over Phi:
+//   giga.py:31-38        scorends = An.T.dot([cdir, xw]); mask; sqrt; divide; argmax
+//   frankwolfe.py:16-17  (An.T.dot(residual)).argmax()
+//   orthopursuit.py:18-24 dots = An.T.dot(residual); dots.argmax()
+//   bcores.py:78-81      corrs = vecs.dot(resid)/rownorm/S ; argmax
+//
+// Mapping to the hardware: one 64-lane wave owns one 128-row tile at a time; lane l
+// owns rows 2l, 2l+1 of the tile, so sample k of the tile is one coalesced 1 KiB
+// load (16 B per lane).  The S-vector(s) are wave-uniform and come through the
+// scalar cache.  No LDS and no cross-lane traffic inside the sweep; lanes keep a
+// running (score, row) best and the block reduces once at the end.
+// Algorithmic traffic: 8*S*128 B of Phi + 8*128 B of norms per tile.
+#include "bc_internal.h"
+#include <climits>
+#include <cmath>
+
+struct bc_sweep_args {
+  const double* tiles;
+  const double* norms;
+  const double* v;          // mode 0: [S][2] (cdir, xw) interleaved; mode 1: [S]
+  const int* skip_flag;     // optional device flag: when non-zero the sweep is a no-op
+  long long n_rows;
+  long long ntiles;
+  long long row_offset;
+  double post_div;
+  int s;
+};
+
+template <int MODE>
+__device__ __forceinline__ double bc_row_score(double a0, double a1, double nr, double post_div) {
+  if (MODE == 0) {
+    // giga.py:31-38 on normalised columns
+    const double s0 = a0 / nr, s1 = a1 / nr;
+    const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
+    const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
+    return s0 / den;
+  } else {
+    return a0 / nr / post_div;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sweep(bc_sweep_args a, double* __restrict__ blk_val,
+                                              long long* __restrict__ blk_idx) {
+  __shared__ double sv[4];
+  __shared__ long long si[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double best_v = -INFINITY;
+  long long best_i = LLONG_MAX;
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
+  if (!skip) {
+    const int S = a.s;
+    const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.v);
+    const double* __restrict__ v1 = a.v;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < a.ntiles; t += (long long)gridDim.x * 4) {
+      const double2* __restrict__ p = reinterpret_cast<const double2*>(a.tiles + (size_t)t * S * BC_TILE) + lane;
+      double a00 = 0., a01 = 0., a10 = 0., a11 = 0.;
+      int k = 0;
+      constexpr int U = 10;
+      for (; k + U <= S; k += U) {
+        double2 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = p[(size_t)(k + u) * 64];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (MODE == 0) {
+            const double2 vv = v2[k + u];
+            a00 = fma(x[u].x, vv.x, a00);
+            a01 = fma(x[u].x, vv.y, a01);
+            a10 = fma(x[u].y, vv.x, a10);
+            a11 = fma(x[u].y, vv.y, a11);
+          } else {
+            const double vv = v1[k + u];
+            a00 = fma(x[u].x, vv, a00);
+            a10 = fma(x[u].y, vv, a10);
+          }
+        }
+      }
+      for (; k < S; ++k) {
+        const double2 x = p[(size_t)k * 64];
+        if (MODE == 0) {
+          const double2 vv = v2[k];
+          a00 = fma(x.x, vv.x, a00);
+          a01 = fma(x.x, vv.y, a01);
+          a10 = fma(x.y, vv.x, a10);
+          a11 = fma(x.y, vv.y, a11);
+        } else {
+          const double vv = v1[k];
+          a00 = fma(x.x, vv, a00);
+          a10 = fma(x.y, vv, a10);
+        }
+      }
+      const long long r = t * BC_TILE + 2 * lane;
+      const double2 nr = reinterpret_cast<const double2*>(a.norms)[(size_t)t * 64 + lane];
+      if (r < a.n_rows && nr.x != 0.) {
+        const double sc = bc_row_score<MODE>(a00, a01, nr.x, a.post_div);
+        const long long gi = a.row_offset + r;
+        if (bc_better(sc, gi, best_v, best_i)) { best_v = sc; best_i = gi; }
+      }
+      if (r + 1 < a.n_rows && nr.y != 0.) {
+        const double sc = bc_row_score<MODE>(a10, a11, nr.y, a.post_div);
+        const long long gi = a.row_offset + r + 1;
+        if (bc_better(sc, gi, best_v, best_i)) { best_v = sc; best_i = gi; }
+      }
+    }
+  }
+  bc_wave_argmax(best_v, best_i);
+  if (lane == 0) { sv[wave] = best_v; si[wave] = best_i; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bc_better(sv[w], si[w], best_v, best_i)) { best_v = sv[w]; best_i = si[w]; }
+    blk_val[blockIdx.x] = best_v;
+    blk_idx[blockIdx.x] = best_i;
+  }
+}
+
+// Reduce the per-block candidates to the local winner and emit its candidate record:
+//   rec[0] = score, rec[1] = global index (int64 bits), rec[2] = row norm, rec[3] = 1.0 if valid,
+//   rec[4..4+S) = Phi[row, :]  (the un-normalised column A[:, f])
+__global__ __launch_bounds__(256) void k_local_winner(const double* __restrict__ blk_val,
+                                                     const long long* __restrict__ blk_idx, int nblk,
+                                                     const double* __restrict__ tiles,
+                                                     const double* __restrict__ norms, int s, long long row_offset,
+                                                     const int* skip_flag, double* __restrict__ rec) {
+  __shared__ double sv[4];
+  __shared__ long long si[4];
+  __shared__ long long win;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double bv = -INFINITY;
+  long long bi = LLONG_MAX;
+  const bool skip = skip_flag != nullptr && *skip_flag != 0;
+  if (!skip)
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x)
+      if (bc_better(blk_val[i], blk_idx[i], bv, bi)) { bv = blk_val[i]; bi = blk_idx[i]; }
+  bc_wave_argmax(bv, bi);
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    const bool valid = bi != LLONG_MAX;
+    rec[0] = bv;
+    reinterpret_cast<long long*>(rec)[1] = valid ? bi : -1;
+    rec[2] = valid ? norms[bi - row_offset] : 0.0;
+    rec[3] = valid ? 1.0 : 0.0;
+    win = valid ? bi - row_offset : -1;
+  }
+  __syncthreads();
+  const long long r = win;
+  for (int k = threadIdx.x; k < s; k += blockDim.x) rec[BC_REC_HDR + k] = (r >= 0) ? tiles[bc_tile_off(r, k, s)] : 0.0;
+}
+
+// host-side launcher shared by bc_phi_argmax and the solver loop
+int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev) {
+  bc_ctx* ctx = p->ctx;
+  bc_sweep_args a;
+  a.tiles = p->tiles;
+  a.norms = p->norms;
+  a.v = v_dev;
+  a.skip_flag = skip_flag;
+  a.n_rows = p->n_rows;
+  a.ntiles = p->ntiles;
+  a.row_offset = p->row_offset;
+  a.post_div = post_div;
+  a.s = p->s;
+  int rc = bc_timer_begin(ctx, 0);
+  if (rc) return rc;
+  if (mode == 0)
+    hipLaunchKernelGGL(k_sweep<0>, dim3(p->sweep_blocks), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
+  else
+    hipLaunchKernelGGL(k_sweep<1>, dim3(p->sweep_blocks), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
+  BC_HIP(hipGetLastError());
+  rc = bc_timer_end(ctx, 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_local_winner, dim3(1), dim3(256), 0, ctx->stream, p->blk_val, p->blk_idx, p->sweep_blocks,
+                     p->tiles, p->norms, p->s, (long long)p->row_offset, skip_flag, rec_dev);
+  BC_HIP(hipGetLastError());
+  return BC_OK;
+}
+
+extern "C" int bc_phi_argmax(bc_phi* p, int mode, const double* v, double post_div, int64_t* best, double* score) {
+  if (!p || !v || (mode != 0 && mode != 1)) { bc_set_error("bc_phi_argmax: bad argument"); return BC_INVALID_ARGUMENT; }
+  bc_ctx* ctx = p->ctx;
+  const size_t nv = (size_t)(mode == 0 ? 2 : 1) * p->s;
+  BC_HIP(hipMemcpyAsync(p->vbuf, v, nv * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = bc_launch_sweep(p, mode, p->vbuf, post_div, nullptr, p->rec);
+  if (rc) return rc;
+  BC_HIP(hipMemcpyAsync(ctx->pinned, p->rec, BC_REC_HDR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  if (best) *best = reinterpret_cast<long long*>(ctx->pinned)[1];
+  if (score) *score = ctx->pinned[0];
+  return BC_OK;
+}
+
+// scores[i] = Phi[i,:].v  (test / debugging aid; same access pattern as the sweep)
+__global__ __launch_bounds__(256) void k_matvec(const double* __restrict__ tiles, const double* __restrict__ v, int s,
+                                               long long ntiles, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
+    const double2* __restrict__ p = reinterpret_cast<const double2*>(tiles + (size_t)t * s * BC_TILE) + lane;
+    double a0 = 0., a1 = 0.;
+    for (int k = 0; k < s; ++k) {
+      const double2 x = p[(size_t)k * 64];
+      a0 = fma(x.x, v[k], a0);
+      a1 = fma(x.y, v[k], a1);
+    }
+    reinterpret_cast<double2*>(out)[(size_t)t * 64 + lane] = make_double2(a0, a1);
+  }
+}
+
+extern "C" int bc_phi_matvec(bc_phi* p, const double* v, double* out) {
+  if (!p || !v || (!out && p->n_rows)) { bc_set_error("bc_phi_matvec: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (p->n_rows == 0) return BC_OK;
+  bc_ctx* ctx = p->ctx;
+  double* dout = nullptr;
+  BC_HIP(hipMalloc((void**)&dout, (size_t)p->ntiles * BC_TILE * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(p->vbuf, v, (size_t)p->s * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_matvec, dim3(p->sweep_blocks), dim3(256), 0, ctx->stream, p->tiles, p->vbuf, p->s,
+                       (long long)p->ntiles, dout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)p->n_rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dout);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_phi_matvec", __FILE__, __LINE__);
+  return BC_OK;
+}

@@ -1,0 +1,194 @@
+"""Thin RAII wrappers over the C-ABI handles: one Context per process/GPU, data rows
+resident on the device (DeviceData) and the tiled Phi matrix (DevicePhi).
+
+DevicePhi quacks enough like the N x S ndarray `vecs` of hilbert.py:11-17 /
+bcores.py:44 for the drop-in classes to work without copying it to the host:
+`.shape`, `.T` (what the solvers take as A), `.sum(axis=0)` (= b), `np.asarray()`.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _native as N
+
+_default_ctx = None
+
+
+def _as_f64(a, what):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if not a.flags['C_CONTIGUOUS']:
+        raise ValueError(what + ' must be convertible to a C-contiguous float64 array')
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class Context:
+    """One GPU, one stream.  `stream`: integer hipStream_t handle to launch on (pass
+    torch.cuda.current_stream().cuda_stream when collectives issued through
+    torch.distributed must order with the kernels); None = library-owned stream."""
+
+    def __init__(self, device=None, stream=None):
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0')) if os.environ.get('BC_DEVICE') is None \
+                else int(os.environ['BC_DEVICE'])
+        h = C.c_void_p()
+        N.call('bc_ctx_create', int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        self.h = h
+        self.device = int(device)
+        self._fin = weakref.finalize(self, N.load().bc_ctx_destroy, h)
+
+    def sync(self):
+        N.call('bc_ctx_sync', self.h)
+
+    def enable_timing(self, on=True):
+        N.call('bc_ctx_enable_timing', self.h, 1 if on else 0)
+
+    def kernel_time(self, which):
+        """(total_ms, launches) of kernel class `which` (0 = K3 sweep, 1 = K1 projection, 2 = K4 gram)."""
+        ms, n = C.c_double(), C.c_int64()
+        N.call('bc_ctx_kernel_time', self.h, int(which), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        N.call('bc_ctx_kernel_time_reset', self.h)
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class DeviceData:
+    """Data rows Z (n x dz, row-major float64) resident in HBM."""
+
+    def __init__(self, z=None, ctx=None, device_ptr=None, shape=None, keepalive=None, row_offset=0):
+        self.ctx = ctx or default_context()
+        self.row_offset = int(row_offset)     # global index of row 0 when the rows are one shard of a larger set
+        h = C.c_void_p()
+        if device_ptr is not None:
+            n, dz = shape
+            N.call('bc_data_from_device', self.ctx.h, C.c_void_p(device_ptr), int(n), int(dz), C.byref(h))
+            self._keep = keepalive
+        else:
+            z = np.atleast_2d(z)
+            z = _as_f64(z, 'data')
+            n, dz = z.shape
+            N.call('bc_data_from_host', self.ctx.h, _ptr(z), int(n), int(dz), C.byref(h))
+        self.h = h
+        self.shape = (int(n), int(dz))
+        self._fin = weakref.finalize(self, N.load().bc_data_destroy, h)
+
+    @classmethod
+    def from_torch(cls, t, ctx=None, row_offset=0):
+        """Borrow a contiguous float64 CUDA tensor (kept alive by this object)."""
+        assert t.is_cuda and t.is_contiguous() and str(t.dtype) == 'torch.float64' and t.dim() == 2
+        return cls(ctx=ctx, device_ptr=t.data_ptr(), shape=tuple(t.shape), keepalive=t, row_offset=row_offset)
+
+
+class _PhiT:
+    """`vecs.T`: the S x N view handed to the solvers as A (hilbert.py:17)."""
+
+    def __init__(self, phi):
+        self.phi = phi
+        self.shape = (phi.shape[1], phi.shape[0])
+        self.size = phi.shape[0] * phi.shape[1]
+
+    @property
+    def T(self):
+        return self.phi
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.phi).T
+
+
+class DevicePhi:
+    """N x S matrix of row-centred (beta-)log-likelihoods in the tiled HBM layout."""
+
+    def __init__(self, handle, ctx, owner=True):
+        self.h = handle
+        self.ctx = ctx
+        n, s, off = C.c_int64(), C.c_int32(), C.c_int64()
+        N.call('bc_phi_shape', handle, C.byref(n), C.byref(s), C.byref(off))
+        self.shape = (n.value, s.value)
+        self.row_offset = off.value
+        self.size = n.value * s.value
+        self._fin = weakref.finalize(self, N.load().bc_phi_destroy, handle) if owner else None
+
+    # -- construction
+    @classmethod
+    def from_host(cls, phi, ctx=None, row_offset=0):
+        ctx = ctx or default_context()
+        phi = np.atleast_2d(phi)
+        phi = _as_f64(phi, 'Phi')
+        h = C.c_void_p()
+        N.call('bc_phi_from_host', ctx.h, _ptr(phi), int(phi.shape[0]), int(phi.shape[1]), int(row_offset), C.byref(h))
+        return cls(h, ctx)
+
+    # -- ndarray-like surface
+    @property
+    def T(self):
+        return _PhiT(self)
+
+    def sum(self, axis=None):
+        if axis != 0:
+            raise NotImplementedError('DevicePhi.sum supports axis=0 only (b = Phi^T 1)')
+        return self.colsum()
+
+    def __array__(self, dtype=None, copy=None):
+        return self.to_host()
+
+    def __len__(self):
+        return self.shape[0]
+
+    # -- device queries
+    def colsum(self):
+        out = np.empty(self.shape[1])
+        N.call('bc_phi_colsum', self.h, _ptr(out))
+        return out
+
+    def norms(self):
+        out = np.empty(self.shape[0])
+        N.call('bc_phi_norms', self.h, _ptr(out))
+        return out
+
+    def norm_stats(self):
+        z, s = C.c_int64(), C.c_double()
+        N.call('bc_phi_norm_stats', self.h, C.byref(z), C.byref(s))
+        return z.value, s.value
+
+    def to_host(self):
+        out = np.empty(self.shape)
+        N.call('bc_phi_to_host', self.h, _ptr(out))
+        return out
+
+    def rows(self, local_idx):
+        idx = np.ascontiguousarray(local_idx, dtype=np.int64).ravel()
+        out = np.empty((idx.shape[0], self.shape[1]))
+        N.call('bc_phi_gather_rows', self.h, _ptr(idx), int(idx.shape[0]), _ptr(out))
+        return out
+
+    def matvec(self, v):
+        v = _as_f64(v, 'v')
+        out = np.empty(self.shape[0])
+        N.call('bc_phi_matvec', self.h, _ptr(v), _ptr(out))
+        return out
+
+    def argmax(self, v, mode, post_div=1.0):
+        """One fused K3 sweep. mode 0: v = (S,2) [cdir, xw] -> GIGA score; mode 1: v = (S,) -> Phi.v/norm/post_div.
+        Returns (global row index or -1, score)."""
+        v = _as_f64(v, 'v')
+        best, score = C.c_int64(), C.c_double()
+        N.call('bc_phi_argmax', self.h, int(mode), _ptr(v), float(post_div), C.byref(best), C.byref(score))
+        return best.value, score.value

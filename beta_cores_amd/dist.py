@@ -1,0 +1,104 @@
+"""Row sharding over ranks (one process per GPU) and the per-step candidate exchange.
+
+The N axis shards naturally: rank r owns the contiguous rows
+[bounds[r], bounds[r+1]) of Z / Phi; Theta, b, xw and the sparse weight list are
+replicated.  The only data-path collective per greedy step is ONE all-gather of a
+(S + 4)-double candidate record per rank (score, global index, row norm, valid flag,
+the un-normalised column), after which every rank runs the identical device finish
+kernel -- so the replicated state stays bit-identical and independent of the world
+size.  torch.distributed is the transport: backend "nccl" (= RCCL over xGMI) gathers
+the device buffers in place; backend "gloo" (CPU tests, or several ranks sharing one
+GPU) stages the record through pinned host tensors.
+"""
+import numpy as np
+
+
+def shard_bounds(n_rows, world, align=128):
+    """Contiguous row ranges, sizes equal up to one tile: shard starts are multiples of
+    `align` (the Phi tile height) so that tiles never straddle ranks."""
+    tiles = (n_rows + align - 1) // align
+    per, extra = divmod(tiles, world)
+    bounds = [0]
+    for r in range(world):
+        bounds.append(min(n_rows, bounds[-1] + (per + (1 if r < extra else 0)) * align))
+    bounds[-1] = n_rows
+    return bounds
+
+
+class _Exchange:
+    """Send/recv buffers for the per-step record all-gather."""
+
+    def __init__(self, comm, rec_len, ctx):
+        import torch
+        self.comm = comm
+        self.torch = torch
+        self.rec_len = rec_len
+        self.ctx = ctx
+        dev = torch.device('cuda', ctx.device)
+        self.send = torch.zeros(rec_len, dtype=torch.float64, device=dev)
+        self.all = torch.zeros(comm.world * rec_len, dtype=torch.float64, device=dev)
+        self.send_ptr = self.send.data_ptr()
+        self.all_ptr = self.all.data_ptr()
+        self.on_device = comm.backend == 'nccl'
+        if not self.on_device:
+            self.h_send = torch.zeros(rec_len, dtype=torch.float64).pin_memory()
+            self.h_all = torch.zeros(comm.world * rec_len, dtype=torch.float64).pin_memory()
+
+    def all_gather(self):
+        dist = self.torch.distributed
+        if self.on_device:
+            # RCCL: enqueued behind the sweep on the same (torch current) stream, no host sync
+            dist.all_gather_into_tensor(self.all, self.send, group=self.comm.group)
+        else:
+            self.ctx.sync()
+            self.h_send.copy_(self.send)
+            dist.all_gather_into_tensor(self.h_all, self.h_send, group=self.comm.group)
+            self.all.copy_(self.h_all)
+            self.torch.cuda.current_stream(self.ctx.device).synchronize()
+
+
+class ShardComm:
+    """torch.distributed process group + the shard arithmetic the solvers need."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('ShardComm needs an initialised torch.distributed process group')
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    # -- small replicated reductions (host values, deterministic rank order)
+    def gather_host(self, arr):
+        """all-gather a small host float64 array -> (world, ...) ndarray, via a device tensor for nccl."""
+        import torch
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        t = torch.from_numpy(arr.copy())
+        if self.backend == 'nccl':
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def sum_in_rank_order(self, arr):
+        """Sum over ranks in rank order: the same bits on every rank (and on re-runs)."""
+        parts = self.gather_host(arr)
+        acc = parts[0].copy()
+        for r in range(1, self.world):
+            acc = acc + parts[r]
+        return acc
+
+    def total_rows(self, n_local):
+        return int(self.sum_in_rank_order(np.array([float(n_local)]))[0])
+
+    def row_offset(self, n_local):
+        sizes = self.gather_host(np.array([float(n_local)]))[:, 0]
+        return int(sizes[:self.rank].sum())
+
+    def make_exchange(self, rec_len, ctx):
+        return _Exchange(self, rec_len, ctx)
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)

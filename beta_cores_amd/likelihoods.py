@@ -1,0 +1,73 @@
+"""Likelihood models evaluated by the K1 projection kernel.
+
+Each class names one formula of the reference's examples/common/*.py, holds its
+hyper-parameters and knows how to lay them out for bc_project (include/beta_cores.h).
+`theta_for_device(samples)` returns the S x D matrix the contraction runs against
+(for the Gaussian-location model that is Theta.Siginv, so the kernel's GEMM gives
+x^T Siginv theta directly).
+"""
+import numpy as np
+
+LINREG_LL, LINREG_BETA, LOGISTIC_LL, LOGISTIC_BETA, GAUSS_LL, GAUSS_BETA, GAUSS_BETA_GRAD = range(7)
+
+
+class _Model:
+    model_id = None
+    beta_model_id = None
+    beta_grad_model_id = None
+
+    def theta_for_device(self, samples):
+        return np.ascontiguousarray(np.atleast_2d(samples), dtype=np.float64)
+
+    def data_width(self, theta_dim):
+        raise NotImplementedError
+
+
+class LinearRegression(_Model):
+    """Rows z = [x (D), y].  log-lik: model_linreg.py:4-10 == model_neurlinr.py:90-97;
+    beta-likelihood: model_neurlinr.py:102-110."""
+    model_id = LINREG_LL
+    beta_model_id = LINREG_BETA
+
+    def __init__(self, sigsq=1.0):
+        self.sigsq = float(sigsq)
+
+    def params(self, beta=None, grad=False):
+        return np.array([self.sigsq] if beta is None else [self.sigsq, float(beta)])
+
+    def data_width(self, theta_dim):
+        return theta_dim + 1
+
+
+class LogisticRegression(_Model):
+    """Rows z = y*x (D).  log-lik: model_lr.py:72-79; beta-likelihood: model_lr.py:81-86."""
+    model_id = LOGISTIC_LL
+    beta_model_id = LOGISTIC_BETA
+
+    def params(self, beta=None, grad=False):
+        return np.array([] if beta is None else [float(beta)])
+
+    def data_width(self, theta_dim):
+        return theta_dim
+
+
+class GaussianLocation(_Model):
+    """Rows x (d), known covariance.  gaussian.py:7-15 (log-lik), :34-44 (beta-likelihood),
+    :46-62 (d/dbeta)."""
+    model_id = GAUSS_LL
+    beta_model_id = GAUSS_BETA
+    beta_grad_model_id = GAUSS_BETA_GRAD
+
+    def __init__(self, Siginv, logdetSig):
+        self.Siginv = np.ascontiguousarray(Siginv, dtype=np.float64)
+        self.logdetSig = float(logdetSig)
+
+    def params(self, beta=None, grad=False):
+        head = [self.logdetSig] if beta is None else [float(beta), self.logdetSig]
+        return np.concatenate((np.array(head), self.Siginv.ravel()))
+
+    def theta_for_device(self, samples):
+        return np.ascontiguousarray(np.atleast_2d(samples), dtype=np.float64)
+
+    def data_width(self, theta_dim):
+        return theta_dim

@@ -1,0 +1,141 @@
+"""HIP-backed solver engine: the device side of SparseNNLS.
+
+One engine == one bc_snnls handle (this rank's row shard of Phi plus the replicated
+sparse weight state).  `comm` (beta_cores_amd.dist.ShardComm) carries the per-step
+candidate all-gather when the rows are sharded over several ranks/GPUs.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from .. import _native as N
+from ..device import DevicePhi, _PhiT, _ptr, default_context
+
+ALG_IDS = {'giga': N.ALG_GIGA, 'fw': N.ALG_FW, 'omp': N.ALG_OMP}
+
+
+def phi_from_A(A, ctx=None, row_offset=0):
+    """Accept what the reference's solvers accept as A (an S x N array, usually the
+    transposed view `vecs.T` of a C-contiguous N x S array, hilbert.py:17) or a
+    device-resident `DevicePhi.T`, and return a DevicePhi."""
+    if isinstance(A, _PhiT):
+        return A.phi
+    if isinstance(A, DevicePhi):
+        raise ValueError('pass DevicePhi.T (S x N) as A, like the reference passes vecs.T')
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim != 2:
+        raise ValueError('A must be 2-dimensional (S x N)')
+    return DevicePhi.from_host(A.T, ctx=ctx, row_offset=row_offset)   # A.T of vecs.T is the C-contiguous vecs: no copy
+
+
+class HipEngine:
+    def __init__(self, phi, b, alg, norm_sum=None, allow_zero_rows=False, comm=None, tol=1e-12):
+        self.phi = phi
+        self.ctx = phi.ctx
+        self.comm = comm
+        self.s = phi.shape[1]
+        self.n_local = phi.shape[0]
+        self.row_offset = phi.row_offset
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if b.shape != (self.s,):
+            raise ValueError('b must have shape (%d,), got %s' % (self.s, b.shape))
+        if norm_sum is None:
+            norm_sum = phi.norm_stats()[1]
+            if comm is not None and comm.world > 1:
+                norm_sum = comm.sum_in_rank_order(np.array([norm_sum]))[0]
+        h = C.c_void_p()
+        N.call('bc_snnls_create', self.ctx.h, phi.h, _ptr(b), ALG_IDS[alg], float(norm_sum), 1 if allow_zero_rows else 0,
+               C.byref(h))
+        self.h = h
+        self._fin = weakref.finalize(self, N.load().bc_snnls_destroy, h)
+        N.call('bc_snnls_set_tolerance', h, float(tol))
+        self.world = 1 if comm is None else comm.world
+        if self.world > 1:
+            n = C.c_int32()
+            N.call('bc_snnls_record_doubles', h, C.byref(n))
+            self._xchg = comm.make_exchange(n.value, self.ctx)
+            N.call('bc_snnls_bind_exchange', h, self.world, C.c_void_p(self._xchg.send_ptr), C.c_void_p(self._xchg.all_ptr))
+
+    # ---- fused loop (snnls.py:31-79 on the device)
+    def build_fused(self, itrs):
+        lim = C.c_int()
+        if self.world == 1:
+            N.call('bc_snnls_build', self.h, int(itrs), C.byref(lim))
+        else:
+            N.call('bc_snnls_build_begin', self.h, int(itrs))
+            for _ in range(int(itrs)):
+                N.call('bc_snnls_step_local', self.h)
+                self._xchg.all_gather()
+                N.call('bc_snnls_step_finish', self.h)
+            N.call('bc_snnls_build_end', self.h, C.byref(lim), None)
+        return bool(lim.value)
+
+    # ---- step-wise protocol
+    def select(self):
+        f = C.c_int64()
+        if self.world == 1:
+            N.call('bc_snnls_select', self.h, C.byref(f))
+        else:
+            N.call('bc_snnls_select_local', self.h)
+            self._xchg.all_gather()
+            N.call('bc_snnls_select_pick', self.h, C.byref(f))
+        return f.value
+
+    def reweight(self, f):
+        N.call('bc_snnls_reweight', self.h, int(f))
+
+    def error(self):
+        e = C.c_double()
+        N.call('bc_snnls_error', self.h, C.byref(e))
+        return e.value
+
+    def size(self):
+        n = C.c_int64()
+        N.call('bc_snnls_size', self.h, C.byref(n))
+        return n.value
+
+    def sparse_weights(self):
+        n = C.c_int64()
+        N.call('bc_snnls_weights', self.h, 0, None, None, C.byref(n))
+        idx = np.empty(n.value, dtype=np.int64)
+        val = np.empty(n.value)
+        if n.value:
+            N.call('bc_snnls_weights', self.h, n.value, _ptr(idx), _ptr(val), C.byref(n))
+        return idx, val
+
+    def columns(self):
+        n = C.c_int64()
+        N.call('bc_snnls_columns', self.h, 0, None, C.byref(n))
+        cols = np.empty((n.value, self.s))
+        if n.value:
+            N.call('bc_snnls_columns', self.h, n.value, _ptr(cols), C.byref(n))
+        return cols
+
+    def set_sparse_weights(self, idx, val, cols=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        if cols is not None:
+            cols = np.ascontiguousarray(cols, dtype=np.float64)
+        N.call('bc_snnls_set_weights', self.h, int(idx.shape[0]), _ptr(idx), _ptr(val), _ptr(cols) if cols is not None else None)
+
+    def reset(self):
+        N.call('bc_snnls_reset', self.h)
+
+    def get_limit(self):
+        v = C.c_int()
+        N.call('bc_snnls_get_flags', self.h, C.byref(v))
+        return bool(v.value)
+
+    def set_limit(self, flag):
+        N.call('bc_snnls_set_flags', self.h, 1 if flag else 0)
+
+    def trace(self):
+        n = C.c_int64()
+        N.call('bc_snnls_trace', self.h, 0, None, None, None, C.byref(n))
+        f = np.empty(n.value, dtype=np.int64)
+        st = np.empty(n.value, dtype=np.int32)
+        er = np.empty(n.value)
+        if n.value:
+            N.call('bc_snnls_trace', self.h, n.value, _ptr(f), _ptr(st), _ptr(er), C.byref(n))
+        return f, st, er

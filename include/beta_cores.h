@@ -1,0 +1,183 @@
+/*
+ * beta_cores.h -- C ABI of the MI355X (gfx950) sparse-NNLS coreset hot path.
+ *
+ * The reference (dionman/beta-cores, package `bayesiancoresets`) is pure
+ * Python/NumPy and has no FFI of its own; its plug-in boundary is the duck-typed
+ * class protocol  SparseNNLS / Projector / Coreset.  This header is the layer a
+ * maintainer would bind (ctypes stub: INTEGRATION.md) underneath those classes.
+ * Each entry point names the reference call site(s) it replaces.
+ *
+ * Conventions
+ *   - every function returns an int status:
+ *        BC_OK                   0
+ *        BC_NUMERICAL_PRECISION  1   (host raises NumericalPrecisionError,
+ *                                     bayesiancoresets/util/errors.py:1)
+ *        BC_INVALID_ARGUMENT     2   (host raises ValueError)
+ *        < 0                         HIP failure (host raises RuntimeError)
+ *     bc_last_error() returns a thread-local message for the last non-OK status.
+ *   - host pointers are borrowed for the duration of the call only; device
+ *     memory is owned by the handles; handles are not thread-safe.
+ *   - all arithmetic is IEEE double (the reference computes in float64);
+ *     indices are int64 GLOBAL row numbers (row_offset + local row).
+ *   - one context == one GPU == one process (ranks are separate processes;
+ *     the per-step candidate exchange is done by the host with
+ *     torch.distributed/RCCL on the buffers bound with bc_snnls_bind_exchange).
+ *
+ * Phi layout in HBM ("row tiles"): rows are grouped in tiles of 128; inside a
+ * tile the element (row r, sample s) lives at  tile*S*128 + s*128 + (r%128),
+ * so that a 64-lane wavefront reading one sample of one tile issues a single
+ * fully-coalesced 1 KiB load (16 B per lane = two adjacent rows).  Padding rows
+ * of the last tile are zero and have norm 0.
+ */
+#ifndef BETA_CORES_H
+#define BETA_CORES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BC_OK 0
+#define BC_NUMERICAL_PRECISION 1
+#define BC_INVALID_ARGUMENT 2
+
+#define BC_TILE_ROWS 128
+
+/* solver kinds (bayesiancoresets/snnls/__init__.py:1-4) */
+#define BC_ALG_GIGA 0 /* giga.py:6-64 */
+#define BC_ALG_FW 1   /* frankwolfe.py:5-40 */
+#define BC_ALG_OMP 2  /* orthopursuit.py:7-42 (select on device, NNLS refit on host) */
+
+/* likelihood models for bc_project (K1).  params layout per model below. */
+#define BC_MODEL_LINREG_LL 0     /* model_linreg.py:4-10 == model_neurlinr.py:90-97 ; params = {sigsq}          ; Z = [x(D), y] */
+#define BC_MODEL_LINREG_BETA 1   /* model_neurlinr.py:102-110                       ; params = {sigsq, beta}    ; Z = [x(D), y] */
+#define BC_MODEL_LOGISTIC_LL 2   /* model_lr.py:72-79                               ; params = {}               ; Z = y*x (D)   */
+#define BC_MODEL_LOGISTIC_BETA 3 /* model_lr.py:81-86                               ; params = {beta}           ; Z = y*x (D)   */
+#define BC_MODEL_GAUSS_LL 4      /* gaussian.py:7-15  ; params = {logdetSig, Siginv[d*d]}        ; Z = x (d) */
+#define BC_MODEL_GAUSS_BETA 5    /* gaussian.py:34-44 ; params = {beta, logdetSig, Siginv[d*d]}  ; Z = x (d) */
+#define BC_MODEL_GAUSS_BETA_GRAD 6 /* gaussian.py:46-62 ; params as GAUSS_BETA (d/dbeta, projector.py:56-61) */
+
+typedef struct bc_ctx bc_ctx;
+typedef struct bc_data bc_data;
+typedef struct bc_phi bc_phi;
+typedef struct bc_snnls bc_snnls;
+
+/* ---- library / context ------------------------------------------------ */
+int bc_version(void);
+const char* bc_last_error(void);
+/* device: HIP ordinal.  stream: a hipStream_t to launch on (e.g. torch's current
+ * stream so RCCL collectives issued by the host order with the kernels), or NULL
+ * to let the library create its own. */
+int bc_ctx_create(int device, void* stream, bc_ctx** out);
+int bc_ctx_destroy(bc_ctx* ctx);
+int bc_ctx_sync(bc_ctx* ctx);
+/* time (ms) spent inside the dominant kernels since the last reset, measured
+ * with HIP events on the launch stream; which: 0 = K3 score/argmax sweep,
+ * 1 = K1 projection, 2 = K4 XtWX.  launches returns the launch count. */
+int bc_ctx_kernel_time(bc_ctx* ctx, int which, double* total_ms, int64_t* launches);
+int bc_ctx_kernel_time_reset(bc_ctx* ctx);
+int bc_ctx_enable_timing(bc_ctx* ctx, int on);
+
+/* ---- data rows (Z) resident on the device ----------------------------- */
+/* replaces the `data`/`pts` ndarray argument of Projector.project (projector.py:23,51) */
+int bc_data_from_host(bc_ctx* ctx, const double* z_rowmajor, int64_t n_rows, int32_t dz, bc_data** out);
+/* borrow an existing device buffer (row-major n_rows x dz doubles); not freed by destroy */
+int bc_data_from_device(bc_ctx* ctx, const void* z_dev, int64_t n_rows, int32_t dz, bc_data** out);
+int bc_data_destroy(bc_data* d);
+
+/* ---- Phi: the N x S matrix of row-centred (beta-)log-likelihoods ------- */
+/* upload a C-contiguous n_rows x S host array (what `vecs` is at hilbert.py:11-17;
+ * the solver's A = vecs.T is a view of it).  row_offset = global index of row 0. */
+int bc_phi_from_host(bc_ctx* ctx, const double* phi_rowmajor, int64_t n_rows, int32_t s,
+                     int64_t row_offset, bc_phi** out);
+/* K1: Phi = f(Z, Theta[, beta]) - rowmean  (projector.py:24-26, :53-55 + the model
+ * formula named by `model`).  theta: host, S x D row-major.  If *inout is non-NULL
+ * and has the same shape its buffers are reused (BetaCoreset re-projects every
+ * gradient call, bcores.py:141-146). Fuses row norms and column sums (K2). */
+int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+               const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
+int bc_phi_shape(const bc_phi* phi, int64_t* n_rows, int32_t* s, int64_t* row_offset);
+/* b = Phi^T 1 over the local rows (hilbert.py:17 `vecs.sum(axis=0)`, bcores.py:77) */
+int bc_phi_colsum(bc_phi* phi, double* out_s);
+/* row norms sqrt(sum_s Phi[i,s]^2) (giga.py:10, hilbert.py:16, bcores.py:78) */
+int bc_phi_norms(bc_phi* phi, double* out_n);
+/* number of all-zero rows (dropped at hilbert.py:16 / bcores.py:67) and sum of norms (frankwolfe.py:21,24) */
+int bc_phi_norm_stats(bc_phi* phi, int64_t* zero_rows, double* norm_sum);
+int bc_phi_to_host(bc_phi* phi, double* out_rowmajor);
+/* rows by LOCAL index -> m x S row-major (A[:, f] at giga.py:45, frankwolfe.py:27) */
+int bc_phi_gather_rows(bc_phi* phi, const int64_t* local_idx, int64_t m, double* out);
+/* out[j] = sum_i weights[i] * Phi[i, :]  is not needed by the reference; what it
+ * needs is Phi . v for ONE S-vector: scores[i] = Phi[i,:].v  (bcores.py:78 before
+ * the row-norm division).  Mostly a debugging / test aid. */
+int bc_phi_matvec(bc_phi* phi, const double* v_s, double* out_n);
+int bc_phi_destroy(bc_phi* phi);
+
+/* ---- K3-only entry: one fused score + argmax sweep --------------------- */
+/* mode 0 (GIGA, giga.py:31-38): v = [cdir, xw] interleaved (2*S doubles).
+ * mode 1 (dot, frankwolfe.py:16-17, orthopursuit.py:18-19, bcores.py:78-81):
+ *        v = residual (S doubles); score = Phi[i,:].v / norm[i] / post_div.
+ * Zero-norm rows are skipped.  Returns the best local row as a GLOBAL index
+ * (-1 if there is no valid row) and its score. */
+int bc_phi_argmax(bc_phi* phi, int mode, const double* v, double post_div, int64_t* best, double* score);
+
+/* ---- sparse-NNLS solver state (bayesiancoresets/snnls/snnls.py:8-106) -- */
+/* b: host, S doubles, the GLOBAL right-hand side (replicated on every rank).
+ * norm_sum: GLOBAL sum of row norms (FrankWolfe, frankwolfe.py:21,24); pass the
+ * value from bc_phi_norm_stats when there is one rank.
+ * Raises BC_INVALID_ARGUMENT if a local row has zero norm (giga.py:11-12) unless
+ * allow_zero_rows != 0 (HilbertCoreset keeps dropped rows in place, masked). */
+int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int alg, double norm_sum,
+                    int allow_zero_rows, bc_snnls** out);
+int bc_snnls_destroy(bc_snnls* h);
+/* bayesiancoresets/util/__init__.py:4-7 (TOL, set_tolerance); default 1e-12 */
+int bc_snnls_set_tolerance(bc_snnls* h, double tol);
+/* multi-rank: device buffers (world*(S+4) and (S+4) doubles) through which the
+ * host all-gathers the per-rank candidate records between step_local and
+ * step_finish.  With world == 1 nothing needs binding. */
+int bc_snnls_bind_exchange(bc_snnls* h, int world, void* cand_send_dev, void* cand_all_dev);
+int bc_snnls_record_doubles(const bc_snnls* h, int32_t* n);
+
+/* fused greedy loop, all on device, no host round trip per iteration
+ * (snnls.py:31-79 incl. the monotone guard, revert, retry-once-then-stop).   */
+int bc_snnls_build_begin(bc_snnls* h, int itrs);      /* resets the per-call retry flag (snnls.py:40) */
+int bc_snnls_step_local(bc_snnls* h);                 /* K3 sweep + local winner -> cand_send */
+int bc_snnls_step_finish(bc_snnls* h);                /* winner over cand_all, reweight, guard, prep next */
+int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* iterations_consumed);
+/* = begin; itrs x (step_local; step_finish); end   -- single-rank convenience */
+int bc_snnls_build(bc_snnls* h, int itrs, int* reached_numeric_limit);
+
+/* step-wise protocol for SparseNNLS subclasses (snnls.py:102-106).
+ * select: BC_NUMERICAL_PRECISION when the reference's _select would raise
+ * (giga.py:28-29).  For world > 1 call select_local, all-gather, select_pick. */
+int bc_snnls_select(bc_snnls* h, int64_t* f);
+int bc_snnls_select_local(bc_snnls* h);
+int bc_snnls_select_pick(bc_snnls* h, int64_t* f);
+/* reweight with column f.  The column is taken from the last select's candidate
+ * records when f is among them, else gathered from the local shard
+ * (BC_INVALID_ARGUMENT if f is not local and world > 1). */
+int bc_snnls_reweight(bc_snnls* h, int64_t f);
+int bc_snnls_error(bc_snnls* h, double* err);                       /* snnls.py:28-29 */
+int bc_snnls_size(bc_snnls* h, int64_t* nnz_positive);              /* snnls.py:21-22 */
+/* sparse view of w: entries in selection order (values may be 0). cap = capacity of the arrays. */
+int bc_snnls_weights(bc_snnls* h, int64_t cap, int64_t* idx, double* val, int64_t* n);
+/* replace w (snnls.py:59 revert, :88 optimize, orthopursuit.py:41).  cols: n x S
+ * row-major columns A[:, idx[j]] or NULL to gather them from the local shard. */
+int bc_snnls_set_weights(bc_snnls* h, int64_t n, const int64_t* idx, const double* val, const double* cols);
+/* columns of the current active list, n x S (for the host NNLS refit, snnls.py:87) */
+int bc_snnls_columns(bc_snnls* h, int64_t cap, double* cols, int64_t* n);
+int bc_snnls_reset(bc_snnls* h);                                    /* snnls.py:18-20 */
+int bc_snnls_get_flags(bc_snnls* h, int* reached_numeric_limit);
+int bc_snnls_set_flags(bc_snnls* h, int reached_numeric_limit);
+/* per-iteration trace of the fused loop since the last reset: f (or -1), status, error */
+int bc_snnls_trace(bc_snnls* h, int64_t cap, int64_t* f, int32_t* status, double* err, int64_t* n);
+
+/* ---- K4: X^T diag(w) X and X^T (w*y) (model_linreg.py:29,31) ----------- */
+/* data rows are [x(D), y]; w: host, n_rows doubles (NULL = all ones).
+ * out_xtwx: D x D row-major, out_xtwy: D.  Local rows only; the host sums over ranks. */
+int bc_weighted_gram(bc_ctx* ctx, const bc_data* data, const double* w, double* out_xtwx, double* out_xtwy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BETA_CORES_H */
