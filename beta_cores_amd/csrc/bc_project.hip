@@ -24,18 +24,19 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 struct ProjArgs {
   const double* z;        // [n_rows][dz]
   const double* theta;    // [nt*16][dk]  zero padded
-  const double* saux;     // [nt*16] per-sample extra (gauss: theta^T Siginv theta) or null
+  const double* saux;     // [nt*16] per-sample extra (gauss: theta^T Siginv theta)
   const double* rowaux;   // [n_rows] per-row extra (gauss: x^T Siginv x) or null
   double* tiles;
   double* norms;
   double* tile_part;
   long long n_rows;
   int dz, d, dk, s, model;
-  double p[6];            // model constants, see bc_project()
+  double c[8];            // model constants, see model_constants()
 };
 
-__device__ __forceinline__ double bc_model_value(int model, double p, double ra, double sa, const double* c) {
-  switch (model) {
+template <int MODEL>
+__device__ __forceinline__ double bc_model_value(double p, double ra, double sa, const double* c) {
+  switch (MODEL) {
     case BC_MODEL_LINREG_LL: {            // c0 - c1*(y^2 - 2*p*y + p^2)
       const double q = (ra * ra - (2. * p) * ra) + p * p;
       return c[0] - c[1] * q;
@@ -67,7 +68,444 @@ __device__ __forceinline__ double bc_model_value(int model, double p, double ra,
       const double t1 = c[3] * (c[0] * gq - c[2]);
       const double t2 = c[4] * gq;
       const double t3 = c[5] * q * gq;
-      return ((t1 - t2) - t3) - p_dummy_never_used(c);
+      return ((t1 - t2) - t3) - c[6];
     }
   }
+}
+
+// NT = number of 16-sample accumulator tiles (S <= 16*NT), KC = D-chunk staged per LDS pass,
+// JT = 16-row sub-tiles per wave (2 -> 4 waves per 128-row tile, 1 -> 8 waves; the latter keeps
+// the accumulators of a 200+-sample projection within the register file).
+template <int MODEL, int NT, int KC, int JT>
+__global__ __launch_bounds__(128 / (16 * JT) * 64, 2) void k_project(ProjArgs a) {
+  constexpr int NTHR = 128 / (16 * JT) * 64;
+  constexpr int LDZ = KC + 1;    // odd stride: rows (2j, 2j+1) of a lane pair hit distinct banks
+  constexpr int LDT = KC + 2;
+  constexpr int ZP = (128 * KC) / NTHR;           // 8-byte loads of Z per thread per chunk
+  constexpr int TN = NT * 16 * KC / 2;            // 16-byte loads of Theta per chunk (whole block)
+  constexpr int TP = (TN + NTHR - 1) / NTHR;
+  extern __shared__ double lds[];
+  double* Zl = lds;                    // [128][LDZ]
+  double* Tl = lds + 128 * LDZ;        // [NT*16][LDT]   (reused for the column partials after the loop)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const long long tile = blockIdx.x;
+  const long long r0 = tile * BC_TILE;
+  const int S = a.s;
+  const int row_base = (JT == 2) ? 32 * w + 2 * j : 16 * w + j;   // this lane's first data row in the tile
+
+  double4_t acc[JT][NT];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
+
+  double zr[ZP];
+  double2 tr[TP];
+  auto load_chunk = [&](int d0) {
+#pragma unroll
+    for (int q = 0; q < ZP; ++q) {
+      const int idx = tid + q * NTHR;
+      const int r = idx / KC, cc = idx % KC;
+      const long long gr = r0 + r;
+      zr[q] = (gr < a.n_rows && d0 + cc < a.d) ? a.z[(size_t)gr * a.dz + d0 + cc] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < TP; ++q) {
+      const int idx = tid + q * NTHR;
+      const int r = idx / (KC / 2), cc = (idx % (KC / 2)) * 2;
+      tr[q] = (idx < TN) ? *reinterpret_cast<const double2*>(a.theta + (size_t)r * a.dk + d0 + cc) : make_double2(0., 0.);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int q = 0; q < ZP; ++q) {
+      const int idx = tid + q * NTHR;
+      const int r = idx / KC, cc = idx % KC;
+      Zl[r * LDZ + cc] = zr[q];
+    }
+#pragma unroll
+    for (int q = 0; q < TP; ++q) {
+      const int idx = tid + q * NTHR;
+      const int r = idx / (KC / 2), cc = (idx % (KC / 2)) * 2;
+      if (idx < TN) *reinterpret_cast<double2*>(Tl + r * LDT + cc) = tr[q];
+    }
+  };
+
+  const int nchunks = a.dk / KC;
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    store_chunk();
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk((c + 1) * KC);
+    const double* zrow0 = Zl + row_base * LDZ + g;
+    const double* trow = Tl + j * LDT + g;
+#pragma unroll 2
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      double bz[JT];
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) bz[jt] = zrow0[jt * LDZ + kk * 4];
+#pragma unroll
+      for (int st = 0; st < NT; ++st) {
+        const double at = trow[st * 16 * LDT + kk * 4];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bz[jt], acc[jt][st], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, for data rows (row_base + jt), samples s = 16*st + g + 4*reg
+  double* colpart = Tl;   // [waves][NT*16]
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+    const long long gr = r0 + row_base + jt;
+    const bool live = gr < a.n_rows;
+    double ra = 0.;
+    if (live) {
+      if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra = a.z[(size_t)gr * a.dz + a.d];
+      else if (MODEL >= BC_MODEL_GAUSS_LL) ra = a.rowaux[gr];
+    }
+    double sum = 0., vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < NT; ++st) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int s = 16 * st + g + 4 * reg;
+        double v = 0.;
+        if (s < S && live) {
+          v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c);
+          vmin = fmin(vmin, v);
+          vmax = fmax(vmax, v);
+        }
+        acc[jt][st][reg] = v;
+        sum += v;
+      }
+    }
+    sum += __shfl_xor(sum, 16, BC_WAVE);
+    sum += __shfl_xor(sum, 32, BC_WAVE);
+    vmin = fmin(vmin, __shfl_xor(vmin, 16, BC_WAVE));
+    vmin = fmin(vmin, __shfl_xor(vmin, 32, BC_WAVE));
+    vmax = fmax(vmax, __shfl_xor(vmax, 16, BC_WAVE));
+    vmax = fmax(vmax, __shfl_xor(vmax, 32, BC_WAVE));
+    // a row whose S values are all the same number centres to exactly 0 (the rounded mean of S equal
+    // numbers need not equal them); such rows are the "all-zero rows" dropped at hilbert.py:16
+    const bool constant_row = vmin == vmax;
+    const double mean = constant_row ? vmax : sum / (double)S;           // lls.mean(axis=1)
+    double sq = 0.;
+#pragma unroll
+    for (int st = 0; st < NT; ++st) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int s = 16 * st + g + 4 * reg;
+        double v = acc[jt][st][reg];
+        v = (s < S && live) ? v - mean : 0.;
+        acc[jt][st][reg] = v;
+        sq = fma(v, v, sq);
+      }
+    }
+    sq += __shfl_xor(sq, 16, BC_WAVE);
+    sq += __shfl_xor(sq, 32, BC_WAVE);
+    if (g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
+  }
+  // store the tile (JT == 2: two adjacent rows per lane -> 16-byte stores, 256 B contiguous per 16 lanes)
+  double* tbase = a.tiles + (size_t)tile * S * BC_TILE + row_base;
+#pragma unroll
+  for (int st = 0; st < NT; ++st) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int s = 16 * st + g + 4 * reg;
+      double cp;
+      if (JT == 2) {
+        if (s < S) *reinterpret_cast<double2*>(tbase + (size_t)s * BC_TILE) = make_double2(acc[0][st][reg], acc[JT - 1][st][reg]);
+        cp = acc[0][st][reg] + acc[JT - 1][st][reg];
+      } else {
+        if (s < S) tbase[(size_t)s * BC_TILE] = acc[0][st][reg];
+        cp = acc[0][st][reg];
+      }
+      // per-tile column partial (K2): sum over this wave's rows
+      cp += __shfl_xor(cp, 1, BC_WAVE);
+      cp += __shfl_xor(cp, 2, BC_WAVE);
+      cp += __shfl_xor(cp, 4, BC_WAVE);
+      cp += __shfl_xor(cp, 8, BC_WAVE);
+      if (j == 0) colpart[w * (NT * 16) + s] = cp;
+    }
+  }
+  __syncthreads();
+  constexpr int NW = NTHR / 64;
+  for (int s = tid; s < S; s += NTHR) {
+    double t = colpart[s];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) t += colpart[ww * NT * 16 + s];
+    a.tile_part[(size_t)tile * S + s] = t;
+  }
+}
+
+// x^T Siginv x per row, in the reference's order: (x * (x.dot(Siginv))).sum(axis=1)   (gaussian.py:10)
+__global__ __launch_bounds__(256) void k_row_quadform(const double* __restrict__ z, long long n_rows, int d,
+                                                     const double* __restrict__ siginv, double* __restrict__ out) {
+  extern __shared__ double sl[];   // Siginv [d][d]
+  for (int i = threadIdx.x; i < d * d; i += blockDim.x) sl[i] = siginv[i];
+  __syncthreads();
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (long long)gridDim.x * blockDim.x) {
+    const double* x = z + (size_t)r * d;
+    double tot = 0.;
+    for (int aa = 0; aa < d; ++aa) {
+      double t = 0.;
+      for (int bb = 0; bb < d; ++bb) t = fma(x[bb], sl[bb * d + aa], t);
+      tot += x[aa] * t;
+    }
+    out[r] = tot;
+  }
+}
+
+// ------------------------------------------------------------------ host side
+struct ProjScratch {
+  double* theta = nullptr;
+  size_t theta_cap = 0;
+  double* saux = nullptr;
+  size_t saux_cap = 0;
+  double* rowaux = nullptr;
+  size_t rowaux_cap = 0;
+  double* siginv = nullptr;
+  size_t siginv_cap = 0;
+  double* pinned = nullptr;
+  size_t pinned_cap = 0;
+};
+
+static ProjScratch g_scr[16];   // per device
+
+static int grow_dev(double** p, size_t* cap, size_t need) {
+  if (need <= *cap) return BC_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  BC_HIP(hipMalloc((void**)p, need * sizeof(double)));
+  *cap = need;
+  return BC_OK;
+}
+
+static int grow_pinned(ProjScratch& sc, size_t need) {
+  if (need <= sc.pinned_cap) return BC_OK;
+  if (sc.pinned) (void)hipHostFree(sc.pinned);
+  sc.pinned = nullptr;
+  sc.pinned_cap = 0;
+  BC_HIP(hipHostMalloc((void**)&sc.pinned, need * sizeof(double), hipHostMallocDefault));
+  sc.pinned_cap = need;
+  return BC_OK;
+}
+
+// model constants, evaluated in the same expression order as the Python sources
+static int model_constants(int model, const double* p, int np, int d, double* c, const double** siginv) {
+  const double pi = 3.141592653589793;
+  *siginv = nullptr;
+  memset(c, 0, 8 * sizeof(double));
+  switch (model) {
+    case BC_MODEL_LINREG_LL: {
+      if (np != 1) return BC_INVALID_ARGUMENT;
+      const double sigsq = p[0];
+      c[0] = -1. / 2. * log(2. * pi * sigsq);
+      c[1] = 1. / (2. * sigsq);
+      return BC_OK;
+    }
+    case BC_MODEL_LINREG_BETA: {
+      if (np != 2) return BC_INVALID_ARGUMENT;
+      const double sigsq = p[0], beta = p[1];
+      c[0] = 1. / pow(2 * pi * sigsq, beta / 2.);
+      c[1] = -(beta + 1.) / beta;
+      c[2] = -beta / (2. * sigsq);
+      c[3] = 1. / sqrt(1. + beta);
+      return BC_OK;
+    }
+    case BC_MODEL_LOGISTIC_LL:
+      return np == 0 ? BC_OK : BC_INVALID_ARGUMENT;
+    case BC_MODEL_LOGISTIC_BETA: {
+      if (np != 1) return BC_INVALID_ARGUMENT;
+      const double beta = p[0];
+      c[0] = (beta + 1.) / beta;
+      c[1] = -beta;
+      c[2] = -beta - 1.;
+      return BC_OK;
+    }
+    case BC_MODEL_GAUSS_LL: {
+      if (np != 1 + d * d) return BC_INVALID_ARGUMENT;
+      const double logdet = p[0];
+      c[0] = -(double)d / 2 * log(2 * pi) - 1. / 2. * logdet;
+      *siginv = p + 1;
+      return BC_OK;
+    }
+    case BC_MODEL_GAUSS_BETA:
+    case BC_MODEL_GAUSS_BETA_GRAD: {
+      if (np != 2 + d * d) return BC_INVALID_ARGUMENT;
+      const double beta = p[0], logdet = p[1], dd = (double)d;
+      c[0] = 1. / beta;
+      c[1] = -.5 * beta;
+      c[2] = pow(1 + beta, -.5 * dd - 1);
+      c[3] = log(pow(2 * pi, -.5 * dd) * pow(exp(logdet), -.5));
+      c[4] = 1. / pow(beta, 2);
+      c[5] = 1. / (2. * beta);
+      c[6] = pow(1 + beta, -.5 * dd - 1.) * log(1. + beta);
+      *siginv = p + 2;
+      return BC_OK;
+    }
+  }
+  return BC_INVALID_ARGUMENT;
+}
+
+template <int MODEL, int NT, int KC, int JT>
+static int launch_project(bc_ctx* ctx, const ProjArgs& a, long long ntiles) {
+  const size_t lds = (size_t)(128 * (KC + 1) + NT * 16 * (KC + 2)) * sizeof(double);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_project<MODEL, NT, KC, JT>), dim3((unsigned)ntiles), dim3(128 / (16 * JT) * 64), lds, ctx->stream, a);
+  BC_HIP(hipGetLastError());
+  return BC_OK;
+}
+
+template <int MODEL>
+static int launch_project_nt(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int ntsel) {
+  switch (ntsel) {
+    case 4: return launch_project<MODEL, 4, 32, 2>(ctx, a, ntiles);
+    case 7: return launch_project<MODEL, 7, 32, 2>(ctx, a, ntiles);
+    case 13: return launch_project<MODEL, 13, 16, 1>(ctx, a, ntiles);
+    default: return launch_project<MODEL, 16, 16, 1>(ctx, a, ntiles);
+  }
+}
+
+extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                          const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout) {
+  if (!ctx || !data || !theta || !inout || s <= 0 || (n_params > 0 && !params)) {
+    bc_set_error("bc_project: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  if (data->ctx != ctx) { bc_set_error("bc_project: data belongs to another context"); return BC_INVALID_ARGUMENT; }
+  if (model < 0 || model > BC_MODEL_GAUSS_BETA_GRAD) { bc_set_error("bc_project: unknown model %d", model); return BC_INVALID_ARGUMENT; }
+  if (s > 256) { bc_set_error("bc_project: projection dimension S=%d > 256 is not supported by this build", s); return BC_INVALID_ARGUMENT; }
+  const bool has_y = (model == BC_MODEL_LINREG_LL || model == BC_MODEL_LINREG_BETA);
+  const int d = data->dz - (has_y ? 1 : 0);
+  if (d <= 0) { bc_set_error("bc_project: data rows too short for this model"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  ProjArgs a;
+  memset(&a, 0, sizeof(a));
+  const double* siginv = nullptr;
+  if (model_constants(model, params, n_params, d, a.c, &siginv) != BC_OK) {
+    bc_set_error("bc_project: model %d expects a different number of parameters than %d (d = %d)", model, n_params, d);
+    return BC_INVALID_ARGUMENT;
+  }
+  // output handle: reuse buffers when the shape matches
+  bc_phi* phi = *inout;
+  if (phi && (phi->ctx != ctx || phi->n_rows != data->n_rows || phi->s != s)) {
+    bc_set_error("bc_project: *inout has a different shape; pass NULL to allocate");
+    return BC_INVALID_ARGUMENT;
+  }
+  bool fresh = false;
+  if (!phi) {
+    int rc = bc_phi_alloc(ctx, data->n_rows, s, row_offset, &phi);
+    if (rc) return rc;
+    fresh = true;
+  }
+  phi->row_offset = row_offset;
+  phi->stats_valid = false;
+
+  const int nt = (s + 15) / 16;
+  const int NTsel = nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 16;
+  const int KC = NTsel <= 7 ? 32 : 16;
+  const int dk = ((d + KC - 1) / KC) * KC;
+  ProjScratch& sc = g_scr[ctx->device & 15];
+  const size_t th_n = (size_t)NTsel * 16 * dk, sa_n = (size_t)NTsel * 16;
+  int rc = grow_dev(&sc.theta, &sc.theta_cap, th_n);
+  if (!rc) rc = grow_dev(&sc.saux, &sc.saux_cap, sa_n);
+  if (!rc) rc = grow_pinned(sc, th_n + sa_n + (siginv ? (size_t)d * d : 0));
+  if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
+  // make sure an earlier launch is no longer reading the pinned staging area
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  double* hth = sc.pinned;
+  double* hsa = sc.pinned + th_n;
+  memset(hth, 0, (th_n + sa_n) * sizeof(double));
+  if (siginv) {
+    // Theta' = (Siginv . Theta^T)^T  so that the contraction yields x^T Siginv theta (gaussian.py:12),
+    // tSt = (th * (th.dot(Siginv))).sum(axis=1)                                       (gaussian.py:11)
+    for (int q = 0; q < s; ++q) {
+      const double* th = theta + (size_t)q * d;
+      double tst = 0.;
+      for (int aa = 0; aa < d; ++aa) {
+        double m1 = 0., m2 = 0.;
+        for (int bb = 0; bb < d; ++bb) {
+          m1 += siginv[(size_t)aa * d + bb] * th[bb];   // (Siginv . th^T)[aa]
+          m2 += th[bb] * siginv[(size_t)bb * d + aa];   // (th . Siginv)[aa]
+        }
+        hth[(size_t)q * dk + aa] = m1;
+        tst += th[aa] * m2;
+      }
+      hsa[q] = tst;
+    }
+  } else {
+    for (int q = 0; q < s; ++q) memcpy(hth + (size_t)q * dk, theta + (size_t)q * d, (size_t)d * sizeof(double));
+  }
+  hipError_t e = hipMemcpyAsync(sc.theta, hth, th_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(sc.saux, hsa, sa_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  a.rowaux = nullptr;
+  if (e == hipSuccess && siginv && data->n_rows > 0) {
+    rc = grow_dev(&sc.rowaux, &sc.rowaux_cap, (size_t)data->n_rows);
+    if (!rc) rc = grow_dev(&sc.siginv, &sc.siginv_cap, (size_t)d * d);
+    if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
+    double* hsi = sc.pinned + th_n + sa_n;
+    memcpy(hsi, siginv, (size_t)d * d * sizeof(double));
+    e = hipMemcpyAsync(sc.siginv, hsi, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      if ((size_t)d * d * sizeof(double) > 60 * 1024) {
+        if (fresh) bc_phi_destroy(phi);
+        bc_set_error("bc_project: Gaussian-location model supports d <= 87 in this build (Siginv staged in LDS)");
+        return BC_INVALID_ARGUMENT;
+      }
+      long long blocks = (data->n_rows + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(k_row_quadform, dim3((unsigned)blocks), dim3(256), (size_t)d * d * sizeof(double), ctx->stream,
+                         data->z, (long long)data->n_rows, d, sc.siginv, sc.rowaux);
+      e = hipGetLastError();
+      a.rowaux = sc.rowaux;
+    }
+  }
+  if (e != hipSuccess) { if (fresh) bc_phi_destroy(phi); return bc_hip_fail(e, "bc_project staging", __FILE__, __LINE__); }
+
+  a.z = data->z;
+  a.theta = sc.theta;
+  a.saux = sc.saux;
+  a.tiles = phi->tiles;
+  a.norms = phi->norms;
+  a.tile_part = phi->tile_part;
+  a.n_rows = data->n_rows;
+  a.dz = data->dz;
+  a.d = d;
+  a.dk = dk;
+  a.s = s;
+  a.model = model;
+  rc = BC_OK;
+  if (phi->ntiles > 0) {
+    rc = bc_timer_begin(ctx, 1);
+    if (!rc) {
+      switch (model) {
+        case BC_MODEL_LINREG_LL: rc = launch_project_nt<BC_MODEL_LINREG_LL>(ctx, a, phi->ntiles, NTsel); break;
+        case BC_MODEL_LINREG_BETA: rc = launch_project_nt<BC_MODEL_LINREG_BETA>(ctx, a, phi->ntiles, NTsel); break;
+        case BC_MODEL_LOGISTIC_LL: rc = launch_project_nt<BC_MODEL_LOGISTIC_LL>(ctx, a, phi->ntiles, NTsel); break;
+        case BC_MODEL_LOGISTIC_BETA: rc = launch_project_nt<BC_MODEL_LOGISTIC_BETA>(ctx, a, phi->ntiles, NTsel); break;
+        case BC_MODEL_GAUSS_LL: rc = launch_project_nt<BC_MODEL_GAUSS_LL>(ctx, a, phi->ntiles, NTsel); break;
+        case BC_MODEL_GAUSS_BETA: rc = launch_project_nt<BC_MODEL_GAUSS_BETA>(ctx, a, phi->ntiles, NTsel); break;
+        default: rc = launch_project_nt<BC_MODEL_GAUSS_BETA_GRAD>(ctx, a, phi->ntiles, NTsel); break;
+      }
+    }
+    if (!rc) rc = bc_timer_end(ctx, 1);
+  } else {
+    e = hipMemsetAsync(phi->norms, 0, BC_TILE * sizeof(double), ctx->stream);
+    if (e != hipSuccess) rc = bc_hip_fail(e, "memset", __FILE__, __LINE__);
+  }
+  if (!rc) rc = bc_phi_finish_stats(phi);
+  if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
+  *inout = phi;
+  return BC_OK;
 }

@@ -1,0 +1,214 @@
+"""GPU parity of K1 (projection kernel, through bc_project) against the oracle's
+formulas and the golden fixtures generated from the reference.
+
+Tolerance (written here as the north_star asks): Phi is a row-centred difference of
+values of magnitude max|f|; the device contraction sums D products in a different order
+and uses the ROCm libm (exp/log1p/pow <= 2 ulp), so |Phi_dev - Phi_ref| <= 1e-11 * (1 + max|f|)
+element-wise.  Downstream selections must still be bit-exact, weights within 1e-5."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import models_ref as M
+from oracle import coreset_ref as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def bc():
+    import beta_cores_amd as bc
+    bc.default_context()
+    return bc
+
+
+def centred(raw):
+    return raw - raw.mean(axis=1)[:, None]
+
+
+def check_phi(dev_phi, raw, tol=1e-11):
+    ref = centred(raw)
+    got = np.asarray(dev_phi)
+    scale = 1. + np.abs(raw).max()
+    assert got.shape == ref.shape
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - ref).max() <= tol * scale, np.abs(got - ref).max() / scale
+    np.testing.assert_allclose(dev_phi.colsum(), got.sum(axis=0), rtol=1e-10, atol=1e-9 * scale)
+    np.testing.assert_allclose(dev_phi.norms(), np.sqrt((got ** 2).sum(axis=1)), rtol=1e-12, atol=1e-300)
+
+
+def fixed(th):
+    return lambda n, w, p: th
+
+
+def test_f2_linreg(bc):
+    g = load_golden('f2_formulas')
+    Z, th = g['lin_Z'], g['lin_th']
+    for sig in (1.0, 2.5):
+        prj = bc.DeviceBetaProjector(fixed(th), th.shape[0], bc.likelihoods.LinearRegression(sig))
+        check_phi(prj.project(Z), g['lin_ll_sig%g' % sig])
+        for beta in (0.1, 0.2, 0.5):
+            check_phi(prj.project_f(Z, beta), g['lin_bl_sig%g_b%g' % (sig, beta)])
+
+
+def test_f2_logistic_incl_overflow_branches(bc):
+    g = load_golden('f2_formulas')
+    Z, th = g['log_Z'], g['log_th']
+    prj = bc.DeviceBetaProjector(fixed(th), th.shape[0], bc.likelihoods.LogisticRegression())
+    check_phi(prj.project(Z), g['log_ll'])                        # rows with |m| = 120, 800 exercise the m<100 branch
+    for beta in (0.1, 0.2, 0.5):
+        check_phi(prj.project_f(Z, beta), g['log_bl_b%g' % beta])   # exp overflow -> inf -> pow(inf, -b) = 0, no NaN
+
+
+def test_f2_gaussian_location(bc):
+    g = load_golden('f2_formulas')
+    X, th = g['gau_X'], g['gau_th']
+    for nm in ('iso', 'full'):
+        model = bc.likelihoods.GaussianLocation(g['gau_%s_Siginv' % nm], float(g['gau_%s_logdet' % nm]))
+        prj = bc.DeviceBetaProjector(fixed(th), th.shape[0], model)
+        check_phi(prj.project(X), g['gau_%s_ll' % nm], tol=1e-10)
+        for beta in (0.1, 0.5):
+            bl, bg = prj.project_f(X, beta, grad=True)
+            check_phi(bl, g['gau_%s_bl_b%g' % (nm, beta)], tol=1e-10)
+            check_phi(bg, g['gau_%s_bg_b%g' % (nm, beta)], tol=1e-10)
+
+
+# a spread of shapes that touches every NT template (S<=64, <=112, <=208, <=256), both JT
+# variants, partial D-chunks, partial tiles and single-row / single-sample inputs
+_RAGGED = [(1, 1, 1), (2, 3, 16), (127, 31, 50), (128, 32, 64), (129, 33, 100), (1000, 64, 100), (1000, 100, 112),
+           (129, 64, 113), (1000, 33, 200), (127, 100, 256), (1000, 1, 256), (128, 3, 113), (2, 100, 200),
+           (1, 64, 100), (1000, 32, 16), (129, 31, 1)]
+
+
+@pytest.mark.parametrize('n,d,s', _RAGGED)
+def test_ragged_shapes_linreg(bc, n, d, s):
+    rng = np.random.RandomState(n * 1000 + d * 10 + s)
+    Z = rng.randn(n, d + 1)
+    th = rng.randn(s, d) * 0.5
+    prj = bc.DeviceBetaProjector(fixed(th), s, bc.likelihoods.LinearRegression(1.3))
+    check_phi(prj.project(Z), M.linreg_loglik(Z, th, 1.3))
+    check_phi(prj.project_f(Z, 0.3), M.linreg_beta_lik(Z, th, 0.3, 1.3))
+
+
+@pytest.mark.parametrize('d,s', [(16, 100), (128, 100), (40, 200)])
+def test_logistic_random(bc, d, s):
+    rng = np.random.RandomState(d + s)
+    n = 3000
+    X = rng.randn(n, d)
+    y = np.where(rng.rand(n) < 0.5, 1., -1.)
+    Z = y[:, None] * X
+    th = rng.randn(s, d) / np.sqrt(d) * 3
+    prj = bc.DeviceBetaProjector(fixed(th), s, bc.likelihoods.LogisticRegression())
+    check_phi(prj.project(Z), M.logistic_loglik(Z, th))
+    check_phi(prj.project_f(Z, 0.1), M.logistic_beta_lik(Z, th, 0.1))
+
+
+def test_projection_dimension_limit(bc):
+    th = np.zeros((257, 4))
+    prj_err = None
+    try:
+        prj = bc.DeviceProjector(fixed(th), 257, bc.likelihoods.LinearRegression(1.0))
+        prj.project(np.zeros((10, 5)))
+    except ValueError as e:
+        prj_err = e
+    assert prj_err is not None and '256' in str(prj_err)
+    with pytest.raises(ValueError):
+        bc.DeviceProjector(fixed(np.zeros((8, 4))), 8, bc.likelihoods.LinearRegression(1.0)).project(np.zeros((10, 7)))
+
+
+# ------------------------------------------------------------------ pipelines: K1 -> K2 -> fused greedy loop
+@pytest.mark.parametrize('nm', ['ll', 'bl'])
+@pytest.mark.parametrize('alg', ['giga', 'fw', 'omp'])
+def test_f3_hilbert_pipeline(bc, nm, alg):
+    g = load_golden('f3_hilbert_linreg')
+    Z, th = g['Z'], g['th']
+    model = bc.likelihoods.LinearRegression(1.0)
+    if nm == 'll':
+        prj = bc.DeviceProjector(fixed(th), th.shape[0], model)
+    else:
+        class BetaAsPlain(bc.DeviceBetaProjector):          # HilbertCoreset calls .project(); bind beta = 0.1
+            def project(self, pts, grad=False):
+                return self.project_f(pts, 0.1)
+        prj = BetaAsPlain(fixed(th), th.shape[0], model)
+    cls = dict(giga=bc.snnls.GIGA, fw=bc.snnls.FrankWolfe, omp=bc.snnls.OrthoPursuit)[alg]
+    key = '%s_%s_' % (nm, alg)
+    steps = g[key + 'sel'].shape[0]
+    h = bc.HilbertCoreset(Z, prj, snnls=cls)
+    np.testing.assert_allclose(h.snnls.b, g[key + 'b'], rtol=1e-9, atol=1e-9)
+    for m in range(steps):
+        h.build(1, m + 1)
+        np.testing.assert_allclose(h.error(), g[key + 'err'][m], rtol=1e-6)
+    wts, pts, idcs = h.get()
+    np.testing.assert_array_equal(idcs, g[key + 'idcs'])
+    np.testing.assert_allclose(wts, g[key + 'wts'], rtol=1e-5)
+    assert np.array_equal(pts, Z[idcs])
+    if alg != 'omp':
+        f, st, er = h.snnls._eng.trace()
+        np.testing.assert_array_equal(f, g[key + 'sel'])
+    h.optimize()
+    wts, pts, idcs = h.get()
+    np.testing.assert_array_equal(idcs, g[key + 'opt_idcs'])
+    np.testing.assert_allclose(wts, g[key + 'opt_wts'], rtol=1e-5)
+    with pytest.raises(ValueError):
+        h.build(1, h.size() - 1 if h.size() > 0 else -1)          # coreset.py:38-39 cannot shrink
+
+
+def test_f4_logistic_and_gauss_pipelines(bc):
+    g = load_golden('f4_hilbert_logistic_gauss')
+    Z, th = g['log_Z'], g['log_th']
+
+    class BetaAsPlain(bc.DeviceBetaProjector):
+        def project(self, pts, grad=False):
+            return self.project_f(pts, 0.1)
+    for nm, prj in (('ll', bc.DeviceProjector(fixed(th), th.shape[0], bc.likelihoods.LogisticRegression())),
+                    ('bl', BetaAsPlain(fixed(th), th.shape[0], bc.likelihoods.LogisticRegression()))):
+        key = 'log_%s_' % nm
+        steps = g[key + 'sel'].shape[0]
+        h = bc.HilbertCoreset(Z, prj)
+        h.build(steps, steps)
+        wts, pts, idcs = h.get()
+        np.testing.assert_array_equal(idcs, g[key + 'idcs'])
+        np.testing.assert_allclose(wts, g[key + 'wts'], rtol=1e-5)
+        np.testing.assert_array_equal(h.snnls._eng.trace()[0], g[key + 'sel'])
+    # config-1 plumbing shape, shrunk: Gaussian location, d=8, S=200, outlier clusters
+    X, thg = g['gau_X'], g['gau_th']
+    model = bc.likelihoods.GaussianLocation(g['gau_Siginv'], float(g['gau_logdet']))
+    h = bc.HilbertCoreset(X, bc.DeviceProjector(fixed(thg), thg.shape[0], model))
+    steps = g['gau_ll_sel'].shape[0]
+    h.build(steps, steps)
+    wts, pts, idcs = h.get()
+    np.testing.assert_array_equal(idcs, g['gau_ll_idcs'])
+    np.testing.assert_allclose(wts, g['gau_ll_wts'], rtol=1e-5)
+    np.testing.assert_array_equal(h.snnls._eng.trace()[0], g['gau_ll_sel'])
+
+
+def test_blackbox_projector_still_works(bc):
+    """The reference's own projector class (host callable) feeding the device solver."""
+    g = load_golden('f3_hilbert_linreg')
+    Z, th = g['Z'], g['th']
+    prj = bc.BlackBoxProjector(fixed(th), th.shape[0], lambda z, t: M.linreg_loglik(z, t, 1.0))
+    h = bc.HilbertCoreset(Z, prj)
+    h.build(50, 50)
+    wts, pts, idcs = h.get()
+    np.testing.assert_array_equal(idcs, g['ll_giga_idcs'])
+    np.testing.assert_allclose(wts, g['ll_giga_wts'], rtol=1e-5)
+
+
+def test_zero_rows_follow_reference_index_quirk(bc):
+    """hilbert.py:16 drops all-zero rows and then indexes the filtered matrix (hilbert.py:32)."""
+    rng = np.random.RandomState(9)
+    n, d, s = 600, 5, 16                                           # S = 16: the mean of 16 equal doubles is exact
+    Z = rng.randn(n, d + 1)
+    th = np.tile(rng.randn(1, d), (s, 1))
+    th[:, 0] += rng.randn(s) * 0.3                                 # only x_0 distinguishes the samples
+    Z[[3, 100, 101, 400], 0] = 0.                                  # -> f(z, th_s) constant in s -> centred row == 0
+    ll = lambda z, t: M.linreg_loglik(z, t, 1.0)
+    ref = C.RefHilbert(Z, ll, th)
+    assert ref.vecs.shape[0] == n - 4
+    ref.build(15, 15)
+    h = bc.HilbertCoreset(Z, bc.DeviceProjector(fixed(th), s, bc.likelihoods.LinearRegression(1.0)))
+    h.build(15, 15)
+    wts, pts, idcs = h.get()
+    np.testing.assert_array_equal(idcs, ref.idcs)
+    np.testing.assert_allclose(wts, ref.wts, rtol=1e-5)
+    assert np.array_equal(pts, Z[idcs])
