@@ -33,6 +33,7 @@ _SIGNATURES = {
     'bc_ctx_enable_timing': [vp, C.c_int],
     'bc_data_from_host': [vp, vp, C.c_int64, C.c_int32, vpp],
     'bc_data_from_device': [vp, vp, C.c_int64, C.c_int32, vpp],
+    'bc_data_gather_rows': [vp, vp, C.c_int64, vp],
     'bc_data_destroy': [vp],
     'bc_phi_from_host': [vp, vp, C.c_int64, C.c_int32, C.c_int64, vpp],
     'bc_project': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, C.c_int64, vpp],

@@ -94,7 +94,7 @@ class HilbertCoreset(Coreset):
             n_loc = self.snnls.n_local
             local = (self.idcs >= off) & (self.idcs < off + n_loc)
             pts = np.full((self.idcs.shape[0], self.data.shape[1]), np.nan)
-            pts[local] = np.asarray(self.data)[self.idcs[local] - off]
+            pts[local] = self.data[self.idcs[local] - off]
             self.pts = pts
         else:
             self.pts = self.data[self.idcs]

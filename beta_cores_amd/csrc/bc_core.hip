@@ -182,6 +182,40 @@ extern "C" int bc_data_from_device(bc_ctx* ctx, const void* z_dev, int64_t n_row
   return BC_OK;
 }
 
+__global__ void k_gather_data_rows(const double* __restrict__ z, int dz, const long long* __restrict__ idx, long long m,
+                                   double* __restrict__ out) {
+  const long long j = blockIdx.x;
+  if (j >= m) return;
+  const long long r = idx[j];
+  for (int k = threadIdx.x; k < dz; k += blockDim.x) out[(size_t)j * dz + k] = z[(size_t)r * dz + k];
+}
+
+extern "C" int bc_data_gather_rows(bc_data* d, const int64_t* local_idx, int64_t m, double* out) {
+  if (!d || m < 0 || (m > 0 && (!local_idx || !out))) { bc_set_error("bc_data_gather_rows: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (m == 0) return BC_OK;
+  for (int64_t j = 0; j < m; ++j)
+    if (local_idx[j] < 0 || local_idx[j] >= d->n_rows) {
+      bc_set_error("bc_data_gather_rows: index %lld out of range [0,%lld)", (long long)local_idx[j], (long long)d->n_rows);
+      return BC_INVALID_ARGUMENT;
+    }
+  bc_ctx* ctx = d->ctx;
+  long long* didx = nullptr;
+  double* dout = nullptr;
+  BC_HIP(hipMalloc((void**)&didx, (size_t)m * sizeof(long long)));
+  hipError_t e = hipMalloc((void**)&dout, (size_t)m * d->dz * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(didx, local_idx, (size_t)m * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_gather_data_rows, dim3((unsigned)m), dim3(128), 0, ctx->stream, d->z, d->dz, didx, (long long)m, dout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)m * d->dz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(didx);
+  if (dout) (void)hipFree(dout);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_data_gather_rows", __FILE__, __LINE__);
+  return BC_OK;
+}
+
 extern "C" int bc_data_destroy(bc_data* d) {
   if (!d) return BC_OK;
   if (d->owned && d->z) (void)hipFree(d->z);

@@ -90,6 +90,21 @@ class DeviceData:
         self.shape = (int(n), int(dz))
         self._fin = weakref.finalize(self, N.load().bc_data_destroy, h)
 
+    def rows(self, local_idx):
+        """Rows by LOCAL index, on the host (m x dz)."""
+        idx = np.ascontiguousarray(local_idx, dtype=np.int64).ravel()
+        out = np.empty((idx.shape[0], self.shape[1]))
+        N.call('bc_data_gather_rows', self.h, _ptr(idx), int(idx.shape[0]), _ptr(out))
+        return out
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)):
+            return self.rows([idx])[0]
+        return self.rows(idx)
+
+    def __len__(self):
+        return self.shape[0]
+
     @classmethod
     def from_torch(cls, t, ctx=None, row_offset=0):
         """Borrow a contiguous float64 CUDA tensor (kept alive by this object)."""

@@ -84,6 +84,8 @@ int bc_ctx_enable_timing(bc_ctx* ctx, int on);
 int bc_data_from_host(bc_ctx* ctx, const double* z_rowmajor, int64_t n_rows, int32_t dz, bc_data** out);
 /* borrow an existing device buffer (row-major n_rows x dz doubles); not freed by destroy */
 int bc_data_from_device(bc_ctx* ctx, const void* z_dev, int64_t n_rows, int32_t dz, bc_data** out);
+/* rows by LOCAL index -> m x dz row-major on the host (`pts = data[idcs]`, hilbert.py:33) */
+int bc_data_gather_rows(bc_data* d, const int64_t* local_idx, int64_t m, double* out);
 int bc_data_destroy(bc_data* d);
 
 /* ---- Phi: the N x S matrix of row-centred (beta-)log-likelihoods ------- */
