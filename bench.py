@@ -141,13 +141,20 @@ def main():
     prj = bc.DeviceProjector(lambda n, w, p: theta, S, model, ctx=ctx)
 
     # ---------------- K1: projection, points*dims/s
+    import gc
+    gc.collect()
+    gc.disable()          # a gen-2 collection (tens of ms with torch loaded) must not land in a timed region
     ctx.enable_timing(True)
     prj.project(data)                      # warm-up (also allocates Phi)
     barrier()
     ctx.kernel_time_reset()
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.proj_reps):
+    for i in range(args.proj_reps):
+        ta = time.perf_counter()
         phi = prj.project(data)
+        if os.environ.get('BC_BENCH_VERBOSE'):
+            sys.stderr.write('project rep %d: %.3f ms (host call incl. sync)\n' % (i, 1e3 * (time.perf_counter() - ta)))
     barrier()
     t_proj = (time.perf_counter() - t0) / args.proj_reps
     if world > 1:

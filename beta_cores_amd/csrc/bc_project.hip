@@ -16,6 +16,7 @@
 //   model_linreg.py:4-10 / model_neurlinr.py:90-97,102-110 / model_lr.py:72-86 / gaussian.py:7-15,34-62
 #include "bc_internal.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
 // JT = 16-row sub-tiles per wave (2 -> 4 waves per 128-row tile, 1 -> 8 waves; the latter keeps
 // the accumulators of a 200+-sample projection within the register file).
 template <int MODEL, int NT, int KC, int JT>
-__global__ __launch_bounds__(128 / (16 * JT) * 64, 2) void k_project(ProjArgs a) {
+__global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2) void k_project(ProjArgs a) {
   constexpr int NTHR = 128 / (16 * JT) * 64;
   constexpr int LDZ = KC + 1;    // odd stride: rows (2j, 2j+1) of a lane pair hit distinct banks
   constexpr int LDT = KC + 2;
@@ -101,35 +102,40 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, 2) void k_project(ProjArgs a)
 #pragma unroll
     for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
 
+  // Staging through buffer loads: a wave-uniform descriptor per operand (SGPRs), ONE 32-bit
+  // per-thread byte offset shared by all passes, and a scalar offset per pass -- no 64-bit
+  // address VGPRs.  The Z descriptor covers exactly this tile's valid rows, so rows past the end
+  // of the data read as 0 (hardware range check); columns past D are clamped to a valid column
+  // and multiply the zero padding of Theta.
+  static_assert(NTHR % KC == 0 && NTHR % (KC / 2) == 0, "staging map");
+  constexpr int ZROWS = NTHR / KC;          // rows of Z covered by one pass
+  constexpr int TROWS = NTHR / (KC / 2);    // rows of Theta covered by one pass
+  const int zc = tid % KC, zrw = tid / KC;
+  const int tc = (tid % (KC / 2)) * 2, trw = tid / (KC / 2);
+  const long long rows_here = (a.n_rows - r0) < BC_TILE ? (a.n_rows - r0) : BC_TILE;
+  const auto zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0,
+                                                       (int)(rows_here * a.dz * 8), 0x00020000);
+  const auto trsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.theta, 0, NT * 16 * a.dk * 8, 0x00020000);
+  const int toff = (trw * a.dk + tc) * 8;
   double zr[ZP];
   double2 tr[TP];
   auto load_chunk = [&](int d0) {
+    const int col = min(d0 + zc, a.d - 1);
+    const int voff = (zrw * a.dz + col) * 8;
 #pragma unroll
-    for (int q = 0; q < ZP; ++q) {
-      const int idx = tid + q * NTHR;
-      const int r = idx / KC, cc = idx % KC;
-      const long long gr = r0 + r;
-      zr[q] = (gr < a.n_rows && d0 + cc < a.d) ? a.z[(size_t)gr * a.dz + d0 + cc] : 0.0;
-    }
+    for (int q = 0; q < ZP; ++q)
+      zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * ZROWS * a.dz * 8, 0));
 #pragma unroll
-    for (int q = 0; q < TP; ++q) {
-      const int idx = tid + q * NTHR;
-      const int r = idx / (KC / 2), cc = (idx % (KC / 2)) * 2;
-      tr[q] = (idx < TN) ? *reinterpret_cast<const double2*>(a.theta + (size_t)r * a.dk + d0 + cc) : make_double2(0., 0.);
-    }
+    for (int q = 0; q < TP; ++q)   // rows past NT*16 are outside the descriptor and read as 0
+      tr[q] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, (q * TROWS * a.dk + d0) * 8, 0));
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int q = 0; q < ZP; ++q) {
-      const int idx = tid + q * NTHR;
-      const int r = idx / KC, cc = idx % KC;
-      Zl[r * LDZ + cc] = zr[q];
-    }
+    for (int q = 0; q < ZP; ++q) Zl[(q * ZROWS + zrw) * LDZ + zc] = zr[q];
 #pragma unroll
     for (int q = 0; q < TP; ++q) {
-      const int idx = tid + q * NTHR;
-      const int r = idx / (KC / 2), cc = (idx % (KC / 2)) * 2;
-      if (idx < TN) *reinterpret_cast<double2*>(Tl + r * LDT + cc) = tr[q];
+      const bool ok = (q + 1) * NTHR <= TN || tid + q * NTHR < TN;
+      if (ok) *reinterpret_cast<double2*>(Tl + (q * TROWS + trw) * LDT + tc) = tr[q];
     }
   };
 
@@ -371,7 +377,11 @@ template <int MODEL>
 static int launch_project_nt(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int ntsel) {
   switch (ntsel) {
     case 4: return launch_project<MODEL, 4, 32, 2>(ctx, a, ntiles);
-    case 7: return launch_project<MODEL, 7, 32, 2>(ctx, a, ntiles);
+    case 7: {
+      static const int jt1 = getenv("BC_K1_JT1") ? atoi(getenv("BC_K1_JT1")) : 0;
+      if (jt1) return launch_project<MODEL, 7, 32, 1>(ctx, a, ntiles);
+      return launch_project<MODEL, 7, 32, 2>(ctx, a, ntiles);
+    }
     case 13: return launch_project<MODEL, 13, 16, 1>(ctx, a, ntiles);
     default: return launch_project<MODEL, 16, 16, 1>(ctx, a, ntiles);
   }
