@@ -76,7 +76,13 @@ class _GreedyVICoreset(Coreset):
             corevecs = np.asarray(self._proj(p, beta))
         else:
             corevecs = np.zeros((0, vecs.shape[1]))
-        return vecs, sum_scaling, sub_idcs, group_idcs, corevecs
+        return self._on_device(vecs), sum_scaling, sub_idcs, group_idcs, corevecs
+
+    def _on_device(self, vecs):
+        """Black-box projectors hand back a host array; its N-row reductions still run on the GPU."""
+        if isinstance(vecs, DevicePhi):
+            return vecs
+        return DevicePhi.from_host(np.ascontiguousarray(vecs, dtype=np.float64), ctx=getattr(self.ll_projector, 'ctx', None))
 
     def _colsum(self, vecs):
         b = vecs.sum(axis=0)
@@ -85,26 +91,21 @@ class _GreedyVICoreset(Coreset):
         return b
 
     def _best_correlation(self, vecs, resid, drop_zero_rows):
-        """argmax_i vecs[i].resid / ||vecs[i]|| / S and its value (bcores.py:78-81).
-        The index refers to the zero-row-filtered matrix when `drop_zero_rows`
-        (bcores.py:67-68), like the reference."""
+        """argmax_i vecs[i].resid / ||vecs[i]|| / S and its value (bcores.py:78-81), one K3 sweep.
+        All-zero rows never win (their correlation is 0/0); when `drop_zero_rows` the index
+        refers to the zero-row-filtered matrix, like the reference (bcores.py:67-68)."""
         S = vecs.shape[1]
-        if isinstance(vecs, DevicePhi):
-            best, score = vecs.argmax(resid, mode=1, post_div=float(S))
-            if self.comm is not None:
-                cands = self.comm.gather_host(np.array([score, float(best)]))
-                best, score = -1, -np.inf
-                for sc, bi in cands:
-                    bi = int(bi)
-                    if bi >= 0 and (best < 0 or sc > score or (sc == score and bi < best)):
-                        best, score = bi, sc
-            elif drop_zero_rows and best >= 0 and vecs.norm_stats()[0] > 0:
-                best -= int((vecs.norms()[:best] == 0.).sum())
-            return best, score
-        if drop_zero_rows:
-            vecs = vecs[~np.all(vecs == 0., axis=1)]
-        corrs = vecs.dot(resid) / np.sqrt((vecs ** 2).sum(axis=1)) / S
-        return int(np.argmax(corrs)), corrs.max()
+        best, score = vecs.argmax(resid, mode=1, post_div=float(S))
+        if self.comm is not None:
+            cands = self.comm.gather_host(np.array([score, float(best)]))
+            best, score = -1, -np.inf
+            for sc, bi in cands:
+                bi = int(bi)
+                if bi >= 0 and (best < 0 or sc > score or (sc == score and bi < best)):
+                    best, score = bi, sc
+        elif drop_zero_rows and best >= 0 and vecs.norm_stats()[0] > 0:
+            best -= int((vecs.norms()[:best] == 0.).sum())
+        return best, score
 
     def _row(self, f):
         if self.comm is None:

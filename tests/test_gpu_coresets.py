@@ -1,0 +1,122 @@
+"""GPU parity of the coreset drivers (BetaCoreset / SparseVI / HilbertCoreset) against the
+goldens generated from the reference and against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import models_ref as M
+from oracle import coreset_ref as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def bc():
+    import beta_cores_amd as bc
+    bc.default_context()
+    return bc
+
+
+def make_sampler(Z, E):
+    D = Z.shape[1] - 1
+
+    def sampler(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+        mu, L, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+    return sampler
+
+
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+@pytest.mark.parametrize('projector', ['device', 'blackbox'])
+def test_f5_greedy_vi_goldens(bc, nm, projector):
+    g = load_golden('f5_greedy_vi')
+    Z, E = g['Z'], g['E']
+    S = E.shape[0]
+    beta, opt_itrs = float(g['beta']), int(g['opt_itrs'])
+    sampler = make_sampler(Z, E)
+    model = bc.likelihoods.LinearRegression(1.0)
+    sched = lambda i: 0.1 / (1. + i)
+    if nm == 'bcores':
+        if projector == 'device':
+            prj = bc.DeviceBetaProjector(sampler, S, model)
+        else:
+            prj = bc.BetaBlackBoxProjector(sampler, S, lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0),
+                                           lambda z, t: M.linreg_loglik(z, t, 1.0), None)
+        alg = bc.BetaCoreset(Z, prj, opt_itrs=opt_itrs, step_sched=sched, beta=beta, learn_beta=False)
+    else:
+        if projector == 'device':
+            prj = bc.DeviceProjector(sampler, S, model)
+        else:
+            prj = bc.BlackBoxProjector(sampler, S, lambda z, t: M.linreg_loglik(z, t, 1.0))
+        alg = bc.SparseVICoreset(Z, prj, opt_itrs=opt_itrs, step_sched=sched)
+    for m in range(5):
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-5, atol=1e-12)
+        got = alg.get()
+        np.testing.assert_array_equal(got[2], g['%s_idcs_%d' % (nm, m)])
+        np.testing.assert_allclose(got[0], g['%s_wts_%d' % (nm, m)], rtol=1e-5)
+        assert np.array_equal(got[1], Z[got[2]])
+    if nm == 'bcores':
+        assert len(alg.get()) == 4 and alg.get()[3] == beta           # bcores.py:155-156
+    assert alg.error() == 0.                                          # bcores.py:152-153
+
+
+def test_beta_coreset_larger_vs_oracle(bc):
+    """beta-Cores on contaminated data (10% outliers), full-data mode: every gradient call
+    re-projects all N rows on the device (K1 + K2), selection is a K3 sweep."""
+    rng = np.random.RandomState(21)
+    N, D, S = 6000, 10, 64
+    X = rng.randn(N, D)
+    y = X.dot(rng.randn(D)) + rng.randn(N)
+    out = rng.choice(N, N // 10, replace=False)
+    y[out] = rng.normal(10., .5, out.shape[0])
+    Z = np.hstack((X, y[:, None]))
+    E = rng.randn(S, D)
+    sampler = make_sampler(Z, E)
+    beta = 0.1
+    ref = C.RefGreedyVI(Z, lambda pts, th: C.project_f(lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0), pts, th, beta),
+                        lambda w, p: sampler(S, w, p), 8, lambda i: 0.1 / (1. + i))
+    alg = bc.BetaCoreset(Z, bc.DeviceBetaProjector(sampler, S, bc.likelihoods.LinearRegression(1.0)), opt_itrs=8,
+                         step_sched=lambda i: 0.1 / (1. + i), beta=beta, learn_beta=False)
+    for m in range(8):
+        ref.build(1)
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, ref.idcs)
+        np.testing.assert_allclose(alg.wts, ref.wts, rtol=1e-5, atol=1e-12)
+
+
+def test_learn_beta_is_rejected_like_the_reference_would_fail(bc):
+    g = load_golden('f5_greedy_vi')
+    Z, E = g['Z'], g['E']
+    prj = bc.DeviceBetaProjector(make_sampler(Z, E), E.shape[0], bc.likelihoods.LinearRegression(1.0))
+    alg = bc.BetaCoreset(Z, prj, opt_itrs=2, beta=0.1)                # learn_beta defaults to True (bcores.py:11)
+    with pytest.raises(NotImplementedError):
+        alg.build(1, 1)
+
+
+def test_hilbert_subsample_and_size_guards(bc):
+    g = load_golden('f3_hilbert_linreg')
+    Z, th = g['Z'], g['th']
+    prj = bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0))
+    np.random.seed(7)
+    h = bc.HilbertCoreset(Z, prj, n_subsample=300)
+    np.random.seed(7)
+    sub = np.random.randint(Z.shape[0], size=300)
+    assert np.array_equal(h.sub_idcs, sub)
+    h.build(10, 10)
+    wts, pts, idcs = h.get()
+    assert set(idcs.tolist()) <= set(sub.tolist()) and np.array_equal(pts, Z[idcs]) and np.all(wts > 0)
+    with pytest.raises(ValueError):
+        h.build(5, 12)                                                # hilbert.py:27-28: itrs + size > sz
+    h.reset()
+    assert h.size() == 0 and h.snnls.size() == 0
+
+
+def test_fresh_state_per_instance(bc):
+    """The reference's shared default arrays (coreset.py:8) are deliberately NOT reproduced."""
+    a = bc.Coreset()
+    b = bc.Coreset()
+    assert a.wts is not b.wts and a.idcs is not b.idcs and a.pts is not b.pts
