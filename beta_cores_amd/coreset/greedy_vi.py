@@ -96,14 +96,21 @@ class _GreedyVICoreset(Coreset):
         refers to the zero-row-filtered matrix, like the reference (bcores.py:67-68)."""
         S = vecs.shape[1]
         best, score = vecs.argmax(resid, mode=1, post_div=float(S))
+        n_zero = vecs.norm_stats()[0]
         if self.comm is not None:
-            cands = self.comm.gather_host(np.array([score, float(best)]))
+            cands = self.comm.gather_host(np.array([score, float(best), float(n_zero)]))
             best, score = -1, -np.inf
-            for sc, bi in cands:
+            for sc, bi, _ in cands:
                 bi = int(bi)
                 if bi >= 0 and (best < 0 or sc > score or (sc == score and bi < best)):
                     best, score = bi, sc
-        elif drop_zero_rows and best >= 0 and vecs.norm_stats()[0] > 0:
+            if drop_zero_rows and best >= 0 and cands[:, 2].sum() > 0:
+                before = 0.
+                if n_zero > 0:
+                    gidx = vecs.row_offset + np.flatnonzero(vecs.norms() == 0.)
+                    before = float((gidx < best).sum())
+                best -= int(self.comm.sum_in_rank_order(np.array([before]))[0])
+        elif drop_zero_rows and best >= 0 and n_zero > 0:
             best -= int((vecs.norms()[:best] == 0.).sum())
         return best, score
 

@@ -40,6 +40,7 @@ class Context:
         N.call('bc_ctx_create', int(device), C.c_void_p(stream) if stream else None, C.byref(h))
         self.h = h
         self.device = int(device)
+        self.stream_handle = int(stream) if stream else None    # None: library-owned stream
         self._fin = weakref.finalize(self, N.load().bc_ctx_destroy, h)
 
     def sync(self):

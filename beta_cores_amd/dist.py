@@ -40,6 +40,12 @@ class _Exchange:
         self.send_ptr = self.send.data_ptr()
         self.all_ptr = self.all.data_ptr()
         self.on_device = comm.backend == 'nccl'
+        if self.on_device:
+            cur = torch.cuda.current_stream(dev).cuda_stream
+            if ctx.stream_handle is None or ctx.stream_handle != cur:
+                raise RuntimeError('RCCL exchange: create the Context on torch\'s current stream '
+                                   '(Context(device, stream=torch.cuda.current_stream().cuda_stream) with a '
+                                   'non-default torch stream) so collectives order with the kernels')
         if not self.on_device:
             self.h_send = torch.zeros(rec_len, dtype=torch.float64).pin_memory()
             self.h_all = torch.zeros(comm.world * rec_len, dtype=torch.float64).pin_memory()

@@ -1,0 +1,101 @@
+"""Worker for the multi-process tests (one process per rank).  argv: mode out_prefix.
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def problem(n=3000, s=40, seed=17):
+    rng = np.random.RandomState(seed)
+    base = rng.randn(n, 8).dot(rng.randn(8, s)) + 0.3 * rng.randn(n, s)
+    return base - base.mean(axis=1)[:, None]
+
+
+def linreg_problem(n=5000, d=12, s=48, seed=23):
+    rng = np.random.RandomState(seed)
+    X = rng.randn(n, d)
+    y = X.dot(rng.randn(d)) + rng.randn(n)
+    Z = np.hstack((X, y[:, None]))
+    th = rng.randn(s, d) * 0.3
+    return Z, th
+
+
+def main():
+    mode, out = sys.argv[1], sys.argv[2]
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import beta_cores_amd as bc
+    comm = bc.ShardComm()
+    res = {}
+    if mode == 'comm':
+        v = np.arange(5, dtype=np.float64) * (rank + 1) + 0.1 * rank
+        res['sum'] = comm.sum_in_rank_order(v)
+        res['gather'] = comm.gather_host(v)
+        res['offset'] = np.array(comm.row_offset(100 + rank))
+        res['total'] = np.array(comm.total_rows(100 + rank))
+    elif mode in ('fake_giga', 'fake_fw', 'fake_giga_stepwise'):
+        from fake_engine import NumpyShardEngine
+        phi = problem()
+        b = phi.sum(axis=0)
+        bounds = bc.shard_bounds(phi.shape[0], world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        alg = 'fw' if mode == 'fake_fw' else 'giga'
+        eng = NumpyShardEngine(phi[lo:hi], b, alg, lo, comm)
+        cls = bc.snnls.FrankWolfe if alg == 'fw' else bc.snnls.GIGA
+        s = cls(phi[lo:hi].T, b, comm=comm, engine=eng)
+        assert s.n_total == phi.shape[0] and s.row_offset == lo
+        if mode.endswith('stepwise'):
+            s.build_stepwise(30)
+        else:
+            s.build(30)
+        idx, val = s.sparse_weights()
+        res['idx'], res['val'], res['err'] = idx, val, np.array(s.error())
+        res['w_dense'] = s.weights()
+    elif mode in ('gpu_hilbert', 'gpu_fw', 'gpu_bcores'):
+        Z, th = linreg_problem()
+        bounds = bc.shard_bounds(Z.shape[0], world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        ctx = bc.Context(device=0)                    # every rank shares GPU 0; records travel over gloo
+        bc.set_default_context(ctx)
+        model = bc.likelihoods.LinearRegression(1.0)
+        if mode == 'gpu_bcores':
+            E = np.random.RandomState(3).randn(th.shape[0], Z.shape[1] - 1)
+            from oracle import models_ref as M
+
+            def sampler(sz, wts, pts):
+                if pts.shape[0] == 0:
+                    wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+                mu, L, _ = M.linreg_weighted_post(np.zeros(Z.shape[1] - 1), np.eye(Z.shape[1] - 1), 1.0, pts, wts)
+                return mu + E.dot(L.T)
+            prj = bc.DeviceBetaProjector(sampler, th.shape[0], model, ctx=ctx)
+            alg = bc.BetaCoreset(Z[lo:hi], prj, opt_itrs=5, step_sched=lambda i: 0.1 / (1. + i), beta=0.1,
+                                 learn_beta=False, comm=comm)
+            for m in range(6):
+                alg.build(1, m + 1)
+            res['idx'], res['val'] = alg.idcs, alg.wts
+            res['pts'] = alg.pts
+        else:
+            prj = bc.DeviceProjector(lambda n, w, p: th, th.shape[0], model, ctx=ctx)
+            cls = bc.snnls.FrankWolfe if mode == 'gpu_fw' else bc.snnls.GIGA
+            h = bc.HilbertCoreset(Z[lo:hi], prj, snnls=cls, comm=comm)
+            h.build(25, 25)
+            wts, pts, idcs = h.get()
+            res['idx'], res['val'], res['err'] = idcs, wts, np.array(h.error())
+            res['pts'] = pts
+            res['trace_f'] = h.snnls._eng.trace()[0]
+            local = (idcs >= lo) & (idcs < hi)
+            assert np.array_equal(pts[local], Z[idcs[local]])
+            assert np.all(np.isnan(pts[~local]))
+    np.savez(out + '.rank%d.npz' % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

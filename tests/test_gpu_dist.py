@@ -1,0 +1,62 @@
+"""The sharded path on real kernels: two ranks share GPU 0, each owns half of the rows
+(K1 / K2 / K3 on its shard), candidate records travel over gloo, the finish kernel runs
+replicated.  Results must equal the single-rank device run and the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from test_dist_cpu import launch                    # noqa: E402
+from dist_worker import linreg_problem              # noqa: E402
+from oracle import models_ref as M                  # noqa: E402
+from oracle import coreset_ref as C                 # noqa: E402
+from oracle import RefGIGA, RefFrankWolfe           # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('mode', ['gpu_hilbert', 'gpu_fw'])
+def test_two_ranks_one_gpu_hilbert(tmp_path, mode):
+    import beta_cores_amd as bc
+    Z, th = linreg_problem()
+    ll = lambda z, t: M.linreg_loglik(z, t, 1.0)
+    ref = C.RefHilbert(Z, ll, th, RefFrankWolfe if mode == 'gpu_fw' else RefGIGA)
+    ref.build(25, 25)
+    single = bc.HilbertCoreset(Z, bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0)),
+                               snnls=bc.snnls.FrankWolfe if mode == 'gpu_fw' else bc.snnls.GIGA)
+    single.build(25, 25)
+    r0, r1 = launch(mode, tmp_path)
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r['idx'], ref.idcs)
+        np.testing.assert_array_equal(r['idx'], single.idcs)
+        np.testing.assert_allclose(r['val'], ref.wts, rtol=1e-5)
+        np.testing.assert_allclose(r['val'], single.wts, rtol=1e-9)     # only b's summation order differs
+        np.testing.assert_array_equal(r['trace_f'], single.snnls._eng.trace()[0])
+    assert np.array_equal(r0['val'], r1['val'])                         # replicated state is bit-identical
+    # each rank fills pts for the rows it owns; together they cover the coreset
+    pts = np.where(np.isnan(r0['pts']), r1['pts'], r0['pts'])
+    assert np.array_equal(pts, Z[ref.idcs])
+
+
+def test_two_ranks_one_gpu_beta_coreset(tmp_path):
+    import beta_cores_amd as bc
+    Z, th = linreg_problem()
+    D = Z.shape[1] - 1
+    E = np.random.RandomState(3).randn(th.shape[0], D)
+
+    def sampler(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+        mu, L, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+    ref = C.RefGreedyVI(Z, lambda pts, t: C.project_f(lambda z, tt, b: M.linreg_beta_lik(z, tt, b, 1.0), pts, t, 0.1),
+                        lambda w, p: sampler(0, w, p), 5, lambda i: 0.1 / (1. + i))
+    ref.build(6)
+    r0, r1 = launch('gpu_bcores', tmp_path)
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r['idx'], ref.idcs)
+        np.testing.assert_allclose(r['val'], ref.wts, rtol=1e-5, atol=1e-12)
+        assert np.array_equal(r['pts'], ref.pts)                        # selected rows are broadcast exactly
