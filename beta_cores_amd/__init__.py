@@ -16,9 +16,11 @@ from .device import Context, DeviceData, DevicePhi, default_context, set_default
 from .coreset import (Coreset, HilbertCoreset, BetaCoreset, SparseVICoreset, Projector, BlackBoxProjector,
                       BetaBlackBoxProjector, DeviceProjector, DeviceBetaProjector)
 from . import likelihoods
+from .posterior import weighted_gram, weighted_post, weighted_post_corrected, gaussian_weighted_post
 from .dist import ShardComm, shard_bounds
 
 __all__ = ['util', 'snnls', 'likelihoods', 'NumericalPrecisionError', 'Context', 'DeviceData', 'DevicePhi',
            'default_context', 'set_default_context', 'Coreset', 'HilbertCoreset', 'BetaCoreset', 'SparseVICoreset',
            'Projector', 'BlackBoxProjector', 'BetaBlackBoxProjector', 'DeviceProjector', 'DeviceBetaProjector',
-           'ShardComm', 'shard_bounds']
+           'ShardComm', 'shard_bounds', 'weighted_gram', 'weighted_post', 'weighted_post_corrected',
+           'gaussian_weighted_post']

@@ -250,7 +250,7 @@ int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_
   A((void**)&p->colsum, (size_t)s * sizeof(double));
   A((void**)&p->tile_part, nt * s * sizeof(double));
   A((void**)&p->stats, 4 * sizeof(double));
-  p->stat_blocks = (int)(nt < 512 ? nt : 512);
+  p->stat_blocks = (int)(nt < 256 ? nt : 256);
   A((void**)&p->part2, (size_t)p->stat_blocks * s * sizeof(double));
   A((void**)&p->nstat, (size_t)p->stat_blocks * 2 * sizeof(double));
   A((void**)&p->blk_val, (size_t)p->sweep_blocks * sizeof(double));
@@ -378,23 +378,52 @@ __global__ __launch_bounds__(256) void k_stats_stage1(const double* __restrict__
   }
 }
 
-// stage 2: single block, partials combined in block order.
-__global__ __launch_bounds__(256) void k_stats_stage2(const double* __restrict__ part2, const double* __restrict__ nstat,
-                                                     int nb, int s, double* __restrict__ colsum,
-                                                     double* __restrict__ stats) {
-  for (int k = threadIdx.x; k < s; k += blockDim.x) {
+// stage 2: single block; the nb partials of a column are split over 8 thread groups (fixed
+// contiguous ranges) and the group sums are combined in group order => deterministic.
+__global__ __launch_bounds__(1024) void k_stats_stage2(const double* __restrict__ part2, const double* __restrict__ nstat,
+                                                      int nb, int s, double* __restrict__ colsum,
+                                                      double* __restrict__ stats) {
+  __shared__ double part[1024];
+  const int G = 8, per = (nb + G - 1) / G;
+  const int g = threadIdx.x >> 7, lane = threadIdx.x & 127;
+  for (int k0 = 0; k0 < s; k0 += 128) {
+    const int k = k0 + lane;
     double acc = 0.0;
-    for (int b = 0; b < nb; ++b) acc += part2[(size_t)b * s + k];
-    colsum[k] = acc;
-  }
-  if (threadIdx.x == 0) {
-    double ns = 0.0, nz = 0.0;
-    for (int b = 0; b < nb; ++b) {
-      ns += nstat[2 * b];
-      nz += nstat[2 * b + 1];
+    if (k < s) {
+      const int b0 = g * per, b1 = (b0 + per) < nb ? (b0 + per) : nb;
+      for (int b = b0; b < b1; ++b) acc += part2[(size_t)b * s + k];
     }
-    stats[0] = ns;
-    stats[1] = nz;
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && k < s) {
+      double t = part[lane];
+      for (int gg = 1; gg < G; ++gg) t += part[gg * 128 + lane];
+      colsum[k] = t;
+    }
+    __syncthreads();
+  }
+  // norm statistics: same split over the first 2 x G x ... threads
+  double ns = 0.0, nz = 0.0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+    ns += nstat[2 * b];
+    nz += nstat[2 * b + 1];
+  }
+  part[threadIdx.x] = ns;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    const int m = nb < 1024 ? nb : 1024;
+    for (int i = 0; i < m; ++i) t += part[i];
+    stats[0] = t;
+  }
+  __syncthreads();
+  part[threadIdx.x] = nz;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    const int m = nb < 1024 ? nb : 1024;
+    for (int i = 0; i < m; ++i) t += part[i];
+    stats[1] = t;
   }
 }
 
@@ -405,7 +434,7 @@ int bc_phi_finish_stats(bc_phi* p) {
   hipLaunchKernelGGL(k_stats_stage1, dim3(nb), dim3(256), 0, ctx->stream, p->tile_part, (long long)p->ntiles, p->s,
                      p->norms, (long long)p->n_rows, chunk > 0 ? chunk : 1, p->part2, p->nstat);
   BC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_stats_stage2, dim3(1), dim3(256), 0, ctx->stream, p->part2, p->nstat, nb, p->s, p->colsum,
+  hipLaunchKernelGGL(k_stats_stage2, dim3(1), dim3(1024), 0, ctx->stream, p->part2, p->nstat, nb, p->s, p->colsum,
                      p->stats);
   BC_HIP(hipGetLastError());
   BC_HIP(hipMemcpyAsync(ctx->pinned, p->stats, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,2 +1,212 @@
+// K4: weighted Gram matrix  Z^T diag(w) Z  of the data rows z = [x (D), y], from which the
+// posterior update takes  X^T W X  (D x D) and  X^T (w*y)  (D)   (model_linreg.py:29,31 ==
+// model_neurlinr.py:118,120:  (w[:,None]*X).T.dot(X)  and  (w[:,None]*Y[:,None]*X).sum(axis=0)).
+//
+// This is the one genuinely GEMM-shaped reduction on the path (2*N*Dz^2 flop against 8*N*Dz
+// bytes: intensity Dz/4 flop/B), so it runs on the fp64 matrix cores: v_mfma_f64_16x16x4_f64
+// with A = (w*Z)^T panel, B = Z panel, both staged through LDS in 16-row slabs (buffer loads,
+// register prefetch of the next slab).  Only the upper-triangular BT x BT tiles are computed;
+// the row range is split over the grid (split-K) and the per-split partial tiles are summed in
+// split order by a second kernel, so the result is run-to-run deterministic.
 #include "bc_internal.h"
-extern "C" int bc_weighted_gram(bc_ctx* ctx, const bc_data* data, const double* w, double* out_xtwx, double* out_xtwy){ bc_set_error("bc_weighted_gram: not built yet"); return -1; }
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct GramArgs {
+  const double* z;        // [n_rows][dz]
+  const double* w;        // [n_rows] or null (all ones)
+  double* partial;        // [splits][ntri][BT][BT]
+  long long n_rows;
+  long long rows_per_split;   // multiple of KR
+  int dz, nt;             // nt = number of BT-wide column tiles
+  int ntri;               // nt*(nt+1)/2
+};
+
+template <int BT>
+__global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
+  constexpr int KR = 16;                 // rows per LDS slab
+  constexpr int LDX = BT + 16;           // row stride == 16 (mod 32) doubles: conflict-free 2-row x 16-col reads
+  constexpr int MT = BT / 32;            // MFMA tiles per wave per dimension (wave tile = BT/2 x BT/2)
+  constexpr int LP = (KR * BT) / 256;    // 8-byte loads per thread per panel per slab
+  __shared__ double Al[KR * LDX];
+  __shared__ double Bl[KR * LDX];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int wa = wv >> 1, wb = wv & 1;   // wave position inside the block tile
+  // blockIdx.x = split * ntri + tri  (tiles of one split are neighbours => they share rows in L2)
+  const int tri = blockIdx.x % a.ntri;
+  const long long split = blockIdx.x / a.ntri;
+  int ta = 0, rem = tri;                 // tri -> (ta <= tb)
+  while (rem >= a.nt - ta) { rem -= a.nt - ta; ++ta; }
+  const int tb = ta + rem;
+  const int a0 = ta * BT, b0 = tb * BT;
+  const long long r_begin = split * a.rows_per_split;
+  long long r_end = r_begin + a.rows_per_split;
+  if (r_end > a.n_rows) r_end = a.n_rows;
+
+  double4_t acc[MT][MT];
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < MT; ++y) acc[x][y] = (double4_t){0., 0., 0., 0.};
+
+  // staging map: thread -> (row lr = idx / BT, col lc = idx % BT) of the slab, LP passes
+  const int lc = tid % BT, lr0 = tid / BT;
+  constexpr int RPP = 256 / BT;          // rows covered per pass
+  const bool a_ok = a0 + lc < a.dz, b_ok = b0 + lc < a.dz;
+  const int ca = a_ok ? a0 + lc : 0, cb = b_ok ? b0 + lc : 0;
+  double ra[LP], rb[LP];
+  auto load_slab = [&](long long r0) {
+    const long long left = r_end - r0;
+    const long long rows_here = left < KR ? (left > 0 ? left : 0) : KR;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0, (int)(rows_here * a.dz * 8), 0x00020000);
+#pragma unroll
+    for (int q = 0; q < LP; ++q) {
+      const int lr = lr0 + q * RPP;
+      double wr = 1.0;
+      if (a.w) wr = (r0 + lr < r_end) ? a.w[r0 + lr] : 0.0;
+      const double va = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + ca) * 8, 0, 0));
+      const double vb = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + cb) * 8, 0, 0));
+      ra[q] = a_ok ? wr * va : 0.0;      // A panel carries the weights: (w[:,None]*X)
+      rb[q] = b_ok ? vb : 0.0;
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int q = 0; q < LP; ++q) {
+      const int lr = lr0 + q * RPP;
+      Al[lr * LDX + lc] = ra[q];
+      Bl[lr * LDX + lc] = rb[q];
+    }
+  };
+
+  if (r_begin < r_end) load_slab(r_begin);
+  for (long long r0 = r_begin; r0 < r_end; r0 += KR) {
+    store_slab();
+    __syncthreads();
+    if (r0 + KR < r_end) load_slab(r0 + KR);
+#pragma unroll
+    for (int kk = 0; kk < KR / 4; ++kk) {
+      double fa[MT], fb[MT];
+#pragma unroll
+      for (int x = 0; x < MT; ++x) fa[x] = Al[(kk * 4 + g) * LDX + wa * (BT / 2) + x * 16 + j];
+#pragma unroll
+      for (int y = 0; y < MT; ++y) fb[y] = Bl[(kk * 4 + g) * LDX + wb * (BT / 2) + y * 16 + j];
+#pragma unroll
+      for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int y = 0; y < MT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[x], fb[y], acc[x][y], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+  double* out = a.partial + ((size_t)split * a.ntri + tri) * BT * BT;
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < MT; ++y)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = wa * (BT / 2) + x * 16 + g + 4 * reg;
+        const int col = wb * (BT / 2) + y * 16 + j;
+        out[(size_t)row * BT + col] = acc[x][y][reg];
+      }
+}
+
+// sum the per-split partial tiles in split order and scatter them (and their mirror images)
+// into the dense dz x dz matrix
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ partial, long long splits, int ntri,
+                                                    int nt, int bt, int dz, double* __restrict__ out) {
+  const int tri = blockIdx.x;
+  int ta = 0, rem = tri;
+  while (rem >= nt - ta) { rem -= nt - ta; ++ta; }
+  const int tb = ta + rem;
+  for (int e = threadIdx.x; e < bt * bt; e += blockDim.x) {
+    double acc = 0.0;
+    for (long long sp = 0; sp < splits; ++sp) acc += partial[((size_t)sp * ntri + tri) * bt * bt + e];
+    const int r = ta * bt + e / bt, c = tb * bt + e % bt;
+    if (r < dz && c < dz) {
+      if (ta != tb || r <= c) {
+        out[(size_t)r * dz + c] = acc;
+        out[(size_t)c * dz + r] = acc;
+      }
+    }
+  }
+}
+
+template <int BT>
+static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, double* out_dev) {
+  const int dz = data->dz;
+  const int nt = (dz + BT - 1) / BT;
+  const int ntri = nt * (nt + 1) / 2;
+  const int KR = 16;
+  // enough blocks for ~8 per CU, at least 2 slabs per split
+  long long want_splits = ((long long)ctx->n_cu * 8 + ntri - 1) / ntri;
+  long long max_splits = (data->n_rows + 2 * KR - 1) / (2 * KR);
+  long long splits = want_splits < max_splits ? want_splits : max_splits;
+  if (splits < 1) splits = 1;
+  long long rps = (data->n_rows + splits - 1) / splits;
+  rps = ((rps + KR - 1) / KR) * KR;
+  if (rps < KR) rps = KR;
+  splits = (data->n_rows + rps - 1) / rps;
+  if (splits < 1) splits = 1;
+  double* partial = nullptr;
+  BC_HIP(hipMalloc((void**)&partial, (size_t)splits * ntri * BT * BT * sizeof(double)));
+  GramArgs a;
+  a.z = data->z;
+  a.w = w_dev;
+  a.partial = partial;
+  a.n_rows = data->n_rows;
+  a.rows_per_split = rps;
+  a.dz = dz;
+  a.nt = nt;
+  a.ntri = ntri;
+  int rc = bc_timer_begin(ctx, 2);
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    hipLaunchKernelGGL(k_gram<BT>, dim3((unsigned)(splits * ntri)), dim3(256), 0, ctx->stream, a);
+    e = hipGetLastError();
+  }
+  if (!rc && e == hipSuccess) rc = bc_timer_end(ctx, 2);
+  if (!rc && e == hipSuccess) {
+    hipLaunchKernelGGL(k_gram_reduce, dim3(ntri), dim3(256), 0, ctx->stream, partial, splits, ntri, nt, BT, dz, out_dev);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(partial);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
+  return rc;
+}
+
+extern "C" int bc_weighted_gram(bc_ctx* ctx, const bc_data* data, const double* w, double* out_xtwx, double* out_xtwy) {
+  if (!ctx || !data || !out_xtwx || !out_xtwy) { bc_set_error("bc_weighted_gram: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (data->ctx != ctx) { bc_set_error("bc_weighted_gram: data belongs to another context"); return BC_INVALID_ARGUMENT; }
+  const int dz = data->dz, d = dz - 1;
+  if (d <= 0) { bc_set_error("bc_weighted_gram: rows must be [x (D >= 1), y]"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  std::vector<double> full((size_t)dz * dz, 0.0);
+  if (data->n_rows > 0) {
+    double* w_dev = nullptr;
+    double* out_dev = nullptr;
+    hipError_t e = hipMalloc((void**)&out_dev, (size_t)dz * dz * sizeof(double));
+    if (e == hipSuccess && w) {
+      e = hipMalloc((void**)&w_dev, (size_t)data->n_rows * sizeof(double));
+      if (e == hipSuccess) e = hipMemcpyAsync(w_dev, w, (size_t)data->n_rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    }
+    int rc = BC_OK;
+    if (e == hipSuccess) rc = dz > 96 ? run_gram<128>(ctx, data, w_dev, out_dev) : run_gram<64>(ctx, data, w_dev, out_dev);
+    if (e == hipSuccess && !rc) e = hipMemcpy(full.data(), out_dev, (size_t)dz * dz * sizeof(double), hipMemcpyDeviceToHost);
+    if (w_dev) (void)hipFree(w_dev);
+    if (out_dev) (void)hipFree(out_dev);
+    if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
+    if (rc) return rc;
+  }
+  for (int r = 0; r < d; ++r) {
+    for (int c = 0; c < d; ++c) out_xtwx[(size_t)r * d + c] = full[(size_t)r * dz + c];
+    out_xtwy[r] = full[(size_t)r * dz + d];
+  }
+  return BC_OK;
+}

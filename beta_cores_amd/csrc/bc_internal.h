@@ -131,6 +131,28 @@ __device__ __forceinline__ double bc_block_sum(double v, double* red) {
   return red[16];
 }
 
+// block-wide sum of N values at once (one barrier pair for all of them); red must hold >= 17*N doubles
+template <int N>
+__device__ __forceinline__ void bc_block_sum_n(double (&v)[N], double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = bc_wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[i * 17 + wave] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[threadIdx.x * 17 + w];
+    red[threadIdx.x * 17 + 16] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = red[i * 17 + 16];
+}
+
 // element (row r, sample k) of a tiled Phi
 __device__ __forceinline__ size_t bc_tile_off(long long r, int k, int s) {
   return (size_t)(r >> 7) * (size_t)s * BC_TILE + (size_t)k * BC_TILE + (size_t)(r & (BC_TILE - 1));

@@ -25,6 +25,7 @@ struct SnnlsState {
   double sel_score;
   double sel_norm;
   double err_cur;       // ||A.w - b||_2 for the current w
+  double xw_sq;         // ||A.w||^2 for the current w
   int skip;             // select_fail | reached_limit : makes the next sweep a no-op
   int reached_limit;
   int retried;
@@ -84,23 +85,48 @@ __device__ __forceinline__ double dev_dot(const double* a, const double* b, int 
   return bc_block_sum(acc, red);
 }
 
-// xw = sum_j val[j] * cols[j], err = ||xw - b||
+// xw = sum_j val[j] * cols[j], err = ||xw - b||, ||xw||^2 and the positive count, all threads busy:
+// the list is split over G = blockDim/S thread groups (fixed split => deterministic), partial
+// vectors are combined in group order through LDS.
+#define BC_FIN_THREADS 512
 __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
+  __shared__ double part[BC_FIN_THREADS];
   const int s = P.s;
-  double e = 0.0;
-  for (int k = threadIdx.x; k < s; k += blockDim.x) {
+  const long long nnz = S.nnz;
+  double e = 0.0, q = 0.0, np = 0.0;
+  for (long long j = threadIdx.x; j < nnz; j += blockDim.x) np += (P.val[j] > 0.) ? 1.0 : 0.0;
+  if (s <= (int)blockDim.x) {
+    const int G = blockDim.x / s;
+    const int g = threadIdx.x / s, k = threadIdx.x - g * s;
     double acc = 0.0;
-    for (long long j = 0; j < S.nnz; ++j) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
-    P.xw[k] = acc;
-    const double d = acc - P.b[k];
-    e += d * d;
+    if (g < G)
+      for (long long j = g; j < nnz; j += G) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < s) {
+      double t = part[threadIdx.x];
+      for (int gg = 1; gg < G; ++gg) t += part[gg * s + threadIdx.x];
+      P.xw[threadIdx.x] = t;
+      const double d = t - P.b[threadIdx.x];
+      e = d * d;
+      q = t * t;
+    }
+  } else {
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      double acc = 0.0;
+      for (long long j = 0; j < nnz; ++j) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
+      P.xw[k] = acc;
+      const double d = acc - P.b[k];
+      e += d * d;
+      q += acc * acc;
+    }
   }
-  e = bc_block_sum(e, red);
+  double r3[3] = {e, q, np};
+  bc_block_sum_n<3>(r3, red);
   if (threadIdx.x == 0) {
-    S.err_cur = sqrt(e);
-    long long np = 0;
-    for (long long j = 0; j < S.nnz; ++j) np += (P.val[j] > 0.) ? 1 : 0;
-    S.npos = np;
+    S.err_cur = sqrt(r3[0]);
+    S.xw_sq = r3[1];
+    S.npos = (long long)r3[2];
   }
   __syncthreads();
 }
@@ -110,7 +136,7 @@ template <int ALG>
 __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
   const int s = P.s;
   if (ALG == BC_ALG_GIGA) {
-    double nw = sqrt(dev_dot(P.xw, P.xw, s, red));
+    double nw = sqrt(S.xw_sq);
     nw = (nw == 0.) ? 1. : nw;
     double bd = 0.0;
     for (int k = threadIdx.x; k < s; k += blockDim.x) {
@@ -166,8 +192,8 @@ __device__ void dev_pick(const SnnlsDev& P, SnnlsState& S, double* red) {
   __syncthreads();
   if (ALG == BC_ALG_OMP && S.sel_valid && S.npos > 0) {
     // neg = max over active j of -(An[:,j] . residual)
-    __shared__ double nv[4];
-    __shared__ long long ni[4], nj[4];
+    __shared__ double nv[16];
+    __shared__ long long ni[16], nj[16];
     double bv = -INFINITY;
     long long bi = LLONG_MAX, bj = -1;
     for (long long j = threadIdx.x; j < S.nnz; j += blockDim.x) {
@@ -214,19 +240,18 @@ template <int ALG>
 __device__ int dev_step_sizes(const SnnlsDev& P, const SnnlsState& S, double* red, double& alpha, double& beta) {
   const int s = P.s;
   if (ALG == BC_ALG_GIGA) {   // giga.py:42-61
-    double nw = sqrt(dev_dot(P.xw, P.xw, s, red));
+    double nw = sqrt(S.xw_sq);
     nw = (nw == 0.) ? 1. : nw;
     const double nf = sqrt(dev_dot(P.xf, P.xf, s, red));
-    double bxf = 0., bxw = 0., xwxf = 0.;
+    double r3[3] = {0., 0., 0.};
     for (int k = threadIdx.x; k < s; k += blockDim.x) {
       const double fn = P.xf[k] / nf, wn = P.xw[k] / nw;
-      bxf = fma(P.bn[k], fn, bxf);
-      bxw = fma(P.bn[k], wn, bxw);
-      xwxf = fma(wn, fn, xwxf);
+      r3[0] = fma(P.bn[k], fn, r3[0]);
+      r3[1] = fma(P.bn[k], wn, r3[1]);
+      r3[2] = fma(wn, fn, r3[2]);
     }
-    bxf = bc_block_sum(bxf, red);
-    bxw = bc_block_sum(bxw, red);
-    xwxf = bc_block_sum(xwxf, red);
+    bc_block_sum_n<3>(r3, red);
+    const double bxf = r3[0], bxw = r3[1], xwxf = r3[2];
     const double gA = bxf - bxw * xwxf;
     const double gB = bxw - bxf * xwxf;
     if (gA <= 0. || gB < 0.) return 1;
@@ -262,8 +287,10 @@ __device__ int dev_step_sizes(const SnnlsDev& P, const SnnlsState& S, double* re
       num = fma(d, P.b[k] - P.xw[k], num);
       den = fma(d, d, den);
     }
-    num = bc_block_sum(num, red);
-    den = bc_block_sum(den, red);
+    double r2[2] = {num, den};
+    bc_block_sum_n<2>(r2, red);
+    num = r2[0];
+    den = r2[1];
     if (num < 0. || den == 0. || num > den) return 1;
     alpha = 1. - num / den;
     beta = c * num / den;
@@ -273,18 +300,17 @@ __device__ int dev_step_sizes(const SnnlsDev& P, const SnnlsState& S, double* re
 
 // w = alpha*w ; w[f] = max(0, w[f] + beta)   (giga.py:63-64, frankwolfe.py:39-40)
 __device__ void dev_apply(const SnnlsDev& P, SnnlsState& S, double alpha, double beta) {
-  __shared__ long long slot;
+  __shared__ int slot;
   const int s = P.s;
   const long long f = S.sel_f;
-  for (long long j = threadIdx.x; j < S.nnz; j += blockDim.x) P.val[j] = alpha * P.val[j];
-  if (threadIdx.x == 0) {
-    long long at = -1;
-    for (long long j = 0; j < S.nnz; ++j)
-      if (P.idx[j] == f) { at = j; break; }
-    slot = at;
+  if (threadIdx.x == 0) slot = INT_MAX;
+  __syncthreads();
+  for (long long j = threadIdx.x; j < S.nnz; j += blockDim.x) {
+    P.val[j] = alpha * P.val[j];
+    if (P.idx[j] == f) atomicMin(&slot, (int)j);
   }
   __syncthreads();
-  long long at = slot;
+  long long at = slot == INT_MAX ? -1 : slot;
   if (at >= 0) {
     if (threadIdx.x == 0) {
       const double nv = P.val[at] + beta;
@@ -324,9 +350,9 @@ __device__ __forceinline__ void dev_trace(const SnnlsDev& P, SnnlsState& S, long
 
 // ------------------------------------------------------------------ kernels (grid = 1 block)
 template <int ALG>
-__global__ __launch_bounds__(256) void k_prep(SnnlsDev P, int reset_retry) {
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_prep(SnnlsDev P, int reset_retry) {
   __shared__ SnnlsState S;
-  __shared__ double red[32];
+  __shared__ double red[64];
   if (threadIdx.x == 0) {
     S = *P.st;
     if (reset_retry) S.retried = 0;
@@ -338,9 +364,9 @@ __global__ __launch_bounds__(256) void k_prep(SnnlsDev P, int reset_retry) {
 
 // one guarded greedy iteration, snnls.py:41-74
 template <int ALG>
-__global__ __launch_bounds__(256) void k_step_finish(SnnlsDev P) {
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P) {
   __shared__ SnnlsState S;
-  __shared__ double red[32];
+  __shared__ double red[64];
   __shared__ int sh_fail;
   if (threadIdx.x == 0) S = *P.st;
   __syncthreads();
@@ -360,7 +386,7 @@ __global__ __launch_bounds__(256) void k_step_finish(SnnlsDev P) {
     if (!fail) {
       // keep what is needed to revert (snnls.py:46-47)
       const long long nnz0 = S.nnz, npos0 = S.npos;
-      const double err0 = S.err_cur;
+      const double err0 = S.err_cur, xwsq0 = S.xw_sq;
       for (long long j = threadIdx.x; j < nnz0; j += blockDim.x) P.prev_val[j] = P.val[j];
       for (int k = threadIdx.x; k < s; k += blockDim.x) P.xw_prev[k] = P.xw[k];
       __syncthreads();
@@ -375,6 +401,7 @@ __global__ __launch_bounds__(256) void k_step_finish(SnnlsDev P) {
             S.nnz = nnz0;
             S.npos = npos0;
             S.err_cur = err0;
+            S.xw_sq = xwsq0;
           }
           fail = 1;
         } else if (threadIdx.x == 0) {
@@ -399,9 +426,9 @@ __global__ __launch_bounds__(256) void k_step_finish(SnnlsDev P) {
 }
 
 template <int ALG>
-__global__ __launch_bounds__(256) void k_pick(SnnlsDev P) {
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_pick(SnnlsDev P) {
   __shared__ SnnlsState S;
-  __shared__ double red[32];
+  __shared__ double red[64];
   if (threadIdx.x == 0) S = *P.st;
   __syncthreads();
   if (!S.select_fail) dev_pick<ALG>(P, S, red);
@@ -413,9 +440,9 @@ __global__ __launch_bounds__(256) void k_pick(SnnlsDev P) {
 
 // step-wise _reweight(f): no guard here, the host loop owns it (snnls.py:53-61)
 template <int ALG>
-__global__ __launch_bounds__(256) void k_reweight(SnnlsDev P, long long f) {
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_reweight(SnnlsDev P, long long f) {
   __shared__ SnnlsState S;
-  __shared__ double red[32];
+  __shared__ double red[64];
   __shared__ int found;
   const int s = P.s;
   if (threadIdx.x == 0) {
@@ -460,34 +487,38 @@ __global__ __launch_bounds__(256) void k_reweight(SnnlsDev P, long long f) {
 
 // rebuild the sparse list from (idx, val[, cols]); columns not supplied are looked up in the
 // old list, then in the last candidate records, then in the local shard.
-__global__ __launch_bounds__(256) void k_set_weights(SnnlsDev P, long long n, const long long* __restrict__ nidx,
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_set_weights(SnnlsDev P, long long n, const long long* __restrict__ nidx,
                                                     const double* __restrict__ nval, const double* __restrict__ ncols,
                                                     long long* idx2, double* val2, double* cols2, double* colnorm2) {
   __shared__ SnnlsState S;
-  __shared__ double red[32];
-  __shared__ int kind;
+  __shared__ double red[64];
+  __shared__ int kind, hit;
   __shared__ long long where;
   const int s = P.s;
   if (threadIdx.x == 0) { S = *P.st; S.last_status = BC_OK; }
   __syncthreads();
   for (long long j = 0; j < n; ++j) {
     const long long f = nidx[j];
-    if (threadIdx.x == 0) {
-      int kd = 0;
-      long long w = -1;
-      if (ncols) { kd = 1; }
-      if (!kd)
-        for (long long q = 0; q < S.nnz; ++q)
-          if (P.idx[q] == f) { kd = 2; w = q; break; }
-      if (!kd)
-        for (int r = 0; r < P.world; ++r) {
-          const double* rec = P.cand_all + (size_t)r * P.rec_len;
-          if (rec[3] != 0.0 && reinterpret_cast<const long long*>(rec)[1] == f) { kd = 3; w = r; break; }
-        }
-      if (!kd && f >= P.row_offset && f < P.row_offset + P.n_rows) { kd = 4; w = f - P.row_offset; }
-      if (!kd) S.last_status = BC_INVALID_ARGUMENT;
-      kind = kd;
-      where = w;
+    if (threadIdx.x == 0) { kind = ncols ? 1 : 0; where = -1; hit = INT_MAX; }
+    __syncthreads();
+    if (!ncols) {
+      for (long long q = threadIdx.x; q < S.nnz; q += blockDim.x)
+        if (P.idx[q] == f) atomicMin(&hit, (int)q);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int kd = 0;
+        long long w = -1;
+        if (hit != INT_MAX) { kd = 2; w = hit; }
+        if (!kd)
+          for (int r = 0; r < P.world; ++r) {
+            const double* rec = P.cand_all + (size_t)r * P.rec_len;
+            if (rec[3] != 0.0 && reinterpret_cast<const long long*>(rec)[1] == f) { kd = 3; w = r; break; }
+          }
+        if (!kd && f >= P.row_offset && f < P.row_offset + P.n_rows) { kd = 4; w = f - P.row_offset; }
+        if (!kd) S.last_status = BC_INVALID_ARGUMENT;
+        kind = kd;
+        where = w;
+      }
     }
     __syncthreads();
     const int kd = kind;
@@ -522,8 +553,8 @@ __global__ __launch_bounds__(256) void k_set_weights(SnnlsDev P, long long n, co
   if (threadIdx.x == 0) *P.st = S;
 }
 
-__global__ void k_reset(SnnlsDev P) {
-  __shared__ double red[32];
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_reset(SnnlsDev P) {
+  __shared__ double red[64];
   __shared__ SnnlsState S;
   if (threadIdx.x == 0) {
     memset(&S, 0, sizeof(S));
@@ -626,7 +657,7 @@ extern "C" int bc_snnls_destroy(bc_snnls* h) {
 
 #define LAUNCH1(kern, ...)                                                         \
   do {                                                                             \
-    hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, h->ctx->stream, __VA_ARGS__);   \
+    hipLaunchKernelGGL(kern, dim3(1), dim3(BC_FIN_THREADS), 0, h->ctx->stream, __VA_ARGS__);   \
     BC_HIP(hipGetLastError());                                                     \
   } while (0)
 
@@ -697,7 +728,7 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   if (e == hipSuccess) e = hipMemcpyAsync(d.bn, tmp.data() + s, s * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(h->cand_send, 0, d.rec_len * sizeof(double), ctx->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(256), 0, ctx->stream, d);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(BC_FIN_THREADS), 0, ctx->stream, d);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -914,7 +945,7 @@ extern "C" int bc_snnls_set_weights(bc_snnls* h, int64_t n, const int64_t* idx, 
     if (e == hipSuccess && cols) e = hipMemcpyAsync(dcols, cols, (size_t)n * s * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   }
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_set_weights, dim3(1), dim3(256), 0, ctx->stream, h->d, (long long)n, didx, dval, dcols, h->idx2,
+    hipLaunchKernelGGL(k_set_weights, dim3(1), dim3(BC_FIN_THREADS), 0, ctx->stream, h->d, (long long)n, didx, dval, dcols, h->idx2,
                        h->val2, h->cols2, h->colnorm2);
     e = hipGetLastError();
   }
@@ -939,7 +970,7 @@ extern "C" int bc_snnls_set_weights(bc_snnls* h, int64_t n, const int64_t* idx, 
 
 extern "C" int bc_snnls_reset(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(k_reset, dim3(1), dim3(256), 0, h->ctx->stream, h->d);
+  hipLaunchKernelGGL(k_reset, dim3(1), dim3(BC_FIN_THREADS), 0, h->ctx->stream, h->d);
   BC_HIP(hipGetLastError());
   BC_HIP(hipStreamSynchronize(h->ctx->stream));
   h->nnz_upper = 0;
