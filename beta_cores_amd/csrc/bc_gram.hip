@@ -19,9 +19,10 @@ struct GramArgs {
   const double* z;        // [n_rows][dz]
   const double* w;        // [n_rows] or null (all ones)
   double* partial;        // [splits][ntri][BT][BT]
+  double* partial_y;      // [splits][nt*BT]   X^T (w*y), accumulated by the diagonal-tile blocks
   long long n_rows;
   long long rows_per_split;   // multiple of KR
-  int dz, nt;             // nt = number of BT-wide column tiles
+  int dz, d, nt;          // d = number of x columns (y is column d), nt = number of BT-wide column tiles over d
   int ntri;               // nt*(nt+1)/2
 };
 
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   constexpr int LP = (KR * BT) / 256;    // 8-byte loads per thread per panel per slab
   __shared__ double Al[KR * LDX];
   __shared__ double Bl[KR * LDX];
+  __shared__ double Yl[256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int wa = wv >> 1, wb = wv & 1;   // wave position inside the block tile
@@ -56,8 +58,10 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // staging map: thread -> (row lr = idx / BT, col lc = idx % BT) of the slab, LP passes
   const int lc = tid % BT, lr0 = tid / BT;
   constexpr int RPP = 256 / BT;          // rows covered per pass
-  const bool a_ok = a0 + lc < a.dz, b_ok = b0 + lc < a.dz;
+  const bool a_ok = a0 + lc < a.d, b_ok = b0 + lc < a.d;
   const int ca = a_ok ? a0 + lc : 0, cb = b_ok ? b0 + lc : 0;
+  const bool diag = ta == tb;            // the diagonal block of a column panel also owns its X^T (w*y) slice
+  double vy = 0.0;
   double ra[LP], rb[LP];
   auto load_slab = [&](long long r0) {
     const long long left = r_end - r0;
@@ -72,6 +76,10 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       const double vb = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + cb) * 8, 0, 0));
       ra[q] = a_ok ? wr * va : 0.0;      // A panel carries the weights: (w[:,None]*X)
       rb[q] = b_ok ? vb : 0.0;
+      if (diag) {                        // (w[:,None]*Y[:,None]*X).sum(axis=0), model_linreg.py:31
+        const double yv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + a.d) * 8, 0, 0));
+        vy = fma(ra[q], yv, vy);
+      }
     }
   };
   auto store_slab = [&]() {
@@ -102,6 +110,16 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     }
     __syncthreads();
   }
+  if (diag) {                            // combine the RPP thread-rows of each column in fixed order
+    Yl[tid] = vy;
+    __syncthreads();
+    if (tid < BT) {
+      double t = Yl[tid];
+#pragma unroll
+      for (int q = 1; q < RPP; ++q) t += Yl[q * BT + tid];
+      a.partial_y[(size_t)split * a.nt * BT + ta * BT + tid] = t;
+    }
+  }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
   double* out = a.partial + ((size_t)split * a.ntri + tri) * BT * BT;
 #pragma unroll
@@ -118,9 +136,17 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
 
 // sum the per-split partial tiles in split order and scatter them (and their mirror images)
 // into the dense dz x dz matrix
-__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ partial, long long splits, int ntri,
-                                                    int nt, int bt, int dz, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ partial,
+                                                    const double* __restrict__ partial_y, long long splits, int ntri,
+                                                    int nt, int bt, int dz, double* __restrict__ out,
+                                                    double* __restrict__ out_y) {
   const int tri = blockIdx.x;
+  if (tri == 0)
+    for (int c = threadIdx.x; c < dz; c += blockDim.x) {
+      double acc = 0.0;
+      for (long long sp = 0; sp < splits; ++sp) acc += partial_y[(size_t)sp * nt * bt + c];
+      out_y[c] = acc;
+    }
   int ta = 0, rem = tri;
   while (rem >= nt - ta) { rem -= nt - ta; ++ta; }
   const int tb = ta + rem;
@@ -138,9 +164,9 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
 }
 
 template <int BT>
-static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, double* out_dev) {
-  const int dz = data->dz;
-  const int nt = (dz + BT - 1) / BT;
+static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, double* out_dev, double* outy_dev) {
+  const int dz = data->dz, d = dz - 1;
+  const int nt = (d + BT - 1) / BT;
   const int ntri = nt * (nt + 1) / 2;
   const int KR = 16;
   // enough blocks for ~8 per CU, at least 2 slabs per split
@@ -154,29 +180,35 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   splits = (data->n_rows + rps - 1) / rps;
   if (splits < 1) splits = 1;
   double* partial = nullptr;
+  double* partial_y = nullptr;
   BC_HIP(hipMalloc((void**)&partial, (size_t)splits * ntri * BT * BT * sizeof(double)));
+  hipError_t e = hipMalloc((void**)&partial_y, (size_t)splits * nt * BT * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(partial); return bc_hip_fail(e, "hipMalloc(gram)", __FILE__, __LINE__); }
   GramArgs a;
   a.z = data->z;
   a.w = w_dev;
   a.partial = partial;
+  a.partial_y = partial_y;
   a.n_rows = data->n_rows;
   a.rows_per_split = rps;
   a.dz = dz;
+  a.d = d;
   a.nt = nt;
   a.ntri = ntri;
   int rc = bc_timer_begin(ctx, 2);
-  hipError_t e = hipSuccess;
   if (!rc) {
     hipLaunchKernelGGL(k_gram<BT>, dim3((unsigned)(splits * ntri)), dim3(256), 0, ctx->stream, a);
     e = hipGetLastError();
   }
   if (!rc && e == hipSuccess) rc = bc_timer_end(ctx, 2);
   if (!rc && e == hipSuccess) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3(ntri), dim3(256), 0, ctx->stream, partial, splits, ntri, nt, BT, dz, out_dev);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(ntri), dim3(256), 0, ctx->stream, partial, partial_y, splits, ntri, nt, BT, d,
+                       out_dev, outy_dev);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(partial);
+  (void)hipFree(partial_y);
   if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
   return rc;
 }
@@ -187,26 +219,27 @@ extern "C" int bc_weighted_gram(bc_ctx* ctx, const bc_data* data, const double* 
   const int dz = data->dz, d = dz - 1;
   if (d <= 0) { bc_set_error("bc_weighted_gram: rows must be [x (D >= 1), y]"); return BC_INVALID_ARGUMENT; }
   BC_HIP(hipSetDevice(ctx->device));
-  std::vector<double> full((size_t)dz * dz, 0.0);
-  if (data->n_rows > 0) {
-    double* w_dev = nullptr;
-    double* out_dev = nullptr;
-    hipError_t e = hipMalloc((void**)&out_dev, (size_t)dz * dz * sizeof(double));
-    if (e == hipSuccess && w) {
-      e = hipMalloc((void**)&w_dev, (size_t)data->n_rows * sizeof(double));
-      if (e == hipSuccess) e = hipMemcpyAsync(w_dev, w, (size_t)data->n_rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    }
-    int rc = BC_OK;
-    if (e == hipSuccess) rc = dz > 96 ? run_gram<128>(ctx, data, w_dev, out_dev) : run_gram<64>(ctx, data, w_dev, out_dev);
-    if (e == hipSuccess && !rc) e = hipMemcpy(full.data(), out_dev, (size_t)dz * dz * sizeof(double), hipMemcpyDeviceToHost);
-    if (w_dev) (void)hipFree(w_dev);
-    if (out_dev) (void)hipFree(out_dev);
-    if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
-    if (rc) return rc;
+  if (data->n_rows == 0) {
+    memset(out_xtwx, 0, (size_t)d * d * sizeof(double));
+    memset(out_xtwy, 0, (size_t)d * sizeof(double));
+    return BC_OK;
   }
-  for (int r = 0; r < d; ++r) {
-    for (int c = 0; c < d; ++c) out_xtwx[(size_t)r * d + c] = full[(size_t)r * dz + c];
-    out_xtwy[r] = full[(size_t)r * dz + d];
+  double* w_dev = nullptr;
+  double* out_dev = nullptr;
+  double* outy_dev = nullptr;
+  hipError_t e = hipMalloc((void**)&out_dev, (size_t)d * d * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&outy_dev, (size_t)d * sizeof(double));
+  if (e == hipSuccess && w) {
+    e = hipMalloc((void**)&w_dev, (size_t)data->n_rows * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(w_dev, w, (size_t)data->n_rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   }
-  return BC_OK;
+  int rc = BC_OK;
+  if (e == hipSuccess) rc = d > 64 ? run_gram<128>(ctx, data, w_dev, out_dev, outy_dev) : run_gram<64>(ctx, data, w_dev, out_dev, outy_dev);
+  if (e == hipSuccess && !rc) e = hipMemcpy(out_xtwx, out_dev, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && !rc) e = hipMemcpy(out_xtwy, outy_dev, (size_t)d * sizeof(double), hipMemcpyDeviceToHost);
+  if (w_dev) (void)hipFree(w_dev);
+  if (out_dev) (void)hipFree(out_dev);
+  if (outy_dev) (void)hipFree(outy_dev);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
+  return rc;
 }
