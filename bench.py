@@ -89,7 +89,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     comm = None
-    if world > 1:
+    force_xchg = os.environ.get('BC_FORCE_EXCHANGE') == '1' and 'RANK' in os.environ   # 1-GPU rehearsal of the RCCL path
+    if world > 1 or force_xchg:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
     import beta_cores_amd as bc
@@ -97,7 +98,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = bc.Context(device=local_rank, stream=stream.cuda_stream)
     bc.set_default_context(ctx)
-    if world > 1:
+    if world > 1 or force_xchg:
         comm = bc.ShardComm()
 
     N, D, S = args.n, args.d, args.s
@@ -255,7 +256,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if world > 1 or force_xchg:
         dist.barrier()
         dist.destroy_process_group()
 

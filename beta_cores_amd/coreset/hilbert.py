@@ -1,3 +1,5 @@
+import os
+
 import numpy as np
 
 from ..device import DeviceData, DevicePhi
@@ -26,7 +28,7 @@ class HilbertCoreset(Coreset):
 
     def __init__(self, data, ll_projector, n_subsample=None, snnls=GIGA, comm=None, **kw):
         self.comm = comm
-        sharded = comm is not None and comm.world > 1
+        sharded = comm is not None and (comm.world > 1 or os.environ.get('BC_FORCE_EXCHANGE') == '1')
         if n_subsample is None:
             sub_idcs = None
             src = data
@@ -89,7 +91,7 @@ class HilbertCoreset(Coreset):
             idx = idx - self._zero_map[idx]                      # index into the zero-row-filtered matrix (hilbert.py:16,32)
         self.wts = val
         self.idcs = self.sub_idcs[idx] if self.sub_idcs is not None else idx
-        if self.comm is not None and self.comm.world > 1:
+        if self.comm is not None and hasattr(self.snnls, 'row_offset') and getattr(self.snnls, 'comm', None) is not None:
             off = self.snnls.row_offset
             n_loc = self.snnls.n_local
             local = (self.idcs >= off) & (self.idcs < off + n_loc)

@@ -5,6 +5,7 @@ sparse weight state).  `comm` (beta_cores_amd.dist.ShardComm) carries the per-st
 candidate all-gather when the rows are sharded over several ranks/GPUs.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -51,7 +52,9 @@ class HipEngine:
         self._fin = weakref.finalize(self, N.load().bc_snnls_destroy, h)
         N.call('bc_snnls_set_tolerance', h, float(tol))
         self.world = 1 if comm is None else comm.world
-        if self.world > 1:
+        # BC_FORCE_EXCHANGE=1 routes a 1-rank group through the collective too (rehearsal of the RCCL path on one GPU)
+        self.exchange = self.world > 1 or (comm is not None and os.environ.get('BC_FORCE_EXCHANGE') == '1')
+        if self.exchange:
             n = C.c_int32()
             N.call('bc_snnls_record_doubles', h, C.byref(n))
             self._xchg = comm.make_exchange(n.value, self.ctx)
@@ -60,7 +63,7 @@ class HipEngine:
     # ---- fused loop (snnls.py:31-79 on the device)
     def build_fused(self, itrs):
         lim = C.c_int()
-        if self.world == 1:
+        if not self.exchange:
             N.call('bc_snnls_build', self.h, int(itrs), C.byref(lim))
         else:
             N.call('bc_snnls_build_begin', self.h, int(itrs))
@@ -74,7 +77,7 @@ class HipEngine:
     # ---- step-wise protocol
     def select(self):
         f = C.c_int64()
-        if self.world == 1:
+        if not self.exchange:
             N.call('bc_snnls_select', self.h, C.byref(f))
         else:
             N.call('bc_snnls_select_local', self.h)

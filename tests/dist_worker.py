@@ -29,7 +29,12 @@ def main():
     mode, out = sys.argv[1], sys.argv[2]
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if mode == 'gpu_nccl1':
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     import beta_cores_amd as bc
     comm = bc.ShardComm()
     res = {}
@@ -57,6 +62,26 @@ def main():
         idx, val = s.sparse_weights()
         res['idx'], res['val'], res['err'] = idx, val, np.array(s.error())
         res['w_dense'] = s.weights()
+    elif mode == 'gpu_nccl1':
+        # one rank, RCCL backend, exchange forced on: the exact code path of `bench.py --gpus N`
+        import torch
+        os.environ['BC_FORCE_EXCHANGE'] = '1'
+        Z, th = linreg_problem()
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        ctx = bc.Context(device=0, stream=stream.cuda_stream)
+        bc.set_default_context(ctx)
+        prj = bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0), ctx=ctx)
+        data = bc.DeviceData.from_torch(torch.from_numpy(Z).cuda(), ctx=ctx, row_offset=0)
+        h = bc.HilbertCoreset(data, prj, comm=comm)
+        assert h.snnls._eng.exchange and h.snnls._eng._xchg.on_device
+        h.build(25, 25)
+        wts, pts, idcs = h.get()
+        res['idx'], res['val'], res['err'] = idcs, wts, np.array(h.error())
+        res['pts'] = pts
+        res['trace_f'] = h.snnls._eng.trace()[0]
+        f = h.snnls._select()                       # step-wise path through the collective as well
+        res['next_f'] = np.array(f)
     elif mode in ('gpu_hilbert', 'gpu_fw', 'gpu_bcores'):
         Z, th = linreg_problem()
         bounds = bc.shard_bounds(Z.shape[0], world)

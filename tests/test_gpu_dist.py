@@ -60,3 +60,18 @@ def test_two_ranks_one_gpu_beta_coreset(tmp_path):
         np.testing.assert_array_equal(r['idx'], ref.idcs)
         np.testing.assert_allclose(r['val'], ref.wts, rtol=1e-5, atol=1e-12)
         assert np.array_equal(r['pts'], ref.pts)                        # selected rows are broadcast exactly
+
+
+def test_rccl_exchange_path_single_rank(tmp_path):
+    """`bench.py --gpus N` drives the fused loop through torch.distributed/RCCL on the kernels' stream;
+    rehearse exactly that code path with a 1-rank NCCL group (all this box has is one GPU)."""
+    import beta_cores_amd as bc
+    Z, th = linreg_problem()
+    single = bc.HilbertCoreset(Z, bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0)))
+    single.build(25, 25)
+    (r0,) = launch('gpu_nccl1', tmp_path, world=1)
+    np.testing.assert_array_equal(r0['idx'], single.idcs)
+    assert np.array_equal(r0['val'], single.wts)                       # same kernels, same order: bit identical
+    np.testing.assert_array_equal(r0['trace_f'], single.snnls._eng.trace()[0])
+    assert np.array_equal(r0['pts'], Z[single.idcs])
+    assert int(r0['next_f']) == single.snnls._select()
