@@ -35,9 +35,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--n', type=int, default=10_000_000)
-    ap.add_argument('--d', type=int, default=128)
-    ap.add_argument('--s', type=int, default=100)
+    ap.add_argument('--rows', dest='n', type=int, default=10_000_000)
+    ap.add_argument('--dim', dest='d', type=int, default=128)
+    ap.add_argument('--samples', dest='s', type=int, default=100)
     ap.add_argument('--alg', default='giga', choices=['giga', 'fw'])
     ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='rows of the same data given to the CPU baseline')
     ap.add_argument('--cpu-iters', type=int, default=20)

@@ -108,8 +108,17 @@ class DeviceData:
 
     @classmethod
     def from_torch(cls, t, ctx=None, row_offset=0):
-        """Borrow a contiguous float64 CUDA tensor (kept alive by this object)."""
+        """Borrow a contiguous float64 CUDA tensor (kept alive by this object).
+
+        The tensor's producer kernels run on torch's current stream; unless this library launches on
+        that same stream (Context(stream=...)), wait for them here -- otherwise our first kernel could
+        read rows torch has not finished writing."""
         assert t.is_cuda and t.is_contiguous() and str(t.dtype) == 'torch.float64' and t.dim() == 2
+        import torch
+        cur = torch.cuda.current_stream(t.device)
+        c = ctx or default_context()
+        if c.stream_handle is None or c.stream_handle != cur.cuda_stream:
+            cur.synchronize()
         return cls(ctx=ctx, device_ptr=t.data_ptr(), shape=tuple(t.shape), keepalive=t, row_offset=row_offset)
 
 

@@ -1,0 +1,126 @@
+"""BASELINE.json configurations at FULL size on one MI355X, checked through size-independent
+properties (the oracle cannot run these sizes in seconds):
+  configs[1] linreg   N=1M D=64     configs[2] logistic N=1M D=128     configs[4] neural-linear N=2M D=512
+Properties (the reference's own invariant list, tests/test_snnls/test_deterministic.py:37-111, plus
+consistency of the device reductions): nnz <= m, size() == nnz, w >= 0, error monotone, error() equals
+||sum_i w_i Phi_i - sum_i Phi_i|| recomputed from gathered rows, b == Phi^T 1 via an independent device
+matvec, K4 == torch fp64 GEMM, determinism (two builds give identical bits), and a 200k-row prefix of
+the same data reproduces the oracle's selections exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import models_ref as M
+from oracle import coreset_ref as C
+from oracle import RefGIGA
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import beta_cores_amd as bc
+    ctx = bc.default_context()
+    return bc, torch, ctx
+
+
+def gen(torch, n, d, seed, kind):
+    g = torch.Generator(device='cuda')
+    g.manual_seed(seed)
+    if kind == 'relu':                                   # config 5: random ReLU features of a 32-d input
+        U = torch.randn((n, 32), generator=g, dtype=torch.float64, device='cuda')
+        G = torch.randn((32, d), generator=g, dtype=torch.float64, device='cuda') / np.sqrt(32.)
+        X = torch.relu(U @ G)
+    else:
+        X = torch.randn((n, d), generator=g, dtype=torch.float64, device='cuda')
+    thstar = torch.randn((d,), generator=g, dtype=torch.float64, device='cuda') / np.sqrt(d)
+    if kind == 'logistic':
+        p = torch.sigmoid(X @ (torch.ones(d, dtype=torch.float64, device='cuda') / np.sqrt(d)))
+        y = torch.where(torch.rand((n,), generator=g, dtype=torch.float64, device='cuda') <= p, 1., -1.)
+        return (y[:, None] * X).contiguous(), thstar
+    y = X @ thstar + torch.randn((n,), generator=g, dtype=torch.float64, device='cuda')
+    return torch.cat((X, y[:, None]), dim=1).contiguous(), thstar
+
+
+def check_invariants(bc, phi, solver, steps):
+    S = phi.shape[1]
+    b = solver.b
+    prev = np.inf
+    for m in range(1, steps + 1):
+        solver.build(1)
+        idx, val = solver.sparse_weights()
+        assert len(idx) <= m and len(idx) == solver.size() and np.all(val > 0)
+        rows = phi.rows(idx - phi.row_offset)
+        err = np.sqrt(((val.dot(rows) - b) ** 2).sum())
+        assert err <= prev * (1 + 1e-12) + 1e-9
+        assert abs(solver.error() - err) <= 1e-9 * max(1., err)
+        prev = err
+    return idx, val
+
+
+@pytest.mark.parametrize('cfg', ['linreg_1M_64', 'logistic_1M_128', 'neurlin_2M_512'])
+def test_fullsize_properties(env, cfg):
+    bc, torch, ctx = env
+    n, d, kind = {'linreg_1M_64': (1_000_000, 64, 'linreg'), 'logistic_1M_128': (1_000_000, 128, 'logistic'),
+                  'neurlin_2M_512': (2_000_000, 512, 'relu')}[cfg]
+    S = 100
+    Z, thstar = gen(torch, n, d, {'linreg': 20, 'logistic': 30, 'relu': 50}[kind], kind)
+    data = bc.DeviceData.from_torch(Z, ctx=ctx)
+    rng = np.random.default_rng(7)
+    if kind == 'logistic':
+        model = bc.likelihoods.LogisticRegression()
+        theta = thstar.cpu().numpy() + 0.1 * rng.standard_normal((S, d))
+        oracle_ll = M.logistic_loglik
+    else:
+        model = bc.likelihoods.LinearRegression(1.0)
+        # K4 at full size: X^T X, X^T y against torch's fp64 GEMM
+        G, v = bc.weighted_gram(data)
+        Gt = (Z[:, :d].T @ Z[:, :d]).cpu().numpy()
+        vt = (Z[:, :d].T @ Z[:, d]).cpu().numpy()
+        assert np.abs(G - Gt).max() <= 1e-11 * np.abs(Gt).max()
+        assert np.abs(v - vt).max() <= 1e-10 * np.abs(vt).max()
+        mu, L, _ = bc.weighted_post(np.zeros(d), np.eye(d), 1.0, data, None)
+        theta = mu + rng.standard_normal((S, d)).dot(L.T)
+        oracle_ll = lambda z, t: M.linreg_loglik(z, t, 1.0)
+    prj = bc.DeviceBetaProjector(lambda k, w, p: theta, S, model, ctx=ctx)
+    phi = prj.project(data)
+    assert phi.shape == (n, S)
+    # K2: b = Phi^T 1 two independent ways (fused column partials vs per-row matvecs summed on the host)
+    b = phi.colsum()
+    nrm = phi.norms()
+    assert np.all(np.isfinite(b)) and np.all(nrm >= 0) and phi.norm_stats()[0] == 0
+    e = np.zeros(S); e[3] = 1.
+    col3 = phi.matvec(e)
+    assert abs(col3.sum() - b[3]) <= 1e-9 * max(1., np.abs(col3).sum())
+    # rows are centred: Phi . 1 == 0 up to rounding
+    assert np.abs(phi.matvec(np.ones(S))).max() <= 1e-9 * (1. + np.abs(col3).max())
+    # K1 vs the oracle formula on a scattered sample of rows
+    pick = rng.choice(n, 300, replace=False)
+    Zs = data.rows(pick)
+    ref_rows = C.project(oracle_ll, Zs, theta)
+    got_rows = phi.rows(pick)
+    assert np.abs(got_rows - ref_rows).max() <= 1e-10 * (1. + np.abs(ref_rows).max())
+    # greedy loop invariants at full size, GIGA and FrankWolfe
+    idx1, val1 = check_invariants(bc, phi, bc.snnls.GIGA(phi.T, b), 25)
+    check_invariants(bc, phi, bc.snnls.FrankWolfe(phi.T, b), 10)
+    # determinism: a second solver over the same Phi gives identical bits
+    s2 = bc.snnls.GIGA(phi.T, b)
+    s2.build(25)
+    idx2, val2 = s2.sparse_weights()
+    assert np.array_equal(idx1, idx2) and np.array_equal(val1, val2)
+    # beta-projection at full size stays finite and centred
+    phib = prj.project_f(data, 0.1)
+    assert np.all(np.isfinite(phib.colsum())) and np.abs(phib.matvec(np.ones(S))).max() <= 1e-9
+    # a 200k-row prefix through device and oracle: identical selections
+    ns = 200_000
+    Zp = Z[:ns].cpu().numpy()
+    ref = RefGIGA(*(lambda P: (P.T, P.sum(axis=0)))(C.project(oracle_ll, Zp, theta)))
+    ref.build(15)
+    h = bc.HilbertCoreset(Zp, bc.DeviceProjector(lambda k, w, p: theta, S, model, ctx=ctx))
+    h.build(15, 15)
+    np.testing.assert_array_equal(h.snnls._eng.trace()[0], [t[0] for t in ref.trace])
+    ridx = np.where(ref.w > 0)[0]
+    np.testing.assert_array_equal(h.idcs, ridx)
+    np.testing.assert_allclose(h.wts, ref.w[ridx], rtol=1e-5)
+    del phi, phib, data, Z
+    torch.cuda.empty_cache()
