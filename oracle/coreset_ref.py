@@ -97,19 +97,23 @@ class RefHilbert:
 
 
 class RefGreedyVI:
-    """bcores.py:27-150 / sparsevi.py:27-136, ungrouped, full-data
-    (n_subsample=None) so that no RNG enters besides the caller's sampler.
+    """bcores.py:27-150 / sparsevi.py:27-136, full-data (n_subsample=None) so that no RNG
+    enters besides the caller's sampler; ungrouped (bcores.py:75-90) or grouped
+    (bcores.py:46-50, 91-123: per-group sums of the projection rows are scored, a whole group
+    of rows joins the coreset at once).
 
     ``proj(pts, samples)`` is the row-centred projection (beta already bound);
     ``sampler(wts, pts)`` returns the S x D sample matrix for the current
     coreset (called once per projection, as ll_projector.update is)."""
 
-    def __init__(self, data, proj, sampler, opt_itrs, step_sched):
+    def __init__(self, data, proj, sampler, opt_itrs, step_sched, groups=None):
         self.data = data
         self.proj = proj
         self.sampler = sampler
         self.opt_itrs = opt_itrs
         self.step_sched = step_sched
+        self.groups = groups
+        self.selected_groups = []
         self.wts = np.zeros(0)
         self.idcs = np.zeros(0, dtype=np.int64)
         self.pts = np.zeros((0, data.shape[1]))
@@ -117,23 +121,34 @@ class RefGreedyVI:
 
     def _tangent(self, w):
         th = self.sampler(w, self.pts)                               # bcores.py:39
-        vecs = self.proj(self.data, th)                              # bcores.py:44
+        if self.groups is None:
+            vecs = self.proj(self.data, th)                          # bcores.py:44
+        else:                                                        # bcores.py:46-50
+            vecs = np.array([np.sum(self.proj(self.data[g, :], th), axis=0) for g in self.groups])
         core = self.proj(self.pts, th) if self.pts.size > 0 else np.zeros((0, vecs.shape[1]))
         return vecs, core
 
-    def select(self):                                                # bcores.py:74-90
+    def select(self):                                                # bcores.py:74-124
         vecs, core = self._tangent(self.wts)
-        vecs = vecs[~np.all(vecs == 0., axis=1)]
+        if self.groups is None:
+            vecs = vecs[~np.all(vecs == 0., axis=1)]
         resid = 1. * vecs.sum(axis=0) - self.wts.dot(core)
         corrs = vecs.dot(resid) / np.sqrt((vecs ** 2).sum(axis=1)) / vecs.shape[1]
         ccorrs = np.fabs(core.dot(resid) / np.sqrt((core ** 2).sum(axis=1))) / core.shape[1]
         f = -1
         if ccorrs.size == 0 or corrs.max() > ccorrs.max():
             f = int(np.argmax(corrs))
-            if f not in self.idcs:
-                self.wts = np.append(self.wts, 0.)
-                self.idcs = np.append(self.idcs, f)
-                self.pts = np.vstack((self.pts, self.data[f][None, :]))
+            if self.groups is None:
+                if f not in self.idcs:
+                    self.wts = np.append(self.wts, 0.)
+                    self.idcs = np.append(self.idcs, f)
+                    self.pts = np.vstack((self.pts, self.data[f][None, :]))
+            elif f not in self.selected_groups:
+                self.selected_groups.append(f)
+                g = self.groups[f]
+                self.wts = np.concatenate((self.wts, np.zeros(len(g))))
+                self.idcs = np.concatenate((self.idcs, np.asarray(g, dtype=np.int64)))
+                self.pts = np.vstack((self.pts, self.data[g, :]))
         self.sel_trace.append(f)
 
     def optimize(self):                                              # bcores.py:141-150

@@ -327,6 +327,40 @@ def f5_greedy_vi():
     save('f5_greedy_vi', **out)
 
 
+def f8_grouped_vi():
+    """Grouped (batch) selection, bcores.py:46-50,91-123 / sparsevi.py:43-47,93-126, full-data mode."""
+    rng = np.random.RandomState(8)
+    N, D, S = 240, 5, 24
+    Z, _, E = linreg_problem(rng, N, D, S)
+    perm = rng.permutation(N)
+    groups = [sorted(perm[i:i + 12].tolist()) for i in range(0, N, 12)]     # 20 groups of 12 rows
+    out = dict(Z=Z, E=E, groups=np.array(groups))
+    opt_itrs, builds = 6, 4
+
+    def sampler(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts = np.zeros(1)
+            pts = np.zeros((1, Z.shape[1]))
+        mu, L, _ = R.linreg.weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+
+    fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    bl = lambda z, t, b: R.neurlinr.neurlinr_beta_likelihood(z, t, b, 1.0)
+    ll = lambda z, t: R.linreg.gaussian_loglikelihood(z, t, 1.0)
+    bco = R.bcores.BetaCoreset(Z, R.projector.BetaBlackBoxProjector(sampler, S, bl, ll, None), opt_itrs=opt_itrs,
+                               step_sched=lambda i: 0.1 / (1. + i), beta=0.1, learn_beta=False, groups=groups, **fresh())
+    svi = R.sparsevi.SparseVICoreset(Z, R.projector.BlackBoxProjector(sampler, S, ll), opt_itrs=opt_itrs,
+                                     step_sched=lambda i: 0.1 / (1. + i), groups=groups, **fresh())
+    for nm, alg in (('bcores', bco), ('svi', svi)):
+        for m in range(builds):
+            quiet(alg.build, 1, 12 * (m + 1))
+            out['%s_allw_%d' % (nm, m)] = alg.wts.copy()
+            out['%s_allidcs_%d' % (nm, m)] = alg.idcs.copy()
+            out['%s_groups_%d' % (nm, m)] = np.array([int(g) for g in alg.selected_groups])
+    out['opt_itrs'] = np.array(opt_itrs)
+    save('f8_grouped_vi', **out)
+
+
 # ---------------------------------------------------------------- F6/F7
 def f6_weighted_post():
     rng = np.random.RandomState(6)
@@ -373,3 +407,4 @@ if __name__ == '__main__':
     f5_greedy_vi()
     f6_weighted_post()
     f7_nn_opt()
+    f8_grouped_vi()

@@ -88,6 +88,35 @@ def test_beta_coreset_larger_vs_oracle(bc):
         np.testing.assert_allclose(alg.wts, ref.wts, rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+@pytest.mark.parametrize('projector', ['device', 'blackbox'])
+def test_f8_grouped_selection_goldens(bc, nm, projector):
+    """Grouped (batch) selection: per-group sums of the projection rows are scored and whole
+    groups join the coreset (bcores.py:46-50, 91-123; sparsevi.py:43-47, 93-126)."""
+    g = load_golden('f8_grouped_vi')
+    Z, E = g['Z'], g['E']
+    groups = [list(map(int, r)) for r in g['groups']]
+    S = E.shape[0]
+    opt_itrs = int(g['opt_itrs'])
+    sampler = make_sampler(Z, E)
+    model = bc.likelihoods.LinearRegression(1.0)
+    sched = lambda i: 0.1 / (1. + i)
+    if nm == 'bcores':
+        prj = bc.DeviceBetaProjector(sampler, S, model) if projector == 'device' else \
+            bc.BetaBlackBoxProjector(sampler, S, lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0),
+                                     lambda z, t: M.linreg_loglik(z, t, 1.0), None)
+        alg = bc.BetaCoreset(Z, prj, opt_itrs=opt_itrs, step_sched=sched, beta=0.1, learn_beta=False, groups=groups)
+    else:
+        prj = bc.DeviceProjector(sampler, S, model) if projector == 'device' else \
+            bc.BlackBoxProjector(sampler, S, lambda z, t: M.linreg_loglik(z, t, 1.0))
+        alg = bc.SparseVICoreset(Z, prj, opt_itrs=opt_itrs, step_sched=sched, groups=groups)
+    for m in range(4):
+        alg.build(1, 12 * (m + 1))
+        np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+        np.testing.assert_array_equal([int(x) for x in alg.selected_groups], g['%s_groups_%d' % (nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-5, atol=1e-12)
+
+
 def test_learn_beta_is_rejected_like_the_reference_would_fail(bc):
     g = load_golden('f5_greedy_vi')
     Z, E = g['Z'], g['E']

@@ -144,6 +144,31 @@ def test_f5_greedy_vi(nm):
         np.testing.assert_array_equal(i, g['%s_idcs_%d' % (nm, m)])
 
 
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+def test_f8_grouped_vi(nm):
+    g = load_golden('f8_grouped_vi')
+    Z, E = g['Z'], g['E']
+    groups = [list(r) for r in g['groups']]
+    D = Z.shape[1] - 1
+    opt_itrs = int(g['opt_itrs'])
+
+    def sampler(wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+        mu, L, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+    if nm == 'bcores':
+        proj = lambda pts, th: C.project_f(lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0), pts, th, 0.1)
+    else:
+        proj = lambda pts, th: C.project(lambda z, t: M.linreg_loglik(z, t, 1.0), pts, th)
+    alg = C.RefGreedyVI(Z, proj, sampler, opt_itrs, lambda i: 0.1 / (1. + i), groups=groups)
+    for m in range(4):
+        alg.build(1)
+        np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+        np.testing.assert_array_equal(alg.selected_groups, g['%s_groups_%d' % (nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-10, atol=1e-14)
+
+
 def test_f6_weighted_post():
     g = load_golden('f6_weighted_post')
     for D in (8, 64):
