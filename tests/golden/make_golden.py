@@ -361,6 +361,49 @@ def f8_grouped_vi():
     save('f8_grouped_vi', **out)
 
 
+def f9_subsampled_gaussian():
+    """The zellner_gaussian recipe shrunk (main.py:33-105): Gaussian location model, sub-sampled
+    selection / optimisation, samplers drawing from the GLOBAL NumPy RNG -- pins the RNG call order
+    (sampler before randint, bcores.py:39 then :53)."""
+    np.random.seed(9)
+    N, d, S = 600, 6, 40
+    Sig = 500. * np.eye(d)
+    Siginv = np.linalg.inv(Sig)
+    logdet = np.linalg.slogdet(Sig)[1]
+    X = np.random.multivariate_normal(np.zeros(d), Sig, N)
+    Xc = np.concatenate((X, np.random.multivariate_normal(np.zeros(d) + 200, 0.5 * Sig, N // 50),
+                         np.random.multivariate_normal(np.zeros(d), 10 * Sig, N // 10)))
+    mu0, Sig0inv = np.zeros(d), np.eye(d)
+
+    def sampler_w(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts = np.zeros(1)
+            pts = np.zeros((1, Xc.shape[1]))
+        muw, LSigw, _ = R.gaussian.weighted_post(mu0, Sig0inv, Siginv, pts, wts)
+        return muw + np.random.randn(sz, muw.shape[0]).dot(LSigw.T)
+
+    ll = lambda x, th: quiet(R.gaussian.gaussian_loglikelihood, x, th, Siginv, logdet)
+    bl = lambda x, th, beta: R.gaussian.gaussian_beta_likelihood(x, th, beta, Siginv, logdet)
+    fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    out = dict(X=Xc, Siginv=Siginv, logdet=np.array(logdet))
+    for nm in ('bcores', 'svi'):
+        np.random.seed(90)
+        if nm == 'bcores':
+            prj = R.projector.BetaBlackBoxProjector(sampler_w, S, bl, ll, None)
+            alg = R.bcores.BetaCoreset(Xc, prj, opt_itrs=8, n_subsample_opt=60, n_subsample_select=150,
+                                       step_sched=lambda i: 0.1 / (1. + i), beta=.1, learn_beta=False, **fresh())
+        else:
+            prj = R.projector.BlackBoxProjector(sampler_w, S, ll)
+            alg = R.sparsevi.SparseVICoreset(Xc, prj, opt_itrs=8, n_subsample_opt=60, n_subsample_select=150,
+                                             step_sched=lambda i: 0.1 / (1. + i), **fresh())
+        for m in range(6):
+            quiet(alg.build, 1, m + 1)
+            out['%s_allw_%d' % (nm, m)] = alg.wts.copy()
+            out['%s_allidcs_%d' % (nm, m)] = alg.idcs.copy()
+        out['%s_rng_after' % nm] = np.array(np.random.rand())       # the RNG stream position must match too
+    save('f9_subsampled_gaussian', **out)
+
+
 # ---------------------------------------------------------------- F6/F7
 def f6_weighted_post():
     rng = np.random.RandomState(6)
@@ -408,3 +451,4 @@ if __name__ == '__main__':
     f6_weighted_post()
     f7_nn_opt()
     f8_grouped_vi()
+    f9_subsampled_gaussian()

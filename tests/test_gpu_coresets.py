@@ -117,6 +117,36 @@ def test_f8_grouped_selection_goldens(bc, nm, projector):
         np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+def test_f9_subsampled_gaussian_rng_order(bc, nm):
+    """zellner_gaussian recipe (main.py:33-105): Gaussian-location model on the device, sub-sampled
+    select / optimise, samplers on the global NumPy RNG -- selections, weights AND the RNG position
+    after 6 builds must equal the reference's."""
+    g = load_golden('f9_subsampled_gaussian')
+    X, Siginv, logdet = g['X'], g['Siginv'], float(g['logdet'])
+    d, S = X.shape[1], 40
+    mu0, Sig0inv = np.zeros(d), np.eye(d)
+
+    def sampler_w(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, d))
+        muw, LSigw, _ = bc.gaussian_weighted_post(mu0, Sig0inv, Siginv, pts, wts)      # K4 on the device
+        return muw + np.random.randn(sz, muw.shape[0]).dot(LSigw.T)
+    model = bc.likelihoods.GaussianLocation(Siginv, logdet)
+    np.random.seed(90)
+    if nm == 'bcores':
+        alg = bc.BetaCoreset(X, bc.DeviceBetaProjector(sampler_w, S, model), opt_itrs=8, n_subsample_opt=60,
+                             n_subsample_select=150, step_sched=lambda i: 0.1 / (1. + i), beta=.1, learn_beta=False)
+    else:
+        alg = bc.SparseVICoreset(X, bc.DeviceProjector(sampler_w, S, model), opt_itrs=8, n_subsample_opt=60,
+                                 n_subsample_select=150, step_sched=lambda i: 0.1 / (1. + i))
+    for m in range(6):
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-5, atol=1e-12)
+    assert np.random.rand() == float(g['%s_rng_after' % nm])
+
+
 def test_learn_beta_is_rejected_like_the_reference_would_fail(bc):
     g = load_golden('f5_greedy_vi')
     Z, E = g['Z'], g['E']
