@@ -24,7 +24,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct ProjArgs {
   const double* z;        // [n_rows][dz]
-  const double* theta;    // [nt*16][dk]  zero padded
+  const double* theta;    // [nt*16][dk]  zero padded            (MFMA kernel)
+  const double* theta_v;  // [dk][4][SW]  zero padded            (vector-FMA kernel: d-major, one sample quarter per wave)
   const double* saux;     // [nt*16] per-sample extra (gauss: theta^T Siginv theta)
   const double* rowaux;   // [n_rows] per-row extra (gauss: x^T Siginv x) or null
   double* tiles;
@@ -248,6 +249,172 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1, vector-FMA formulation (S <= 100): measured on MI355X the fp64 vector pipe sustains ~56 TF in
+// this register blocking against ~47 TF for v_mfma_f64_16x16x4_f64 (tools/valu_f64_sgpr.hip,
+// tools/mfma_f64_peak.hip; both DVFS-limited), and it needs no padding of S to a multiple of 16.
+//   block = 256 rows (two Phi tiles), 4 waves; wave w owns the sample quarter [w*SW, (w+1)*SW);
+//   lane l owns rows 2l, 2l+1 (tile A) and 128+2l, 129+2l (tile B)  ->  acc[4][SW] in VGPRs;
+//   per feature d: 2 x ds_read_b128 fetch the lane's four x values from the LDS slab [KC][258],
+//   theta[d][quarter] is wave-uniform: s_load into SGPRs, used directly as the FMA's scalar operand.
+// The Z slab is staged with buffer loads (rows past N read as 0) and prefetched one slab ahead.
+template <int MODEL, int SW>
+__global__ __launch_bounds__(256, 2) void k_project_v(ProjArgs a) {
+  constexpr int KC = 8;
+  constexpr int LDR = 258;               // slab row length (256 rows + 2): keeps the 16-byte reads aligned
+  __shared__ double Zl[KC * LDR];
+  __shared__ double rs0[4 * 256];        // cross-wave row reductions: sum / sum of squares
+  __shared__ double rs1[4 * 256];        // min
+  __shared__ double rs2[4 * 256];        // max
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long blk = blockIdx.x;
+  const long long r0 = blk * 256;
+  const int S = a.s;
+
+  double acc[4][SW];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int j = 0; j < SW; ++j) acc[rr][j] = 0.;
+
+  const int zc = tid % KC, zrw = tid / KC;       // staging: thread -> (row zrw + 32*q, column zc)
+  const long long rows_left = a.n_rows - r0;
+  const long long rows_here = rows_left < 256 ? rows_left : 256;
+  const auto zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0,
+                                                       (int)(rows_here * a.dz * 8), 0x00020000);
+  double zr[KC];
+  auto load_chunk = [&](int d0) {
+    const int col = min(d0 + zc, a.d - 1);
+    const int voff = (zrw * a.dz + col) * 8;
+#pragma unroll
+    for (int q = 0; q < KC; ++q)
+      zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * 32 * a.dz * 8, 0));
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int q = 0; q < KC; ++q) Zl[zc * LDR + zrw + 32 * q] = zr[q];
+  };
+
+  const int nchunks = a.dk / KC;
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    store_chunk();
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk((c + 1) * KC);
+    const double* __restrict__ th = a.theta_v + ((size_t)c * KC * 4 + w) * SW;   // wave-uniform
+#pragma unroll 1
+    for (int dd = 0; dd < KC; ++dd) {
+      const double2 xa = *reinterpret_cast<const double2*>(Zl + dd * LDR + 2 * lane);
+      const double2 xb = *reinterpret_cast<const double2*>(Zl + dd * LDR + 128 + 2 * lane);
+      const double* __restrict__ t = th + (size_t)dd * 4 * SW;
+#pragma unroll
+      for (int j = 0; j < SW; ++j) {
+        const double tv = t[j];
+        acc[0][j] = fma(xa.x, tv, acc[0][j]);
+        acc[1][j] = fma(xa.y, tv, acc[1][j]);
+        acc[2][j] = fma(xb.x, tv, acc[2][j]);
+        acc[3][j] = fma(xb.y, tv, acc[3][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const int lrow[4] = {2 * lane, 2 * lane + 1, 128 + 2 * lane, 129 + 2 * lane};
+  bool live[4];
+  double ra[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const long long gr = r0 + lrow[rr];
+    live[rr] = gr < a.n_rows;
+    ra[rr] = 0.;
+    if (live[rr]) {
+      if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra[rr] = a.z[(size_t)gr * a.dz + a.d];
+      else if (MODEL >= BC_MODEL_GAUSS_LL) ra[rr] = a.rowaux[gr];
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    double sum = 0., vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SW; ++j) {
+      const int sidx = w * SW + j;
+      double v = 0.;
+      if (sidx < S && live[rr]) {
+        v = bc_model_value<MODEL>(acc[rr][j], ra[rr], (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[sidx] : 0., a.c);
+        vmin = fmin(vmin, v);
+        vmax = fmax(vmax, v);
+      }
+      acc[rr][j] = v;
+      sum += v;
+    }
+    rs0[w * 256 + lrow[rr]] = sum;
+    rs1[w * 256 + lrow[rr]] = vmin;
+    rs2[w * 256 + lrow[rr]] = vmax;
+  }
+  __syncthreads();
+  double mean[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = lrow[rr];
+    const double tot = ((rs0[r] + rs0[256 + r]) + rs0[512 + r]) + rs0[768 + r];
+    const double mn = fmin(fmin(rs1[r], rs1[256 + r]), fmin(rs1[512 + r], rs1[768 + r]));
+    const double mx = fmax(fmax(rs2[r], rs2[256 + r]), fmax(rs2[512 + r], rs2[768 + r]));
+    mean[rr] = (mn == mx) ? mx : tot / (double)S;      // constant row -> exactly 0 after centring (hilbert.py:16)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    double sq = 0.;
+#pragma unroll
+    for (int j = 0; j < SW; ++j) {
+      const int sidx = w * SW + j;
+      double v = acc[rr][j];
+      v = (sidx < S && live[rr]) ? v - mean[rr] : 0.;
+      acc[rr][j] = v;
+      sq = fma(v, v, sq);
+    }
+    rs0[w * 256 + lrow[rr]] = sq;
+  }
+  __syncthreads();
+  const long long tileA = 2 * blk, tileB = 2 * blk + 1;
+  const bool hasB = tileB * BC_TILE < a.n_rows;
+  if (w == 0) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = lrow[rr];
+      if (rr < 2 || hasB) a.norms[r0 + r] = sqrt(((rs0[r] + rs0[256 + r]) + rs0[512 + r]) + rs0[768 + r]);
+    }
+  }
+  double* tA = a.tiles + (size_t)tileA * S * BC_TILE + 2 * lane;
+  double* tB = a.tiles + (size_t)tileB * S * BC_TILE + 2 * lane;
+#pragma unroll
+  for (int j = 0; j < SW; ++j) {
+    const int sidx = w * SW + j;
+    if (sidx < S) {
+      *reinterpret_cast<double2*>(tA + (size_t)sidx * BC_TILE) = make_double2(acc[0][j], acc[1][j]);
+      if (hasB) *reinterpret_cast<double2*>(tB + (size_t)sidx * BC_TILE) = make_double2(acc[2][j], acc[3][j]);
+    }
+    // column partials (K2): one per 128-row tile, summed over the wave's 64 lanes
+    double cpa = bc_wave_sum(acc[0][j] + acc[1][j]);
+    double cpb = bc_wave_sum(acc[2][j] + acc[3][j]);
+    if (lane == 0 && sidx < S) {
+      a.tile_part[(size_t)tileA * S + sidx] = cpa;
+      if (hasB) a.tile_part[(size_t)tileB * S + sidx] = cpb;
+    }
+  }
+}
+
+template <int MODEL>
+static int launch_project_v(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int sw) {
+  const unsigned grid = (unsigned)((ntiles + 1) / 2);
+  if (sw <= 16) hipLaunchKernelGGL((k_project_v<MODEL, 16>), dim3(grid), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_project_v<MODEL, 25>), dim3(grid), dim3(256), 0, ctx->stream, a);
+  BC_HIP(hipGetLastError());
+  return BC_OK;
+}
+
 // x^T Siginv x per row, in the reference's order: (x * (x.dot(Siginv))).sum(axis=1)   (gaussian.py:10)
 __global__ __launch_bounds__(256) void k_row_quadform(const double* __restrict__ z, long long n_rows, int d,
                                                      const double* __restrict__ siginv, double* __restrict__ out) {
@@ -272,6 +439,8 @@ struct ProjScratch {
   size_t theta_cap = 0;
   double* saux = nullptr;
   size_t saux_cap = 0;
+  double* theta_v = nullptr;
+  size_t theta_v_cap = 0;
   double* rowaux = nullptr;
   size_t rowaux_cap = 0;
   double* siginv = nullptr;
@@ -424,13 +593,21 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
 
   const int nt = (s + 15) / 16;
   const int NTsel = nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 16;
-  const int KC = NTsel <= 7 ? 32 : 16;
+  // The vector-FMA kernel is parity-clean but measured SLOWER than the MFMA kernel in round 1
+  // (N=4M, D=128: 3.73 ms vs 3.11 ms; its scalar theta loads are not software-pipelined yet), so it is
+  // opt-in: BC_K1_VALU=1.
+  static const int want_valu = getenv("BC_K1_VALU") ? atoi(getenv("BC_K1_VALU")) : 0;
+  const bool use_valu = s <= 100 && want_valu;            // vector-FMA kernel: sample quarters of <= 25
+  const int SWv = s <= 64 ? 16 : 25;
+  const int KC = NTsel <= 7 ? 32 : 16;                    // dk is a multiple of 8 (the VALU kernel's chunk) either way
   const int dk = ((d + KC - 1) / KC) * KC;
   ProjScratch& sc = g_scr[ctx->device & 15];
   const size_t th_n = (size_t)NTsel * 16 * dk, sa_n = (size_t)NTsel * 16;
+  const size_t thv_n = use_valu ? (size_t)dk * 4 * SWv : 0;
   int rc = grow_dev(&sc.theta, &sc.theta_cap, th_n);
   if (!rc) rc = grow_dev(&sc.saux, &sc.saux_cap, sa_n);
-  if (!rc) rc = grow_pinned(sc, th_n + sa_n + (siginv ? (size_t)d * d : 0));
+  if (!rc && use_valu) rc = grow_dev(&sc.theta_v, &sc.theta_v_cap, thv_n);
+  if (!rc) rc = grow_pinned(sc, th_n + sa_n + (siginv ? (size_t)d * d : 0) + thv_n);
   if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
   // make sure an earlier launch is no longer reading the pinned staging area
   BC_HIP(hipStreamSynchronize(ctx->stream));
@@ -459,6 +636,16 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
   }
   hipError_t e = hipMemcpyAsync(sc.theta, hth, th_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(sc.saux, hsa, sa_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && use_valu) {
+    // d-major copy for the scalar loads of the vector-FMA kernel: [dk][4 quarters][SW], zero padded
+    double* hv = sc.pinned + th_n + sa_n + (siginv ? (size_t)d * d : 0);
+    memset(hv, 0, thv_n * sizeof(double));
+    for (int q = 0; q < s; ++q) {
+      const int wq = q / SWv, jq = q % SWv;
+      for (int aa = 0; aa < d; ++aa) hv[((size_t)aa * 4 + wq) * SWv + jq] = hth[(size_t)q * dk + aa];
+    }
+    e = hipMemcpyAsync(sc.theta_v, hv, thv_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  }
   a.rowaux = nullptr;
   if (e == hipSuccess && siginv && data->n_rows > 0) {
     rc = grow_dev(&sc.rowaux, &sc.rowaux_cap, (size_t)data->n_rows);
@@ -485,6 +672,7 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
 
   a.z = data->z;
   a.theta = sc.theta;
+  a.theta_v = sc.theta_v;
   a.saux = sc.saux;
   a.tiles = phi->tiles;
   a.norms = phi->norms;
@@ -498,7 +686,17 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
   rc = BC_OK;
   if (phi->ntiles > 0) {
     rc = bc_timer_begin(ctx, 1);
-    if (!rc) {
+    if (!rc && use_valu) {
+      switch (model) {
+        case BC_MODEL_LINREG_LL: rc = launch_project_v<BC_MODEL_LINREG_LL>(ctx, a, phi->ntiles, SWv); break;
+        case BC_MODEL_LINREG_BETA: rc = launch_project_v<BC_MODEL_LINREG_BETA>(ctx, a, phi->ntiles, SWv); break;
+        case BC_MODEL_LOGISTIC_LL: rc = launch_project_v<BC_MODEL_LOGISTIC_LL>(ctx, a, phi->ntiles, SWv); break;
+        case BC_MODEL_LOGISTIC_BETA: rc = launch_project_v<BC_MODEL_LOGISTIC_BETA>(ctx, a, phi->ntiles, SWv); break;
+        case BC_MODEL_GAUSS_LL: rc = launch_project_v<BC_MODEL_GAUSS_LL>(ctx, a, phi->ntiles, SWv); break;
+        case BC_MODEL_GAUSS_BETA: rc = launch_project_v<BC_MODEL_GAUSS_BETA>(ctx, a, phi->ntiles, SWv); break;
+        default: rc = launch_project_v<BC_MODEL_GAUSS_BETA_GRAD>(ctx, a, phi->ntiles, SWv); break;
+      }
+    } else if (!rc) {
       switch (model) {
         case BC_MODEL_LINREG_LL: rc = launch_project_nt<BC_MODEL_LINREG_LL>(ctx, a, phi->ntiles, NTsel); break;
         case BC_MODEL_LINREG_BETA: rc = launch_project_nt<BC_MODEL_LINREG_BETA>(ctx, a, phi->ntiles, NTsel); break;

@@ -60,6 +60,11 @@ struct SnnlsDev {
   long long tr_cap;
   double bnorm, tol, norm_sum;
   int s, world, rec_len;
+  // single-rank fast path: the finish kernel reduces the sweep's per-block candidates itself
+  const double* blk_val;
+  const long long* blk_idx;
+  int nblk;
+  int fuse_winner;
 };
 
 struct bc_snnls {
@@ -99,8 +104,22 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
     const int G = blockDim.x / s;
     const int g = threadIdx.x / s, k = threadIdx.x - g * s;
     double acc = 0.0;
-    if (g < G)
-      for (long long j = g; j < nnz; j += G) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
+    if (g < G) {
+      // 8 independent loads in flight per thread: the list lives in global memory and a dependent
+      // load per term would cost a full memory latency each
+      long long j = g;
+      for (; j + 7 * (long long)G < nnz; j += 8 * (long long)G) {
+        double v8[8], c8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v8[u] = P.val[j + u * (long long)G];
+          c8[u] = P.cols[(size_t)(j + u * (long long)G) * s + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(v8[u], c8[u], acc);
+      }
+      for (; j < nnz; j += G) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
+    }
     part[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < s) {
@@ -234,6 +253,36 @@ __device__ void dev_pick(const SnnlsDev& P, SnnlsState& S, double* red) {
   __syncthreads();
 }
 
+// single-rank variant of dev_pick: reduce the sweep's per-block candidates here (no record round trip)
+__device__ void dev_pick_blocks(const SnnlsDev& P, SnnlsState& S) {
+  __shared__ double sv[16];
+  __shared__ long long si[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double bv = -INFINITY;
+  long long bi = LLONG_MAX;
+  for (int i = threadIdx.x; i < P.nblk; i += blockDim.x)
+    if (bc_better(P.blk_val[i], P.blk_idx[i], bv, bi)) { bv = P.blk_val[i]; bi = P.blk_idx[i]; }
+  bc_wave_argmax(bv, bi);
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nwv = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nwv; ++w)
+      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    const bool valid = bi != LLONG_MAX;
+    S.sel_valid = valid ? 1 : 0;
+    S.sel_f = valid ? bi : -1;
+    S.sel_score = bv;
+    S.sel_norm = valid ? P.norms[bi - P.row_offset] : 0.0;
+  }
+  __syncthreads();
+  if (S.sel_valid) {
+    const long long r = S.sel_f - P.row_offset;
+    for (int k = threadIdx.x; k < P.s; k += blockDim.x) P.xf[k] = P.tiles[bc_tile_off(r, k, P.s)];
+  }
+  __syncthreads();
+}
+
 // closed-form step sizes.  Returns 1 when the reference would raise NumericalPrecisionError
 // (w untouched), else 0 with (alpha, beta) set.
 template <int ALG>
@@ -362,21 +411,38 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_prep(SnnlsDev P, int reset_r
   if (threadIdx.x == 0) *P.st = S;
 }
 
-// one guarded greedy iteration, snnls.py:41-74
+// one guarded greedy iteration, snnls.py:41-74.  The S-vectors (b, bn, xw, xf, previous xw) live in
+// LDS for the duration of the kernel (lds_vecs != 0): one parallel load at the start instead of a
+// global-memory round trip per use.
 template <int ALG>
-__global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P) {
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P0, int lds_vecs) {
+  extern __shared__ double vec_lds[];
   __shared__ SnnlsState S;
   __shared__ double red[64];
   __shared__ int sh_fail;
-  if (threadIdx.x == 0) S = *P.st;
+  if (threadIdx.x == 0) S = *P0.st;
+  SnnlsDev P = P0;
+  const int s = P.s;
+  if (lds_vecs) {
+    P.b = vec_lds;
+    P.bn = vec_lds + s;
+    P.xw = vec_lds + 2 * s;
+    P.xf = vec_lds + 3 * s;
+    P.xw_prev = vec_lds + 4 * s;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      P.b[k] = P0.b[k];
+      P.bn[k] = P0.bn[k];
+      P.xw[k] = P0.xw[k];
+    }
+  }
   __syncthreads();
   if (S.reached_limit) return;                       // snnls.py:32-34 / :73-74
-  const int s = P.s;
   const bool guard = S.npos > 0;                     // snnls.py:44-45 (check_error_monotone is True for GIGA/FW)
   int fail = S.select_fail;                          // _select raised
   long long f = -1;
   if (!fail) {
-    dev_pick<ALG>(P, S, red);
+    if (P.fuse_winner) dev_pick_blocks(P, S);
+    else dev_pick<ALG>(P, S, red);
     if (!S.sel_valid) fail = 1;
     f = S.sel_f;
   }
@@ -422,7 +488,12 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P) {
   dev_trace(P, S, f, sh_fail);
   __syncthreads();
   dev_prep<ALG>(P, S, red);
-  if (threadIdx.x == 0) *P.st = S;
+  if (lds_vecs)
+    for (int k = threadIdx.x; k < s; k += blockDim.x) P0.xw[k] = P.xw[k];
+  if (threadIdx.x == 0) {
+    S.sel_valid = 0;      // the picked column lived in LDS: a later step-wise reweight must fetch it again
+    *P0.st = S;
+  }
 }
 
 template <int ALG>
@@ -774,8 +845,8 @@ static int launch_prep(bc_snnls* h, int reset_retry) {
   return BC_OK;
 }
 
-static int launch_sweep(bc_snnls* h) {
-  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, h->cand_send);
+static int launch_sweep(bc_snnls* h, bool with_record) {
+  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, with_record ? h->cand_send : nullptr);
 }
 
 // ---- fused loop
@@ -791,15 +862,28 @@ extern "C" int bc_snnls_build_begin(bc_snnls* h, int itrs) {
   return launch_prep(h, 1);
 }
 
+// the finish kernel may take the sweep's block candidates directly when nobody else needs the record
+static bool fuse_winner(const bc_snnls* h) { return h->d.world == 1 && h->cand_send_owned; }
+
 extern "C" int bc_snnls_step_local(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
-  return launch_sweep(h);
+  return launch_sweep(h, !fuse_winner(h));
 }
 
 extern "C" int bc_snnls_step_finish(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
-  if (h->alg == BC_ALG_GIGA) LAUNCH1(k_step_finish<BC_ALG_GIGA>, h->d);
-  else LAUNCH1(k_step_finish<BC_ALG_FW>, h->d);
+  SnnlsDev d = h->d;
+  d.fuse_winner = fuse_winner(h) ? 1 : 0;
+  d.blk_val = h->phi->blk_val;
+  d.blk_idx = h->phi->blk_idx;
+  d.nblk = h->phi->sweep_blocks;
+  const int lds_vecs = d.s <= 1024 ? 1 : 0;
+  const size_t lds = lds_vecs ? (size_t)5 * d.s * sizeof(double) : 0;
+  if (h->alg == BC_ALG_GIGA)
+    hipLaunchKernelGGL(k_step_finish<BC_ALG_GIGA>, dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, lds_vecs);
+  else
+    hipLaunchKernelGGL(k_step_finish<BC_ALG_FW>, dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, lds_vecs);
+  BC_HIP(hipGetLastError());
   h->nnz_upper += 1;
   h->iter_upper += 1;
   return BC_OK;
@@ -837,7 +921,7 @@ extern "C" int bc_snnls_select_local(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
   int rc = launch_prep(h, 0);
   if (rc) return rc;
-  return launch_sweep(h);
+  return launch_sweep(h, true);
 }
 
 extern "C" int bc_snnls_select_pick(bc_snnls* h, int64_t* f) {

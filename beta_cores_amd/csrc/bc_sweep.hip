@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void k_local_winner(const double* __restrict__
 }
 
 // host-side launcher shared by bc_phi_argmax and the solver loop
+// rec_dev == nullptr: sweep only (the caller reduces p->blk_val / p->blk_idx itself)
 int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev) {
   bc_ctx* ctx = p->ctx;
   bc_sweep_args a;
@@ -175,6 +176,7 @@ int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, c
   BC_HIP(hipGetLastError());
   rc = bc_timer_end(ctx, 0);
   if (rc) return rc;
+  if (!rec_dev) return BC_OK;
   hipLaunchKernelGGL(k_local_winner, dim3(1), dim3(256), 0, ctx->stream, p->blk_val, p->blk_idx, p->sweep_blocks,
                      p->tiles, p->norms, p->s, (long long)p->row_offset, skip_flag, rec_dev);
   BC_HIP(hipGetLastError());

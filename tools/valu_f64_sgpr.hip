@@ -4,9 +4,9 @@
 #include <cstdio>
 #include <vector>
 template <int R, int SW>
-__global__ __launch_bounds__(256) void k(const double* __restrict__ theta, const double* __restrict__ xin, double* out, int D, int reps) {
+__global__ __launch_bounds__(256, 2) void k(const double* __restrict__ theta, const double* __restrict__ xin, double* out, int D, int reps) {
   __shared__ double xl[64 * R * 33];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double acc[R][SW];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k(const double* __restrict__ theta, const
     for (int s = 0; s < SW; ++s) acc[r][s] = 0.;
   for (int i = threadIdx.x; i < 64 * R * 33; i += 256) xl[i] = xin[i % 1024];
   __syncthreads();
-  const double* th = theta + (w & 1) * SW;     // two sample halves
+  const double* th = theta + (w & 1) * SW;     // two sample halves (wave-uniform)
   for (int rep = 0; rep < reps; ++rep) {
     for (int d = 0; d < D; ++d) {
       double x[R];
@@ -55,4 +55,4 @@ void run(int bpc) {
   double fl = (double)grid * 256 * R * SW * 2.0 * D * reps;
   printf("R=%d SW=%d blocks/CU=%d: %.3f ms  %.1f TF\n", R, SW, bpc, ms, fl / ms / 1e9);
 }
-int main() { run<4, 50>(1); run<4, 50>(2); run<2, 50>(2); run<2, 100>(1); run<2, 100>(2); run<1, 100>(2); run<4, 25>(2); run<4, 25>(4); return 0; }
+int main() { run<4, 25>(1); run<4, 25>(2); run<2, 50>(2); run<2, 32>(2); run<2, 32>(4); run<4, 16>(2); run<4, 16>(4); return 0; }
