@@ -21,6 +21,20 @@
 #include <vector>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double bc_d2v __attribute__((ext_vector_type(2)));
+// Z is read once and Phi written once per projection; the non-temporal policy on both streams
+// (aux = 2 is the `nt` bit of buffer loads on gfx950) was measured and changes nothing here (the kernel
+// is MFMA-bound: 3.18 ms vs 3.05-3.11 ms at N=4M, D=128), so it stays off unless built with -DBC_K1_NT.
+#ifdef BC_K1_NT
+#define BC_K1_Z_AUX 2
+__device__ __forceinline__ void bc_store2(double* p, double x, double y) {
+  bc_d2v v = {x, y};
+  __builtin_nontemporal_store(v, reinterpret_cast<bc_d2v*>(p));
+}
+#else
+#define BC_K1_Z_AUX 0
+__device__ __forceinline__ void bc_store2(double* p, double x, double y) { *reinterpret_cast<double2*>(p) = make_double2(x, y); }
+#endif
 
 struct ProjArgs {
   const double* z;        // [n_rows][dz]
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     const int voff = (zrw * a.dz + col) * 8;
 #pragma unroll
     for (int q = 0; q < ZP; ++q)
-      zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * ZROWS * a.dz * 8, 0));
+      zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * ZROWS * a.dz * 8, BC_K1_Z_AUX));
 #pragma unroll
     for (int q = 0; q < TP; ++q)   // rows past NT*16 are outside the descriptor and read as 0
       tr[q] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, (q * TROWS * a.dk + d0) * 8, 0));
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       const int s = 16 * st + g + 4 * reg;
       double cp;
       if (JT == 2) {
-        if (s < S) *reinterpret_cast<double2*>(tbase + (size_t)s * BC_TILE) = make_double2(acc[0][st][reg], acc[JT - 1][st][reg]);
+        if (s < S) bc_store2(tbase + (size_t)s * BC_TILE, acc[0][st][reg], acc[JT - 1][st][reg]);
         cp = acc[0][st][reg] + acc[JT - 1][st][reg];
       } else {
         if (s < S) tbase[(size_t)s * BC_TILE] = acc[0][st][reg];
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_project_v(ProjArgs a) {
     const int voff = (zrw * a.dz + col) * 8;
 #pragma unroll
     for (int q = 0; q < KC; ++q)
-      zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * 32 * a.dz * 8, 0));
+      zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * 32 * a.dz * 8, BC_K1_Z_AUX));
   };
   auto store_chunk = [&]() {
 #pragma unroll
@@ -393,8 +407,8 @@ __global__ __launch_bounds__(256, 2) void k_project_v(ProjArgs a) {
   for (int j = 0; j < SW; ++j) {
     const int sidx = w * SW + j;
     if (sidx < S) {
-      *reinterpret_cast<double2*>(tA + (size_t)sidx * BC_TILE) = make_double2(acc[0][j], acc[1][j]);
-      if (hasB) *reinterpret_cast<double2*>(tB + (size_t)sidx * BC_TILE) = make_double2(acc[2][j], acc[3][j]);
+      bc_store2(tA + (size_t)sidx * BC_TILE, acc[0][j], acc[1][j]);
+      if (hasB) bc_store2(tB + (size_t)sidx * BC_TILE, acc[2][j], acc[3][j]);
     }
     // column partials (K2): one per 128-row tile, summed over the wave's 64 lanes
     double cpa = bc_wave_sum(acc[0][j] + acc[1][j]);
