@@ -187,6 +187,16 @@ def main():
     out = None
     if rank == 0:
         ach = k3_bytes / (k3_ms_per * 1e-3) / 1e9 if k3_ms_per > 0 else 0.0
+        # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+        # this process); only quoted when it was collected on exactly this workload shape
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            if tj['config'] == {'N': N, 'D': D, 'S': S, 'n_gpus': world} and args.alg == 'giga':
+                traffic = tj['k_sweep']['traffic_bytes_per_launch']
+                traffic_src = 'profiles/r01_pmc_traffic.json: ' + tj['k_sweep']['correction']
+        except Exception:
+            pass
         out = {
             'metric': 'greedy coreset iterations/sec', 'value': args.steps / t_steps, 'unit': 'iterations/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * t_steps / args.steps,
@@ -196,7 +206,7 @@ def main():
                        'N': N, 'D': D, 'S': S, 'M': total, 'rows_per_gpu': n_local, 'parallelism': 'rows/%d' % world},
             'roofline': {'kernel': 'k_sweep<GIGA> (K3 score+argmax)' if args.alg == 'giga' else 'k_sweep<dot>',
                          'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'bytes_per_launch': k3_bytes, 'avg_launch_ms': k3_ms_per, 'launches': k3_n},
             'projection': {'points_dims_per_s': N * D / t_proj, 'ms': 1e3 * t_proj, 'kernel_ms': k1_ms_per,
                            'roofline_hbm': {'achieved': k1_bytes / (k1_ms_per * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,

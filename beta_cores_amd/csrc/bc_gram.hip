@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
                                                     const double* __restrict__ partial_y, long long splits, int ntri,
                                                     int nt, int bt, int dz, double* __restrict__ out,
                                                     double* __restrict__ out_y) {
+  // grid = (ntri, bt*bt/256): one output element per thread, partials summed in split order
   const int tri = blockIdx.x;
-  if (tri == 0)
+  if (tri == 0 && blockIdx.y == 0)
     for (int c = threadIdx.x; c < dz; c += blockDim.x) {
       double acc = 0.0;
       for (long long sp = 0; sp < splits; ++sp) acc += partial_y[(size_t)sp * nt * bt + c];
@@ -150,17 +151,24 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
   int ta = 0, rem = tri;
   while (rem >= nt - ta) { rem -= nt - ta; ++ta; }
   const int tb = ta + rem;
-  for (int e = threadIdx.x; e < bt * bt; e += blockDim.x) {
-    double acc = 0.0;
-    for (long long sp = 0; sp < splits; ++sp) acc += partial[((size_t)sp * ntri + tri) * bt * bt + e];
-    const int r = ta * bt + e / bt, c = tb * bt + e % bt;
-    if (r < dz && c < dz) {
-      if (ta != tb || r <= c) {
-        out[(size_t)r * dz + c] = acc;
-        out[(size_t)c * dz + r] = acc;
-      }
-    }
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= bt * bt) return;
+  const int r = ta * bt + e / bt, c = tb * bt + e % bt;
+  if (r >= dz || c >= dz || (ta == tb && r > c)) return;
+  double acc = 0.0;
+  const double* p = partial + (size_t)tri * bt * bt + e;
+  const size_t stride = (size_t)ntri * bt * bt;
+  long long sp = 0;
+  for (; sp + 8 <= splits; sp += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sp + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
   }
+  for (; sp < splits; ++sp) acc += p[(size_t)sp * stride];
+  out[(size_t)r * dz + c] = acc;
+  out[(size_t)c * dz + r] = acc;
 }
 
 template <int BT>
@@ -202,7 +210,7 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   }
   if (!rc && e == hipSuccess) rc = bc_timer_end(ctx, 2);
   if (!rc && e == hipSuccess) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3(ntri), dim3(256), 0, ctx->stream, partial, partial_y, splits, ntri, nt, BT, d,
+    hipLaunchKernelGGL(k_gram_reduce, dim3(ntri, (BT * BT + 255) / 256), dim3(256), 0, ctx->stream, partial, partial_y, splits, ntri, nt, BT, d,
                        out_dev, outy_dev);
     e = hipGetLastError();
   }

@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256) void k_sweep(bc_sweep_args a, double* __restri
       const double2* __restrict__ p = reinterpret_cast<const double2*>(a.tiles + (size_t)t * S * BC_TILE) + lane;
       double a00 = 0., a01 = 0., a10 = 0., a11 = 0.;
       int k = 0;
-      constexpr int U = 10;
+#ifndef BC_SWEEP_U
+#define BC_SWEEP_U 10
+#endif
+      constexpr int U = BC_SWEEP_U;
       for (; k + U <= S; k += U) {
         double2 x[U];
 #pragma unroll
