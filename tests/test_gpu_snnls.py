@@ -252,3 +252,42 @@ def test_sampling_solvers(bc):
         dev = cls(phi.T, phi.sum(axis=0)); dev.build(20)
         np.testing.assert_allclose(dev.weights(), ref.w, rtol=1e-12)
         np.testing.assert_allclose(dev.error(), ref.error(), rtol=1e-9)
+
+
+def test_empty_and_tiny_inputs(bc):
+    """snnls.py:36-38: an empty A makes build() a logged no-op; N = 1 works (test_deterministic.py N in {1,...})."""
+    s = bc.snnls.GIGA(np.zeros((4, 0)), np.ones(4))
+    s.build(3)
+    assert s.size() == 0 and s.weights().shape == (0,) and not s.reached_numeric_limit
+    assert abs(s.error() - 2.0) < 1e-15
+    x = np.array([[0.3, -1.2, 0.5]])
+    for cls in (bc.snnls.GIGA, bc.snnls.FrankWolfe, bc.snnls.OrthoPursuit):
+        s = cls(x.T, x.sum(axis=0))
+        s.build(2)
+        assert s.size() == 1 and abs(s.weights()[0] - 1.0) < 1e-12 and s.error() < 1e-12   # one point is immediately optimal
+    d = bc.DevicePhi.from_host(np.zeros((0, 3)))
+    assert d.shape == (0, 3) and d.to_host().shape == (0, 3) and np.array_equal(d.colsum(), np.zeros(3))
+    assert d.argmax(np.ones(3), mode=1)[0] == -1
+
+
+def test_large_active_set_growth(bc):
+    """More selected points than the initial device capacity (256 entries): lists, cached columns and the
+    trace are re-allocated between build calls without losing state."""
+    rng = np.random.RandomState(2)
+    phi = rng.randn(4000, 150)
+    from oracle import RefGIGA
+    ref = RefGIGA(phi.T, phi.sum(axis=0)); ref.build(400)
+    dev = bc.snnls.GIGA(phi.T, phi.sum(axis=0))
+    for _ in range(4):
+        dev.build(100)
+    one = bc.snnls.GIGA(phi.T, phi.sum(axis=0))
+    one.build(400)
+    idx, val = dev.sparse_weights()
+    i1, v1 = one.sparse_weights()
+    assert len(idx) > 256
+    assert np.array_equal(idx, i1) and np.array_equal(val, v1)        # incremental == one-shot, bit for bit
+    ridx = np.where(ref.w > 0)[0]
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_allclose(val, ref.w[ridx], rtol=1e-5)
+    f, st, er = dev._eng.trace()
+    np.testing.assert_array_equal(f, [t[0] for t in ref.trace])
