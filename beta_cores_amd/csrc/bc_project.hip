@@ -429,18 +429,24 @@ static int launch_project_v(bc_ctx* ctx, const ProjArgs& a, long long ntiles, in
   return BC_OK;
 }
 
-// x^T Siginv x per row, in the reference's order: (x * (x.dot(Siginv))).sum(axis=1)   (gaussian.py:10)
+// x^T Siginv x per row, in the reference's order: (x * (x.dot(Siginv))).sum(axis=1)   (gaussian.py:10).
+// Siginv is staged in LDS when it fits (use_lds), otherwise read through the caches (wave-uniform loads).
 __global__ __launch_bounds__(256) void k_row_quadform(const double* __restrict__ z, long long n_rows, int d,
-                                                     const double* __restrict__ siginv, double* __restrict__ out) {
-  extern __shared__ double sl[];   // Siginv [d][d]
-  for (int i = threadIdx.x; i < d * d; i += blockDim.x) sl[i] = siginv[i];
-  __syncthreads();
+                                                     const double* __restrict__ siginv, double* __restrict__ out,
+                                                     int use_lds) {
+  extern __shared__ double sl[];   // Siginv [d][d] when use_lds
+  const double* __restrict__ sg = siginv;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < d * d; i += blockDim.x) sl[i] = siginv[i];
+    __syncthreads();
+    sg = sl;
+  }
   for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (long long)gridDim.x * blockDim.x) {
     const double* x = z + (size_t)r * d;
     double tot = 0.;
     for (int aa = 0; aa < d; ++aa) {
       double t = 0.;
-      for (int bb = 0; bb < d; ++bb) t = fma(x[bb], sl[bb * d + aa], t);
+      for (int bb = 0; bb < d; ++bb) t = fma(x[bb], sg[bb * d + aa], t);
       tot += x[aa] * t;
     }
     out[r] = tot;
@@ -669,15 +675,11 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
     memcpy(hsi, siginv, (size_t)d * d * sizeof(double));
     e = hipMemcpyAsync(sc.siginv, hsi, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      if ((size_t)d * d * sizeof(double) > 60 * 1024) {
-        if (fresh) bc_phi_destroy(phi);
-        bc_set_error("bc_project: Gaussian-location model supports d <= 87 in this build (Siginv staged in LDS)");
-        return BC_INVALID_ARGUMENT;
-      }
+      const int use_lds = (size_t)d * d * sizeof(double) <= 60 * 1024;
       long long blocks = (data->n_rows + 255) / 256;
       if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(k_row_quadform, dim3((unsigned)blocks), dim3(256), (size_t)d * d * sizeof(double), ctx->stream,
-                         data->z, (long long)data->n_rows, d, sc.siginv, sc.rowaux);
+      hipLaunchKernelGGL(k_row_quadform, dim3((unsigned)blocks), dim3(256), use_lds ? (size_t)d * d * sizeof(double) : 0,
+                         ctx->stream, data->z, (long long)data->n_rows, d, sc.siginv, sc.rowaux, use_lds);
       e = hipGetLastError();
       a.rowaux = sc.rowaux;
     }

@@ -94,6 +94,21 @@ def test_ragged_shapes_linreg(bc, n, d, s):
     check_phi(prj.project_f(Z, 0.3), M.linreg_beta_lik(Z, th, 0.3, 1.3))
 
 
+def test_gaussian_location_large_d(bc):
+    """d = 100 (the reference example's dimension, zellner_gaussian/main.py:37): Siginv no longer fits the
+    LDS staging of the row quadratic form."""
+    rng = np.random.RandomState(100)
+    n, d, s = 700, 100, 200
+    A = rng.randn(d, d) * 0.1
+    Sig = A.dot(A.T) + 5. * np.eye(d)
+    Siginv, logdet = np.linalg.inv(Sig), np.linalg.slogdet(Sig)[1]
+    X = rng.randn(n, d) * 2.
+    th = rng.randn(s, d)
+    prj = bc.DeviceBetaProjector(fixed(th), s, bc.likelihoods.GaussianLocation(Siginv, logdet))
+    check_phi(prj.project(X), M.gauss_loglik(X, th, Siginv, logdet), tol=1e-10)
+    check_phi(prj.project_f(X, 0.1), M.gauss_beta_lik(X, th, 0.1, Siginv, logdet), tol=1e-10)
+
+
 @pytest.mark.parametrize('d,s', [(16, 100), (128, 100), (40, 200)])
 def test_logistic_random(bc, d, s):
     rng = np.random.RandomState(d + s)
