@@ -47,6 +47,7 @@ struct ProjArgs {
   double* tile_part;
   long long n_rows;
   int dz, d, dk, s, model;
+  int s_total, s_off;     // RAW passes (S > 256): this launch fills samples [s_off, s_off + s) of s_total, un-centred
   double c[8];            // model constants, see model_constants()
 };
 
@@ -92,7 +93,7 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
 // NT = number of 16-sample accumulator tiles (S <= 16*NT), KC = D-chunk staged per LDS pass,
 // JT = 16-row sub-tiles per wave (2 -> 4 waves per 128-row tile, 1 -> 8 waves; the latter keeps
 // the accumulators of a 200+-sample projection within the register file).
-template <int MODEL, int NT, int KC, int JT>
+template <int MODEL, int NT, int KC, int JT, bool RAW = false>
 __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2) void k_project(ProjArgs a) {
   constexpr int NTHR = 128 / (16 * JT) * 64;
   constexpr int LDZ = KC + 1;    // odd stride: rows (2j, 2j+1) of a lane pair hit distinct banks
@@ -178,6 +179,31 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   }
 
   // ---- epilogue: lane holds, for data rows (row_base + jt), samples s = 16*st + g + 4*reg
+  if (RAW) {
+    // S > 256: write the un-centred model values of this sample range; k_center_tiles finishes the job
+    double* rbase = a.tiles + (size_t)tile * a.s_total * BC_TILE + row_base;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      const long long gr = r0 + row_base + jt;
+      const bool live = gr < a.n_rows;
+      double ra = 0.;
+      if (live) {
+        if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra = a.z[(size_t)gr * a.dz + a.d];
+        else if (MODEL >= BC_MODEL_GAUSS_LL) ra = a.rowaux[gr];
+      }
+#pragma unroll
+      for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int s = 16 * st + g + 4 * reg;
+          if (s < S) {
+            const double v = live ? bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c) : 0.;
+            rbase[(size_t)(a.s_off + s) * BC_TILE + jt] = v;
+          }
+        }
+    }
+    return;
+  }
   double* colpart = Tl;   // [waves][NT*16]
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) {
@@ -261,6 +287,52 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     for (int ww = 1; ww < NW; ++ww) t += colpart[ww * NT * 16 + s];
     a.tile_part[(size_t)tile * S + s] = t;
   }
+}
+
+// S > 256, second stage: centre the rows of one tile (subtract the mean over all s_total samples; constant
+// rows become exactly 0), write them back, emit the row norms and the tile's column partial sums.
+__global__ __launch_bounds__(256) void k_center_tiles(double* __restrict__ tiles, double* __restrict__ norms,
+                                                     double* __restrict__ tile_part, long long n_rows, int S) {
+  __shared__ double lds[32 * (BC_TILE + 1)];
+  const long long t = blockIdx.x;
+  double* tp = tiles + (size_t)t * S * BC_TILE;
+  const int tid = threadIdx.x, r = tid & (BC_TILE - 1), half = tid >> 7;   // two threads per row: even / odd chunks of 32 samples
+  const bool live = t * BC_TILE + r < n_rows;
+  __shared__ double psum[256], pmin[256], pmax[256];
+  double sum = 0., vmin = INFINITY, vmax = -INFINITY;
+  for (int s = half; s < S; s += 2) {
+    const double v = tp[(size_t)s * BC_TILE + r];
+    sum += v;
+    vmin = fmin(vmin, v);
+    vmax = fmax(vmax, v);
+  }
+  psum[tid] = sum; pmin[tid] = vmin; pmax[tid] = vmax;
+  __syncthreads();
+  const double tot = psum[r] + psum[128 + r];
+  const double mn = fmin(pmin[r], pmin[128 + r]), mx = fmax(pmax[r], pmax[128 + r]);
+  const double mean = (mn == mx) ? mx : tot / (double)S;
+  __syncthreads();
+  double sq = 0.;
+  for (int s0 = 0; s0 < S; s0 += 32) {
+    const int kc = (S - s0) < 32 ? (S - s0) : 32;
+    for (int k = half; k < kc; k += 2) {
+      double v = tp[(size_t)(s0 + k) * BC_TILE + r];
+      v = live ? v - mean : 0.;
+      tp[(size_t)(s0 + k) * BC_TILE + r] = v;
+      lds[k * (BC_TILE + 1) + r] = v;
+      sq = fma(v, v, sq);
+    }
+    __syncthreads();
+    if (tid < kc) {
+      double acc = 0.0;
+      for (int rr = 0; rr < BC_TILE; ++rr) acc += lds[tid * (BC_TILE + 1) + rr];
+      tile_part[(size_t)t * S + s0 + tid] = acc;
+    }
+    __syncthreads();
+  }
+  psum[tid] = sq;
+  __syncthreads();
+  if (tid < BC_TILE) norms[t * BC_TILE + tid] = sqrt(psum[tid] + psum[128 + tid]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,6 +526,9 @@ __global__ __launch_bounds__(256) void k_row_quadform(const double* __restrict__
 }
 
 // ------------------------------------------------------------------ host side
+static int bc_project_wide(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                           const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
+
 struct ProjScratch {
   double* theta = nullptr;
   size_t theta_cap = 0;
@@ -548,16 +623,16 @@ static int model_constants(int model, const double* p, int np, int d, double* c,
   return BC_INVALID_ARGUMENT;
 }
 
-template <int MODEL, int NT, int KC, int JT>
+template <int MODEL, int NT, int KC, int JT, bool RAW = false>
 static int launch_project(bc_ctx* ctx, const ProjArgs& a, long long ntiles) {
   const size_t lds = (size_t)(128 * (KC + 1) + NT * 16 * (KC + 2)) * sizeof(double);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT>),
+    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT, RAW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_project<MODEL, NT, KC, JT>), dim3((unsigned)ntiles), dim3(128 / (16 * JT) * 64), lds, ctx->stream, a);
+  hipLaunchKernelGGL((k_project<MODEL, NT, KC, JT, RAW>), dim3((unsigned)ntiles), dim3(128 / (16 * JT) * 64), lds, ctx->stream, a);
   BC_HIP(hipGetLastError());
   return BC_OK;
 }
@@ -576,15 +651,18 @@ static int launch_project_nt(bc_ctx* ctx, const ProjArgs& a, long long ntiles, i
   }
 }
 
-extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
-                          const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout) {
+// One launch of the projection.  raw == false: the whole of Phi (s == s_total <= 256), centred, with
+// norms and column partials.  raw == true: samples [s_off, s_off + s) of s_total, un-centred.
+static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                        const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout,
+                        int32_t s_total, int32_t s_off, bool raw) {
   if (!ctx || !data || !theta || !inout || s <= 0 || (n_params > 0 && !params)) {
     bc_set_error("bc_project: bad argument");
     return BC_INVALID_ARGUMENT;
   }
   if (data->ctx != ctx) { bc_set_error("bc_project: data belongs to another context"); return BC_INVALID_ARGUMENT; }
   if (model < 0 || model > BC_MODEL_GAUSS_BETA_GRAD) { bc_set_error("bc_project: unknown model %d", model); return BC_INVALID_ARGUMENT; }
-  if (s > 256) { bc_set_error("bc_project: projection dimension S=%d > 256 is not supported by this build", s); return BC_INVALID_ARGUMENT; }
+  if (s > 256) { bc_set_error("bc_project: internal: a single pass handles at most 256 samples"); return BC_INVALID_ARGUMENT; }
   const bool has_y = (model == BC_MODEL_LINREG_LL || model == BC_MODEL_LINREG_BETA);
   const int d = data->dz - (has_y ? 1 : 0);
   if (d <= 0) { bc_set_error("bc_project: data rows too short for this model"); return BC_INVALID_ARGUMENT; }
@@ -598,13 +676,13 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
   }
   // output handle: reuse buffers when the shape matches
   bc_phi* phi = *inout;
-  if (phi && (phi->ctx != ctx || phi->n_rows != data->n_rows || phi->s != s)) {
+  if (phi && (phi->ctx != ctx || phi->n_rows != data->n_rows || phi->s != s_total)) {
     bc_set_error("bc_project: *inout has a different shape; pass NULL to allocate");
     return BC_INVALID_ARGUMENT;
   }
   bool fresh = false;
   if (!phi) {
-    int rc = bc_phi_alloc(ctx, data->n_rows, s, row_offset, &phi);
+    int rc = bc_phi_alloc(ctx, data->n_rows, s_total, row_offset, &phi);
     if (rc) return rc;
     fresh = true;
   }
@@ -612,12 +690,12 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
   phi->stats_valid = false;
 
   const int nt = (s + 15) / 16;
-  const int NTsel = nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 16;
+  const int NTsel = raw ? 16 : nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 16;
   // The vector-FMA kernel is parity-clean but measured SLOWER than the MFMA kernel in round 1
   // (N=4M, D=128: 3.73 ms vs 3.11 ms; its scalar theta loads are not software-pipelined yet), so it is
   // opt-in: BC_K1_VALU=1.
   static const int want_valu = getenv("BC_K1_VALU") ? atoi(getenv("BC_K1_VALU")) : 0;
-  const bool use_valu = s <= 100 && want_valu;            // vector-FMA kernel: sample quarters of <= 25
+  const bool use_valu = s <= 100 && want_valu && !raw;    // vector-FMA kernel: sample quarters of <= 25
   const int SWv = s <= 64 ? 16 : 25;
   const int KC = NTsel <= 7 ? 32 : 16;                    // dk is a multiple of 8 (the VALU kernel's chunk) either way
   const int dk = ((d + KC - 1) / KC) * KC;
@@ -698,11 +776,23 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
   a.d = d;
   a.dk = dk;
   a.s = s;
+  a.s_total = s_total;
+  a.s_off = s_off;
   a.model = model;
   rc = BC_OK;
   if (phi->ntiles > 0) {
     rc = bc_timer_begin(ctx, 1);
-    if (!rc && use_valu) {
+    if (!rc && raw) {
+      switch (model) {
+        case BC_MODEL_LINREG_LL: rc = launch_project<BC_MODEL_LINREG_LL, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
+        case BC_MODEL_LINREG_BETA: rc = launch_project<BC_MODEL_LINREG_BETA, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
+        case BC_MODEL_LOGISTIC_LL: rc = launch_project<BC_MODEL_LOGISTIC_LL, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
+        case BC_MODEL_LOGISTIC_BETA: rc = launch_project<BC_MODEL_LOGISTIC_BETA, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
+        case BC_MODEL_GAUSS_LL: rc = launch_project<BC_MODEL_GAUSS_LL, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
+        case BC_MODEL_GAUSS_BETA: rc = launch_project<BC_MODEL_GAUSS_BETA, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
+        default: rc = launch_project<BC_MODEL_GAUSS_BETA_GRAD, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
+      }
+    } else if (!rc && use_valu) {
       switch (model) {
         case BC_MODEL_LINREG_LL: rc = launch_project_v<BC_MODEL_LINREG_LL>(ctx, a, phi->ntiles, SWv); break;
         case BC_MODEL_LINREG_BETA: rc = launch_project_v<BC_MODEL_LINREG_BETA>(ctx, a, phi->ntiles, SWv); break;
@@ -728,8 +818,44 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
     e = hipMemsetAsync(phi->norms, 0, BC_TILE * sizeof(double), ctx->stream);
     if (e != hipSuccess) rc = bc_hip_fail(e, "memset", __FILE__, __LINE__);
   }
-  if (!rc) rc = bc_phi_finish_stats(phi);
+  if (!rc && !raw) rc = bc_phi_finish_stats(phi);
   if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
   *inout = phi;
   return BC_OK;
+}
+
+// S > 256: passes of <= 256 samples write un-centred values, then one centring pass over Phi.
+static int bc_project_wide(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                           const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout) {
+  const bool has_y = (model == BC_MODEL_LINREG_LL || model == BC_MODEL_LINREG_BETA);
+  const int d = data->dz - (has_y ? 1 : 0);
+  bc_phi* phi = *inout;
+  const bool fresh = phi == nullptr;
+  for (int s_off = 0; s_off < s; s_off += 256) {
+    const int cs = (s - s_off) < 256 ? (s - s_off) : 256;
+    int rc = project_impl(ctx, data, model, theta + (size_t)s_off * d, cs, params, n_params, row_offset, &phi, s, s_off, true);
+    if (rc) { if (fresh && phi) bc_phi_destroy(phi); return rc; }
+  }
+  if (phi->ntiles > 0) {
+    hipLaunchKernelGGL(k_center_tiles, dim3((unsigned)phi->ntiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                       phi->tile_part, (long long)phi->n_rows, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { if (fresh) bc_phi_destroy(phi); return bc_hip_fail(e, "k_center_tiles", __FILE__, __LINE__); }
+  }
+  int rc = bc_phi_finish_stats(phi);
+  if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
+  *inout = phi;
+  return BC_OK;
+}
+
+extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                          const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout) {
+  if (!ctx || !data || !theta || !inout || s <= 0 || (n_params > 0 && !params)) {
+    bc_set_error("bc_project: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  if (data->ctx != ctx) { bc_set_error("bc_project: data belongs to another context"); return BC_INVALID_ARGUMENT; }
+  if (model < 0 || model > BC_MODEL_GAUSS_BETA_GRAD) { bc_set_error("bc_project: unknown model %d", model); return BC_INVALID_ARGUMENT; }
+  if (s > 256) return bc_project_wide(ctx, data, model, theta, s, params, n_params, row_offset, inout);
+  return project_impl(ctx, data, model, theta, s, params, n_params, row_offset, inout, s, 0, false);
 }

@@ -122,15 +122,29 @@ def test_logistic_random(bc, d, s):
     check_phi(prj.project_f(Z, 0.1), M.logistic_beta_lik(Z, th, 0.1))
 
 
-def test_projection_dimension_limit(bc):
-    th = np.zeros((257, 4))
-    prj_err = None
-    try:
-        prj = bc.DeviceProjector(fixed(th), 257, bc.likelihoods.LinearRegression(1.0))
-        prj.project(np.zeros((10, 5)))
-    except ValueError as e:
-        prj_err = e
-    assert prj_err is not None and '256' in str(prj_err)
+@pytest.mark.parametrize('n,d,s', [(300, 20, 300), (129, 33, 513), (1000, 64, 257), (5, 3, 1000)])
+def test_wide_projection_dimension(bc, n, d, s):
+    """S > 256 runs as passes of <= 256 samples (un-centred) plus one centring pass over Phi."""
+    rng = np.random.RandomState(n + s)
+    Z = rng.randn(n, d + 1)
+    th = rng.randn(s, d) * 0.5
+    prj = bc.DeviceBetaProjector(fixed(th), s, bc.likelihoods.LinearRegression(0.9))
+    check_phi(prj.project(Z), M.linreg_loglik(Z, th, 0.9))
+    check_phi(prj.project_f(Z, 0.2), M.linreg_beta_lik(Z, th, 0.2, 0.9))
+    Zl = rng.randn(n, d) * 0.4
+    prl = bc.DeviceProjector(fixed(th), s, bc.likelihoods.LogisticRegression())
+    check_phi(prl.project(Zl), M.logistic_loglik(Zl, th))
+    # and the solver runs on it (S-vector kernels are generic in S)
+    phi = prj.project(Z)
+    g = bc.snnls.GIGA(phi.T, phi.colsum())
+    g.build(min(n, 5))
+    from oracle import RefGIGA
+    P = np.asarray(phi)
+    ref = RefGIGA(P.T, P.sum(axis=0)); ref.build(min(n, 5))
+    np.testing.assert_array_equal(g.sparse_weights()[0], np.where(ref.w > 0)[0])
+
+
+def test_bad_shapes_are_rejected(bc):
     with pytest.raises(ValueError):
         bc.DeviceProjector(fixed(np.zeros((8, 4))), 8, bc.likelihoods.LinearRegression(1.0)).project(np.zeros((10, 7)))
 
