@@ -33,9 +33,12 @@ _SIGNATURES = {
     'bc_ctx_enable_timing': [vp, C.c_int],
     'bc_data_from_host': [vp, vp, C.c_int64, C.c_int32, vpp],
     'bc_data_from_device': [vp, vp, C.c_int64, C.c_int32, vpp],
+    'bc_data_create': [vp, C.c_int64, C.c_int32, vpp],
+    'bc_data_upload': [vp, vp, C.c_int64],
     'bc_data_gather_rows': [vp, vp, C.c_int64, vp],
     'bc_data_destroy': [vp],
     'bc_phi_from_host': [vp, vp, C.c_int64, C.c_int32, C.c_int64, vpp],
+    'bc_phi_create': [vp, C.c_int64, C.c_int32, vpp],
     'bc_project': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, C.c_int64, vpp],
     'bc_phi_shape': [vp, c_i64p, c_i32p, c_i64p],
     'bc_phi_colsum': [vp, vp],

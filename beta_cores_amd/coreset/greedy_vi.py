@@ -146,7 +146,8 @@ class _GreedyVICoreset(Coreset):
         scale = 1. if (grouped and self.n_subsample_select is None) else sum_scaling
         resid = scale * self._colsum(vecs) - self.wts.dot(corevecs)
         best, best_corr = self._best_correlation(vecs, resid, drop_zero_rows=not grouped)
-        corecorrs = np.fabs(corevecs.dot(resid) / np.sqrt((corevecs ** 2).sum(axis=1))) / corevecs.shape[1]
+        with np.errstate(invalid='ignore', divide='ignore'):      # an all-zero core row gives 0/0 = NaN, as in the reference
+            corecorrs = np.fabs(corevecs.dot(resid) / np.sqrt((corevecs ** 2).sum(axis=1))) / corevecs.shape[1]
         if not grouped:
             if corecorrs.size == 0 or best_corr > corecorrs.max():
                 f = sub_idcs[best] if sub_idcs is not None else best

@@ -82,54 +82,111 @@ class BetaBlackBoxProjector(Projector):
         self.samples = self.sampler(self.projection_dimension, wts, pts)
 
 
+_SMALL_ROWS = 4096     # below this an input is treated as transient (coreset points, sub-samples)
+
+
+def _pool_shutdown(state):
+    state['alive'] = False
+    destroy = N.load().bc_phi_destroy
+    for lst in state['free'].values():
+        for _, h in lst:
+            destroy(h)
+    state['free'].clear()
+
+
+class _PhiPool:
+    """Phi buffers for small projections, recycled instead of hipMalloc'ed / hipFree'd per call.
+    A handle is lent to exactly one DevicePhi wrapper; when that wrapper is garbage collected the
+    handle comes back (so two live results never alias).  Handles still on loan when the pool dies
+    stay valid and are destroyed by their wrapper."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.state = {'alive': True, 'free': {}}     # shared with the release callbacks
+        self._fin = weakref.finalize(self, _pool_shutdown, self.state)
+
+    def acquire(self, n_rows, s):
+        lst = self.state['free'].setdefault(s, [])
+        for i, (cap, h) in enumerate(lst):
+            if cap >= n_rows:
+                lst.pop(i)
+                return cap, h
+        cap = max(256, 1 << int(np.ceil(np.log2(max(n_rows, 1)))))
+        h = C.c_void_p()
+        N.call('bc_phi_create', self.ctx.h, int(cap), int(s), C.byref(h))
+        return cap, h
+
+    def releaser(self, cap, s):
+        state = self.state
+
+        def release(handle):
+            if state['alive']:
+                state['free'].setdefault(s, []).append((cap, handle))
+            else:
+                N.load().bc_phi_destroy(handle)
+        return release
+
+
 class _DeviceProjectorBase(Projector):
     def __init__(self, sampler, projection_dimension, model, ctx=None):
         self.projection_dimension = projection_dimension
         self.sampler = sampler
         self.model = model
         self.ctx = ctx or default_context()
-        self._data_cache = {}      # id(ndarray) -> (weakref, DeviceData)
-        self._phi_cache = {}       # (id(DeviceData), model_id) -> DevicePhi whose buffers get reused
+        self._data_cache = {}      # id(ndarray) -> (weakref, DeviceData)       large, repeatedly projected arrays
+        self._phi_cache = {}       # (id(DeviceData), model_id, S) -> DevicePhi  whose buffers get reused
+        self._slots = {}           # dz -> DeviceData slot for small transient inputs
+        self._pool = _PhiPool(self.ctx)
         self.update(np.array([]), np.array([]))
 
     def update(self, wts, pts):
         self.samples = self.sampler(self.projection_dimension, wts, pts)
 
-    # -- data residency: a large array projected repeatedly is uploaded once
+    # -- data residency: a large array projected repeatedly is uploaded once; small ones go through a slot
     def device_data(self, pts):
         if isinstance(pts, DeviceData):
-            return pts
+            return pts, False
         pts = np.atleast_2d(pts)
+        if pts.shape[0] < _SMALL_ROWS:
+            slot = self._slots.get(pts.shape[1])
+            if slot is None:
+                slot = self._slots[pts.shape[1]] = DeviceData.slot(pts.shape[1], cap_rows=256, ctx=self.ctx)
+            return slot.update(pts), True
         key = id(pts)
         hit = self._data_cache.get(key)
         if hit is not None and hit[0]() is pts:
-            return hit[1]
+            return hit[1], False
         dd = DeviceData(pts, ctx=self.ctx)
-        if pts.shape[0] >= 4096:       # only worth pinning big arrays; small ones (coreset points) change every call
-            try:
-                self._data_cache[key] = (weakref.ref(pts, lambda _, k=key: self._data_cache.pop(k, None)), dd)
-            except TypeError:
-                pass
-        return dd
+        try:
+            self._data_cache[key] = (weakref.ref(pts, lambda _, k=key: self._data_cache.pop(k, None)), dd)
+        except TypeError:
+            pass
+        return dd, False
 
-    def _run(self, pts, model_id, params, reuse=True):
-        dd = self.device_data(pts)
+    def _run(self, pts, model_id, params):
+        dd, transient = self.device_data(pts)
         theta = self.model.theta_for_device(self.samples)
         if dd.shape[1] != self.model.data_width(theta.shape[1]):
             raise ValueError('data rows have %d columns, model expects %d for %d-dimensional samples'
                              % (dd.shape[1], self.model.data_width(theta.shape[1]), theta.shape[1]))
         params = np.ascontiguousarray(params, dtype=np.float64)
-        key = (id(dd), model_id, theta.shape[0])
-        prev = self._phi_cache.get(key) if reuse else None
+        S = int(theta.shape[0])
+        if transient:
+            cap, h = self._pool.acquire(dd.shape[0], S)
+            N.call('bc_project', self.ctx.h, dd.h, int(model_id), _ptr(theta), S, _ptr(params), int(params.shape[0]),
+                   0, C.byref(h))
+            return DevicePhi(h, self.ctx, release=self._pool.releaser(cap, S))
+        key = (id(dd), model_id, S)
+        prev = self._phi_cache.get(key)
         h = C.c_void_p(prev.h.value) if prev is not None else C.c_void_p()
-        N.call('bc_project', self.ctx.h, dd.h, int(model_id), _ptr(theta), int(theta.shape[0]), _ptr(params),
-               int(params.shape[0]), int(dd.row_offset), C.byref(h))
+        N.call('bc_project', self.ctx.h, dd.h, int(model_id), _ptr(theta), S, _ptr(params), int(params.shape[0]),
+               int(dd.row_offset), C.byref(h))
         if prev is not None:
+            prev.refresh()
             return prev
         phi = DevicePhi(h, self.ctx)
         phi._data = dd
-        if reuse and dd.shape[0] >= 4096:
-            self._phi_cache[key] = phi
+        self._phi_cache[key] = phi
         return phi
 
 

@@ -159,11 +159,45 @@ extern "C" int bc_data_from_host(bc_ctx* ctx, const double* z, int64_t n_rows, i
   if (bytes) {
     hipError_t e = hipMalloc((void**)&d->z, bytes);
     if (e != hipSuccess) { delete d; return bc_hip_fail(e, "hipMalloc(data)", __FILE__, __LINE__); }
+    d->cap_rows = n_rows;
     e = hipMemcpyAsync(d->z, z, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d->z); delete d; return bc_hip_fail(e, "hipMemcpy(data)", __FILE__, __LINE__); }
   }
   *out = d;
+  return BC_OK;
+}
+
+extern "C" int bc_data_create(bc_ctx* ctx, int64_t cap_rows, int32_t dz, bc_data** out) {
+  if (!ctx || !out || cap_rows < 0 || dz <= 0) { bc_set_error("bc_data_create: bad argument"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  bc_data* d = new bc_data();
+  d->ctx = ctx;
+  d->dz = dz;
+  d->n_rows = 0;
+  d->cap_rows = cap_rows > 0 ? cap_rows : 1;
+  hipError_t e = hipMalloc((void**)&d->z, (size_t)d->cap_rows * dz * sizeof(double));
+  if (e != hipSuccess) { delete d; return bc_hip_fail(e, "hipMalloc(data)", __FILE__, __LINE__); }
+  *out = d;
+  return BC_OK;
+}
+
+extern "C" int bc_data_upload(bc_data* d, const double* z, int64_t n_rows) {
+  if (!d || n_rows < 0 || (n_rows > 0 && !z) || !d->owned) { bc_set_error("bc_data_upload: bad argument"); return BC_INVALID_ARGUMENT; }
+  bc_ctx* ctx = d->ctx;
+  if (n_rows > d->cap_rows) {
+    BC_HIP(hipStreamSynchronize(ctx->stream));
+    if (d->z) (void)hipFree(d->z);
+    d->z = nullptr;
+    int64_t cap = d->cap_rows * 2 > n_rows ? d->cap_rows * 2 : n_rows;
+    BC_HIP(hipMalloc((void**)&d->z, (size_t)cap * d->dz * sizeof(double)));
+    d->cap_rows = cap;
+  }
+  d->n_rows = n_rows;
+  if (n_rows > 0) {
+    BC_HIP(hipMemcpyAsync(d->z, z, (size_t)n_rows * d->dz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    BC_HIP(hipStreamSynchronize(ctx->stream));     // the host buffer is only borrowed for the call
+  }
   return BC_OK;
 }
 
@@ -232,44 +266,89 @@ int bc_sweep_grid(const bc_phi* phi) {
   return (int)(g < 1 ? 1 : g);
 }
 
-int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out) {
+static int stat_blocks_for(int64_t ntiles) {
+  const int64_t nt = ntiles > 0 ? ntiles : 1;
+  return (int)(nt < 256 ? nt : 256);
+}
+
+int bc_phi_set_rows(bc_phi* p, int64_t n_rows) {
+  const int64_t nt = (n_rows + BC_TILE - 1) / BC_TILE;
+  if (nt > p->cap_tiles) return 1;
+  p->n_rows = n_rows;
+  p->ntiles = nt;
+  p->sweep_blocks = bc_sweep_grid(p);
+  p->stat_blocks = stat_blocks_for(nt);
+  p->stats_valid = false;
+  return 0;
+}
+
+// ONE device allocation per Phi (tiles + all the small side arrays): creating / destroying a Phi is
+// one hipMalloc / hipFree, which matters when small projections are made thousands of times.
+int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out, int64_t cap_rows) {
   bc_phi* p = new bc_phi();
   p->ctx = ctx;
-  p->n_rows = n_rows;
   p->s = s;
   p->row_offset = row_offset;
-  p->ntiles = (n_rows + BC_TILE - 1) / BC_TILE;
-  size_t nt = (size_t)(p->ntiles > 0 ? p->ntiles : 1);
-  p->sweep_blocks = bc_sweep_grid(p);
-  hipError_t e = hipSuccess;
-  auto A = [&](void** ptr, size_t bytes) {
-    if (e == hipSuccess) e = hipMalloc(ptr, bytes);
-  };
-  A((void**)&p->tiles, nt * s * BC_TILE * sizeof(double));
-  A((void**)&p->norms, nt * BC_TILE * sizeof(double));
-  A((void**)&p->colsum, (size_t)s * sizeof(double));
-  A((void**)&p->tile_part, nt * s * sizeof(double));
-  A((void**)&p->stats, 4 * sizeof(double));
-  p->stat_blocks = (int)(nt < 256 ? nt : 256);
-  A((void**)&p->part2, (size_t)p->stat_blocks * s * sizeof(double));
-  A((void**)&p->nstat, (size_t)p->stat_blocks * 2 * sizeof(double));
-  A((void**)&p->blk_val, (size_t)p->sweep_blocks * sizeof(double));
-  A((void**)&p->blk_idx, (size_t)p->sweep_blocks * sizeof(long long));
-  A((void**)&p->vbuf, (size_t)2 * s * sizeof(double));
-  A((void**)&p->rec, (size_t)(s + BC_REC_HDR) * sizeof(double));
+  if (cap_rows < n_rows) cap_rows = n_rows;
+  p->cap_tiles = (cap_rows + BC_TILE - 1) / BC_TILE;
+  if (p->cap_tiles < 1) p->cap_tiles = 1;
+  // sizes at capacity
+  p->n_rows = p->cap_tiles * BC_TILE;
+  p->ntiles = p->cap_tiles;
+  const int sweep_cap = bc_sweep_grid(p);
+  const int stat_cap = stat_blocks_for(p->cap_tiles);
+  const size_t nt = (size_t)p->cap_tiles;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_tiles = take(nt * s * BC_TILE * sizeof(double));
+  const size_t o_norms = take(nt * BC_TILE * sizeof(double));
+  const size_t o_colsum = take((size_t)s * sizeof(double));
+  const size_t o_tpart = take(nt * s * sizeof(double));
+  const size_t o_stats = take(4 * sizeof(double));
+  const size_t o_part2 = take((size_t)stat_cap * s * sizeof(double));
+  const size_t o_nstat = take((size_t)stat_cap * 2 * sizeof(double));
+  const size_t o_bval = take((size_t)sweep_cap * sizeof(double));
+  const size_t o_bidx = take((size_t)sweep_cap * sizeof(long long));
+  const size_t o_vbuf = take((size_t)2 * s * sizeof(double));
+  const size_t o_rec = take((size_t)(s + BC_REC_HDR) * sizeof(double));
+  hipError_t e = hipMalloc(&p->slab, off);
   if (e != hipSuccess) {
-    bc_phi_destroy(p);
+    delete p;
     return bc_hip_fail(e, "hipMalloc(phi)", __FILE__, __LINE__);
   }
+  char* base = (char*)p->slab;
+  p->tiles = (double*)(base + o_tiles);
+  p->norms = (double*)(base + o_norms);
+  p->colsum = (double*)(base + o_colsum);
+  p->tile_part = (double*)(base + o_tpart);
+  p->stats = (double*)(base + o_stats);
+  p->part2 = (double*)(base + o_part2);
+  p->nstat = (double*)(base + o_nstat);
+  p->blk_val = (double*)(base + o_bval);
+  p->blk_idx = (long long*)(base + o_bidx);
+  p->vbuf = (double*)(base + o_vbuf);
+  p->rec = (double*)(base + o_rec);
+  (void)bc_phi_set_rows(p, n_rows);
+  *out = p;
+  return BC_OK;
+}
+
+extern "C" int bc_phi_create(bc_ctx* ctx, int64_t cap_rows, int32_t s, bc_phi** out) {
+  if (!ctx || !out || cap_rows < 0 || s <= 0) { bc_set_error("bc_phi_create: bad argument"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  bc_phi* p = nullptr;
+  int rc = bc_phi_alloc(ctx, 0, s, 0, &p, cap_rows);
+  if (rc) return rc;
+  BC_HIP(hipMemsetAsync(p->norms, 0, BC_TILE * sizeof(double), ctx->stream));
+  BC_HIP(hipMemsetAsync(p->colsum, 0, (size_t)s * sizeof(double), ctx->stream));
   *out = p;
   return BC_OK;
 }
 
 extern "C" int bc_phi_destroy(bc_phi* p) {
   if (!p) return BC_OK;
-  void* ptrs[] = {p->tiles, p->norms, p->colsum, p->tile_part, p->stats, p->part2, p->nstat, p->blk_val, p->blk_idx, p->vbuf, p->rec};
-  for (void* q : ptrs)
-    if (q) (void)hipFree(q);
+  if (p->slab) (void)hipFree(p->slab);
+  if (p->stage) (void)hipFree(p->stage);
   delete p;
   return BC_OK;
 }
@@ -517,17 +596,21 @@ extern "C" int bc_phi_to_host(bc_phi* p, double* out) {
   if (!p || (!out && p->n_rows)) { bc_set_error("bc_phi_to_host: bad argument"); return BC_INVALID_ARGUMENT; }
   if (p->n_rows == 0) return BC_OK;
   bc_ctx* ctx = p->ctx;
-  double* stage = nullptr;
-  size_t bytes = (size_t)p->n_rows * p->s * sizeof(double);
-  BC_HIP(hipMalloc((void**)&stage, bytes));
+  const size_t need = (size_t)p->n_rows * p->s;
+  if (need > p->stage_cap) {
+    if (p->stage) (void)hipFree(p->stage);
+    p->stage = nullptr;
+    p->stage_cap = 0;
+    const size_t cap = (size_t)p->cap_tiles * BC_TILE * p->s;
+    BC_HIP(hipMalloc((void**)&p->stage, (cap > need ? cap : need) * sizeof(double)));
+    p->stage_cap = cap > need ? cap : need;
+  }
   size_t lds = (size_t)32 * (BC_TILE + 1) * sizeof(double);
   hipLaunchKernelGGL(k_layout_to_rowmajor, dim3((unsigned)p->ntiles), dim3(256), lds, ctx->stream, p->tiles,
-                     (long long)p->n_rows, p->s, stage);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(out, stage, bytes, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(stage);
-  if (e != hipSuccess) return bc_hip_fail(e, "bc_phi_to_host", __FILE__, __LINE__);
+                     (long long)p->n_rows, p->s, p->stage);
+  BC_HIP(hipGetLastError());
+  BC_HIP(hipMemcpyAsync(out, p->stage, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
   return BC_OK;
 }
 

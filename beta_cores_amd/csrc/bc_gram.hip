@@ -171,6 +171,29 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
   out[(size_t)c * dz + r] = acc;
 }
 
+// grow-only device scratch per GPU: the sampler calls weighted_post on <= M coreset rows thousands of
+// times (bcores.py:39 -> sampler -> weighted_post), a hipMalloc/hipFree pair per call would dominate
+struct GramScratch {
+  double* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // partial, partial_y, out, out_y, w
+  size_t cap[5] = {0, 0, 0, 0, 0};
+};
+static GramScratch g_gram[16];
+
+static int gram_buf(bc_ctx* ctx, int which, size_t doubles, double** out) {
+  GramScratch& sc = g_gram[ctx->device & 15];
+  if (doubles > sc.cap[which]) {
+    BC_HIP(hipStreamSynchronize(ctx->stream));
+    if (sc.buf[which]) (void)hipFree(sc.buf[which]);
+    sc.buf[which] = nullptr;
+    sc.cap[which] = 0;
+    const size_t want = doubles + doubles / 2;
+    BC_HIP(hipMalloc((void**)&sc.buf[which], want * sizeof(double)));
+    sc.cap[which] = want;
+  }
+  *out = sc.buf[which];
+  return BC_OK;
+}
+
 template <int BT>
 static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, double* out_dev, double* outy_dev) {
   const int dz = data->dz, d = dz - 1;
@@ -189,9 +212,10 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   if (splits < 1) splits = 1;
   double* partial = nullptr;
   double* partial_y = nullptr;
-  BC_HIP(hipMalloc((void**)&partial, (size_t)splits * ntri * BT * BT * sizeof(double)));
-  hipError_t e = hipMalloc((void**)&partial_y, (size_t)splits * nt * BT * sizeof(double));
-  if (e != hipSuccess) { (void)hipFree(partial); return bc_hip_fail(e, "hipMalloc(gram)", __FILE__, __LINE__); }
+  int rcb = gram_buf(ctx, 0, (size_t)splits * ntri * BT * BT, &partial);
+  if (!rcb) rcb = gram_buf(ctx, 1, (size_t)splits * nt * BT, &partial_y);
+  if (rcb) return rcb;
+  hipError_t e = hipSuccess;
   GramArgs a;
   a.z = data->z;
   a.w = w_dev;
@@ -214,9 +238,6 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
                        out_dev, outy_dev);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(partial);
-  (void)hipFree(partial_y);
   if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
   return rc;
 }
@@ -235,19 +256,15 @@ extern "C" int bc_weighted_gram(bc_ctx* ctx, const bc_data* data, const double* 
   double* w_dev = nullptr;
   double* out_dev = nullptr;
   double* outy_dev = nullptr;
-  hipError_t e = hipMalloc((void**)&out_dev, (size_t)d * d * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&outy_dev, (size_t)d * sizeof(double));
-  if (e == hipSuccess && w) {
-    e = hipMalloc((void**)&w_dev, (size_t)data->n_rows * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpyAsync(w_dev, w, (size_t)data->n_rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  }
-  int rc = BC_OK;
-  if (e == hipSuccess) rc = d > 64 ? run_gram<128>(ctx, data, w_dev, out_dev, outy_dev) : run_gram<64>(ctx, data, w_dev, out_dev, outy_dev);
-  if (e == hipSuccess && !rc) e = hipMemcpy(out_xtwx, out_dev, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && !rc) e = hipMemcpy(out_xtwy, outy_dev, (size_t)d * sizeof(double), hipMemcpyDeviceToHost);
-  if (w_dev) (void)hipFree(w_dev);
-  if (out_dev) (void)hipFree(out_dev);
-  if (outy_dev) (void)hipFree(outy_dev);
-  if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
-  return rc;
+  int rc = gram_buf(ctx, 2, (size_t)d * d, &out_dev);
+  if (!rc) rc = gram_buf(ctx, 3, (size_t)d, &outy_dev);
+  if (!rc && w) rc = gram_buf(ctx, 4, (size_t)data->n_rows, &w_dev);
+  if (rc) return rc;
+  if (w) BC_HIP(hipMemcpyAsync(w_dev, w, (size_t)data->n_rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rc = d > 64 ? run_gram<128>(ctx, data, w_dev, out_dev, outy_dev) : run_gram<64>(ctx, data, w_dev, out_dev, outy_dev);
+  if (rc) return rc;
+  BC_HIP(hipMemcpyAsync(out_xtwx, out_dev, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipMemcpyAsync(out_xtwy, outy_dev, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  return BC_OK;
 }

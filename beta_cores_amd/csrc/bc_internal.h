@@ -47,6 +47,7 @@ struct bc_data {
   int32_t dz = 0;
   double* z = nullptr;           // row-major n_rows x dz
   bool owned = true;
+  int64_t cap_rows = 0;          // allocation size in rows (owned buffers)
 };
 
 struct bc_phi {
@@ -55,6 +56,10 @@ struct bc_phi {
   int32_t s = 0;
   int64_t row_offset = 0;
   int64_t ntiles = 0;
+  int64_t cap_tiles = 0;         // allocation size in tiles (n_rows may change below it)
+  void* slab = nullptr;          // the one device allocation all pointers below point into
+  double* stage = nullptr;       // row-major staging for bc_phi_to_host (lazy)
+  size_t stage_cap = 0;
   double* tiles = nullptr;       // [ntiles][s][128]
   double* norms = nullptr;       // [ntiles*128]
   double* colsum = nullptr;      // [s]   (valid when stats_valid)
@@ -74,7 +79,8 @@ struct bc_phi {
   double* rec = nullptr;         // one candidate record
 };
 
-int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out);
+int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out, int64_t cap_rows = 0);
+int bc_phi_set_rows(bc_phi* phi, int64_t n_rows);   // 0 if n_rows fits the capacity (state updated), 1 otherwise
 int bc_phi_finish_stats(bc_phi* phi);   // tile_part -> colsum, norm stats (device), then host copy
 int bc_sweep_grid(const bc_phi* phi);
 

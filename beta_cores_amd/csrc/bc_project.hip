@@ -676,8 +676,8 @@ static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const doubl
   }
   // output handle: reuse buffers when the shape matches
   bc_phi* phi = *inout;
-  if (phi && (phi->ctx != ctx || phi->n_rows != data->n_rows || phi->s != s_total)) {
-    bc_set_error("bc_project: *inout has a different shape; pass NULL to allocate");
+  if (phi && (phi->ctx != ctx || phi->s != s_total || bc_phi_set_rows(phi, data->n_rows) != 0)) {
+    bc_set_error("bc_project: *inout has a different S or too little row capacity; pass NULL to allocate");
     return BC_INVALID_ARGUMENT;
   }
   bool fresh = false;

@@ -91,6 +91,28 @@ class DeviceData:
         self.shape = (int(n), int(dz))
         self._fin = weakref.finalize(self, N.load().bc_data_destroy, h)
 
+    @classmethod
+    def slot(cls, dz, cap_rows=256, ctx=None):
+        """A re-usable device buffer for small row sets that change every call (coreset points,
+        sub-samples): allocate once, then `update(z)` in place."""
+        self = cls.__new__(cls)
+        self.ctx = ctx or default_context()
+        self.row_offset = 0
+        h = C.c_void_p()
+        N.call('bc_data_create', self.ctx.h, int(cap_rows), int(dz), C.byref(h))
+        self.h = h
+        self.shape = (0, int(dz))
+        self._fin = weakref.finalize(self, N.load().bc_data_destroy, h)
+        return self
+
+    def update(self, z):
+        z = _as_f64(np.atleast_2d(z), 'data')
+        if z.shape[1] != self.shape[1]:
+            raise ValueError('slot holds rows of %d columns, got %d' % (self.shape[1], z.shape[1]))
+        N.call('bc_data_upload', self.h, _ptr(z), int(z.shape[0]))
+        self.shape = (int(z.shape[0]), self.shape[1])
+        return self
+
     def rows(self, local_idx):
         """Rows by LOCAL index, on the host (m x dz)."""
         idx = np.ascontiguousarray(local_idx, dtype=np.int64).ravel()
@@ -141,15 +163,21 @@ class _PhiT:
 class DevicePhi:
     """N x S matrix of row-centred (beta-)log-likelihoods in the tiled HBM layout."""
 
-    def __init__(self, handle, ctx, owner=True):
+    def __init__(self, handle, ctx, owner=True, release=None):
         self.h = handle
         self.ctx = ctx
+        self.refresh()
+        if release is not None:
+            self._fin = weakref.finalize(self, release, handle)      # hand the buffers back to a pool
+        else:
+            self._fin = weakref.finalize(self, N.load().bc_phi_destroy, handle) if owner else None
+
+    def refresh(self):
         n, s, off = C.c_int64(), C.c_int32(), C.c_int64()
-        N.call('bc_phi_shape', handle, C.byref(n), C.byref(s), C.byref(off))
+        N.call('bc_phi_shape', self.h, C.byref(n), C.byref(s), C.byref(off))
         self.shape = (n.value, s.value)
         self.row_offset = off.value
         self.size = n.value * s.value
-        self._fin = weakref.finalize(self, N.load().bc_phi_destroy, handle) if owner else None
 
     # -- construction
     @classmethod

@@ -84,6 +84,11 @@ int bc_ctx_enable_timing(bc_ctx* ctx, int on);
 int bc_data_from_host(bc_ctx* ctx, const double* z_rowmajor, int64_t n_rows, int32_t dz, bc_data** out);
 /* borrow an existing device buffer (row-major n_rows x dz doubles); not freed by destroy */
 int bc_data_from_device(bc_ctx* ctx, const void* z_dev, int64_t n_rows, int32_t dz, bc_data** out);
+/* re-usable slot for SMALL inputs that change every call (the <= M coreset points and the sub-sampled
+ * rows that BetaCoreset / SparseVI project thousands of times, bcores.py:52-54,63-64): create once with a
+ * row capacity, then upload in place (the buffer grows if n_rows exceeds the capacity). */
+int bc_data_create(bc_ctx* ctx, int64_t cap_rows, int32_t dz, bc_data** out);
+int bc_data_upload(bc_data* d, const double* z_rowmajor, int64_t n_rows);
 /* rows by LOCAL index -> m x dz row-major on the host (`pts = data[idcs]`, hilbert.py:33) */
 int bc_data_gather_rows(bc_data* d, const int64_t* local_idx, int64_t m, double* out);
 int bc_data_destroy(bc_data* d);
@@ -93,10 +98,12 @@ int bc_data_destroy(bc_data* d);
  * the solver's A = vecs.T is a view of it).  row_offset = global index of row 0. */
 int bc_phi_from_host(bc_ctx* ctx, const double* phi_rowmajor, int64_t n_rows, int32_t s,
                      int64_t row_offset, bc_phi** out);
+/* an empty Phi with room for cap_rows rows: bc_project re-uses it (*inout) for any n_rows <= cap_rows */
+int bc_phi_create(bc_ctx* ctx, int64_t cap_rows, int32_t s, bc_phi** out);
 /* K1: Phi = f(Z, Theta[, beta]) - rowmean  (projector.py:24-26, :53-55 + the model
  * formula named by `model`).  theta: host, S x D row-major.  If *inout is non-NULL
- * and has the same shape its buffers are reused (BetaCoreset re-projects every
- * gradient call, bcores.py:141-146). Fuses row norms and column sums (K2). */
+ * and has the same S and enough row capacity its buffers are reused (BetaCoreset
+ * re-projects every gradient call, bcores.py:141-146). Fuses row norms and column sums (K2). */
 int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
 int bc_phi_shape(const bc_phi* phi, int64_t* n_rows, int32_t* s, int64_t* row_offset);
