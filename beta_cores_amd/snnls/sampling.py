@@ -1,29 +1,36 @@
+"""Sampling "solvers": the importance / uniform sampling baselines behind the SparseNNLS protocol.
+
+Behaviour of bayesiancoresets/snnls/sampling.py:6-37: draw one row index per iteration from a
+fixed distribution (proportional to the row norms of Phi, or uniform), keep counts, and set
+w = (counts / total) / p.  The draws use the GLOBAL NumPy RNG (`np.random.choice`) so seeded runs
+reproduce the reference's sequence; the monotone-error guard is switched off.  The only O(N S)
+work, the row norms, comes from the device copy of Phi.
+"""
 import numpy as np
 
 from .snnls import SparseNNLS
 
 
-class ImportanceSampling(SparseNNLS):
-    """Norm-proportional importance sampling "solver" (bayesiancoresets/snnls/sampling.py:6-32).
+def _normalised(p):
+    total = p.sum()
+    return p / total if np.any(p > 0) else np.full(p.shape[0], 1. / float(p.shape[0]))
 
-    One device pass for the column norms; draws come from the global NumPy RNG like the
-    reference (`np.random.choice`); weights are count-based and the monotone check is
-    off (sampling.py:16)."""
-    _alg = 'fw'
+
+class ImportanceSampling(SparseNNLS):
+    _alg = 'fw'          # any engine: only its norms, error() and the sparse weight list are used
     _fusable = False
 
     def __init__(self, A, b, **kw):
-        kw.setdefault('allow_zero_rows', True)      # the reference only guards ps > 0 (sampling.py:12-15)
+        kw.setdefault('allow_zero_rows', True)      # zero-norm rows simply get probability 0 (sampling.py:12-15)
         super().__init__(A, b, **kw)
         if self.comm is not None and self.comm.world > 1:
             raise NotImplementedError('sampling solvers draw from a host RNG over all rows: single rank only')
+        self.check_error_monotone = False           # sampling.py:16
         self.cts = np.zeros(self.n_total)
-        self.ps = self._eng.phi.norms()
-        if np.any(self.ps > 0):
-            self.ps /= self.ps.sum()
-        else:
-            self.ps = np.ones(self.n_total) / float(self.n_total)
-        self.check_error_monotone = False
+        self.ps = self._probabilities()
+
+    def _probabilities(self):
+        return _normalised(self._eng.phi.norms())
 
     def reset(self):
         super().reset()
@@ -38,8 +45,5 @@ class ImportanceSampling(SparseNNLS):
 
 
 class UniformSampling(ImportanceSampling):
-    """sampling.py:34-37"""
-
-    def __init__(self, A, b, **kw):
-        super().__init__(A, b, **kw)
-        self.ps = np.ones(self.n_total) / float(self.n_total)
+    def _probabilities(self):
+        return np.full(self.n_total, 1. / float(self.n_total))
