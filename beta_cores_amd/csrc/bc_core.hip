@@ -311,6 +311,7 @@ int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_
   const size_t o_bidx = take((size_t)sweep_cap * sizeof(long long));
   const size_t o_vbuf = take((size_t)2 * s * sizeof(double));
   const size_t o_rec = take((size_t)(s + BC_REC_HDR) * sizeof(double));
+  const size_t o_cnt = take(256);
   hipError_t e = hipMalloc(&p->slab, off);
   if (e != hipSuccess) {
     delete p;
@@ -328,6 +329,13 @@ int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_
   p->blk_idx = (long long*)(base + o_bidx);
   p->vbuf = (double*)(base + o_vbuf);
   p->rec = (double*)(base + o_rec);
+  p->sweep_counter = (unsigned*)(base + o_cnt);
+  e = hipMemsetAsync(p->sweep_counter, 0, 256, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(p->slab);
+    delete p;
+    return bc_hip_fail(e, "hipMemset(phi)", __FILE__, __LINE__);
+  }
   (void)bc_phi_set_rows(p, n_rows);
   *out = p;
   return BC_OK;

@@ -77,6 +77,7 @@ struct bc_phi {
   int sweep_blocks = 0;
   double* vbuf = nullptr;        // [2*s]
   double* rec = nullptr;         // one candidate record
+  unsigned* sweep_counter = nullptr;   // arrival counter of the sweep's last-block reduction (kept at 0 between launches)
 };
 
 int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out, int64_t cap_rows = 0);

@@ -15,6 +15,7 @@
 #include "bc_internal.h"
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 struct bc_sweep_args {
   const double* tiles;
@@ -53,6 +54,39 @@ __device__ __forceinline__ double bc_row_score(double a0, double a1, double nr, 
   } else {
     return a0 / nr / post_div;
   }
+}
+
+// Reduce per-block candidates to the local winner and emit its candidate record (whole block):
+//   rec[0] = score, rec[1] = global index (int64 bits), rec[2] = row norm, rec[3] = 1.0 if valid,
+//   rec[4..4+S) = Phi[row, :]  (the un-normalised column A[:, f])
+__device__ __forceinline__ void bc_emit_record(const double* __restrict__ blk_val, const long long* __restrict__ blk_idx,
+                                               int nblk, const double* __restrict__ tiles,
+                                               const double* __restrict__ norms, int s, long long row_offset,
+                                               bool skip, double* __restrict__ rec, double* sv, long long* si,
+                                               long long* win) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double bv = -INFINITY;
+  long long bi = LLONG_MAX;
+  if (!skip)
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x)
+      if (bc_better(blk_val[i], blk_idx[i], bv, bi)) { bv = blk_val[i]; bi = blk_idx[i]; }
+  bc_wave_argmax(bv, bi);
+  __syncthreads();
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    const bool valid = bi != LLONG_MAX;
+    rec[0] = bv;
+    reinterpret_cast<long long*>(rec)[1] = valid ? bi : -1;
+    rec[2] = valid ? norms[bi - row_offset] : 0.0;
+    rec[3] = valid ? 1.0 : 0.0;
+    *win = valid ? bi - row_offset : -1;
+  }
+  __syncthreads();
+  const long long r = *win;
+  for (int k = threadIdx.x; k < s; k += blockDim.x) rec[BC_REC_HDR + k] = (r >= 0) ? tiles[bc_tile_off(r, k, s)] : 0.0;
 }
 
 template <int MODE>
@@ -134,9 +168,9 @@ __global__ __launch_bounds__(256) void k_sweep(bc_sweep_args a, double* __restri
   }
 }
 
-// Reduce the per-block candidates to the local winner and emit its candidate record:
-//   rec[0] = score, rec[1] = global index (int64 bits), rec[2] = row norm, rec[3] = 1.0 if valid,
-//   rec[4..4+S) = Phi[row, :]  (the un-normalised column A[:, f])
+// (An in-launch "last block reduces" variant of the winner was measured and dropped: the agent-scope
+// release each of the 2048 blocks needs before its arrival costs more than the launch it saves --
+// sweep 156 -> 243 us at 1.25M rows.  profiles/r01_notes.md)
 __global__ __launch_bounds__(256) void k_local_winner(const double* __restrict__ blk_val,
                                                      const long long* __restrict__ blk_idx, int nblk,
                                                      const double* __restrict__ tiles,
@@ -145,29 +179,8 @@ __global__ __launch_bounds__(256) void k_local_winner(const double* __restrict__
   __shared__ double sv[4];
   __shared__ long long si[4];
   __shared__ long long win;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double bv = -INFINITY;
-  long long bi = LLONG_MAX;
   const bool skip = skip_flag != nullptr && *skip_flag != 0;
-  if (!skip)
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x)
-      if (bc_better(blk_val[i], blk_idx[i], bv, bi)) { bv = blk_val[i]; bi = blk_idx[i]; }
-  bc_wave_argmax(bv, bi);
-  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
-    const bool valid = bi != LLONG_MAX;
-    rec[0] = bv;
-    reinterpret_cast<long long*>(rec)[1] = valid ? bi : -1;
-    rec[2] = valid ? norms[bi - row_offset] : 0.0;
-    rec[3] = valid ? 1.0 : 0.0;
-    win = valid ? bi - row_offset : -1;
-  }
-  __syncthreads();
-  const long long r = win;
-  for (int k = threadIdx.x; k < s; k += blockDim.x) rec[BC_REC_HDR + k] = (r >= 0) ? tiles[bc_tile_off(r, k, s)] : 0.0;
+  bc_emit_record(blk_val, blk_idx, nblk, tiles, norms, s, row_offset, skip, rec, sv, si, &win);
 }
 
 // host-side launcher shared by bc_phi_argmax and the solver loop

@@ -14,8 +14,9 @@ __global__ __launch_bounds__(256, 2) void k(const double* __restrict__ theta, co
     for (int s = 0; s < SW; ++s) acc[r][s] = 0.;
   for (int i = threadIdx.x; i < 64 * R * 33; i += 256) xl[i] = xin[i % 1024];
   __syncthreads();
-  const double* th = theta + (w & 1) * SW;     // two sample halves (wave-uniform)
+  const double* th = theta + (w & 1) * SW;     // two sample groups (wave-uniform)
   for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll 2
     for (int d = 0; d < D; ++d) {
       double x[R];
 #pragma unroll
@@ -55,4 +56,4 @@ void run(int bpc) {
   double fl = (double)grid * 256 * R * SW * 2.0 * D * reps;
   printf("R=%d SW=%d blocks/CU=%d: %.3f ms  %.1f TF\n", R, SW, bpc, ms, fl / ms / 1e9);
 }
-int main() { run<4, 25>(1); run<4, 25>(2); run<2, 50>(2); run<2, 32>(2); run<2, 32>(4); run<4, 16>(2); run<4, 16>(4); return 0; }
+int main() { run<4, 25>(2); run<8, 13>(1); run<8, 13>(2); run<8, 12>(2); run<6, 17>(2); return 0; }
