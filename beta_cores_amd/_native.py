@@ -52,6 +52,7 @@ _SIGNATURES = {
     'bc_snnls_create': [vp, vp, vp, C.c_int, C.c_double, C.c_int, vpp],
     'bc_snnls_destroy': [vp],
     'bc_snnls_set_tolerance': [vp, C.c_double],
+    'bc_snnls_prefilter_active': [vp, c_ip],
     'bc_snnls_bind_exchange': [vp, C.c_int, vp, vp],
     'bc_snnls_record_doubles': [vp, c_i32p],
     'bc_snnls_build_begin': [vp, C.c_int],
@@ -79,6 +80,23 @@ EXPORTS = sorted(list(_SIGNATURES) + ['bc_version', 'bc_last_error'])
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  A process must run ONE HIP
+    runtime: if ours resolved to the system copy first, a later `import torch` would find a runtime it was
+    not built against ("no ROCm-capable device is detected").  So when torch is installed, map its copy
+    first -- without importing torch -- and let the loader hand that one to libbeta_cores.so as well."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load the shared library (once).  Raises RuntimeError if it has not been built."""
     global _lib
@@ -88,6 +106,7 @@ def load():
         raise RuntimeError(
             'beta_cores_amd: %s is missing -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
             'or `make -C beta_cores_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)

@@ -1,0 +1,393 @@
+// K3 with an fp32 pre-filter: halves the bytes of the per-iteration sweep while returning EXACTLY
+// the row the fp64 sweep (bc_sweep.hip) would return.
+//
+//   u32[i, :] = fp32( Phi[i, :] / ||Phi[i, :]|| )      built once per solver (4*N*S bytes)
+//
+//   pass A  k_sweep_f32   streams u32 (non-temporal, fp64 accumulation), and for every row computes an
+//                         interval [L_i, U_i] that provably contains the fp64 kernel's score of that row:
+//                         fp32 rounding moves each normalised dot product by at most
+//                         delta = 2^-24 * ||u_i|| * ||v|| (Cauchy-Schwarz), propagated through the score
+//                         formula by the mean-value theorem.  Rows the bound cannot handle (|s1| close to 1,
+//                         NaN) get [-inf, +inf].  Writes U_i (fp32, rounded up) and the block maximum of L_i.
+//   pass B  k_select      Lmax = max_i L_i; every row with U_i >= Lmax is a candidate (the true argmax is
+//                         always among them; typically 1-3 rows plus the rows already in the coreset).
+//   pass C  k_rescore     recomputes the candidates' scores from the fp64 Phi with the same arithmetic
+//                         (same fma chain, same epilogue) as k_sweep, takes the argmax with NumPy's
+//                         tie rule, and emits the candidate record.
+//   If the candidate list overflows, a flag makes the (otherwise no-op) fp64 sweep + winner run instead.
+//
+// Algorithmic traffic per row: 4*S (u32) + 8 (norm) + 4 (U written) + 4 (U read) bytes.
+#include "bc_internal.h"
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+#define BC_PTILE 256   // rows per u32 tile: one sample of a tile = 1 KiB = 64 lanes x float4
+
+struct bc_pref {
+  bc_ctx* ctx = nullptr;
+  bc_phi* phi = nullptr;
+  float* u32 = nullptr;       // [ptiles][S][256]
+  float* ub = nullptr;        // [ptiles*256] upper bounds of the last sweep
+  double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
+  long long* cand = nullptr;  // [cap] candidate LOCAL rows
+  int* ctrl = nullptr;        // [0] candidate count, [1] need-the-full-fp64-sweep flag
+  int cap = 4096;
+  long long ptiles = 0;
+  int grid = 1;
+  void* slab = nullptr;
+};
+
+struct PrefArgs {
+  const float* u32;
+  const double* norms;
+  const double* v;
+  const int* skip_flag;
+  const double* v_norm;      // dot mode: ||v|| lives in the solver state (device); GIGA: null (= 1)
+  float* ub;
+  double* blk_l;
+  long long n_rows, ptiles;
+  double post_div;
+  int s;
+};
+
+typedef float bc_f4 __attribute__((ext_vector_type(4)));
+
+// bound of |fp64-kernel dot - fp32-input dot| for unit ||v||: 2^-24 (input rounding, Cauchy-Schwarz with
+// ||u_i|| <= 1 + 2^-24) plus the two fma chains' rounding (S * 2^-53 each), with margin.
+#define BC_PREF_DELTA 6.2e-8
+
+template <int MODE>
+__device__ __forceinline__ void bc_score_interval(double s0, double s1, double delta, double post_div, double& U, double& L) {
+  if (MODE == 0) {
+    const double a = fabs(s1) + delta;
+    const double c = 1. - a * a;
+    if (!(s0 == s0) || !(s1 == s1) || !(c > 1e-6)) {   // NaN, or too close to the validity boundary of giga.py:33
+      U = INFINITY;
+      L = -INFINITY;
+      return;
+    }
+    const double f = s0 / sqrt(1. - s1 * s1);
+    const double rc = 1. / sqrt(c);
+    const double e = delta * (rc + (fabs(s0) + delta) * a * rc * rc * rc) * 1.001 + 1e-13 * (1. + fabs(f));
+    U = f + e;
+    L = f - e;
+  } else {
+    if (!(s0 == s0)) { U = INFINITY; L = -INFINITY; return; }
+    const double f = s0 / post_div;
+    const double e = (delta * 1.001 + 1e-13 * fabs(s0)) / fabs(post_div);
+    U = f + e;
+    L = f - e;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
+  __shared__ double sl[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double best_l = -INFINITY;
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
+  if (!skip) {
+    const int S = a.s;
+    const double delta = (MODE == 0) ? BC_PREF_DELTA : BC_PREF_DELTA * (*a.v_norm);
+    const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.v);
+    const double* __restrict__ v1 = a.v;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < a.ptiles; t += (long long)gridDim.x * 4) {
+      const bc_f4* __restrict__ p = reinterpret_cast<const bc_f4*>(a.u32 + (size_t)t * S * BC_PTILE) + lane;
+      double a0[4] = {0., 0., 0., 0.}, a1[4] = {0., 0., 0., 0.};
+      int k = 0;
+      constexpr int U = 10;
+      for (; k + U <= S; k += U) {
+        bc_f4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + (size_t)(k + u) * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (MODE == 0) {
+            const double2 vv = v2[k + u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const double xd = (double)x[u][j];
+              a0[j] = fma(xd, vv.x, a0[j]);
+              a1[j] = fma(xd, vv.y, a1[j]);
+            }
+          } else {
+            const double vv = v1[k + u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0[j] = fma((double)x[u][j], vv, a0[j]);
+          }
+        }
+      }
+      for (; k < S; ++k) {
+        const bc_f4 x = __builtin_nontemporal_load(p + (size_t)k * 64);
+        if (MODE == 0) {
+          const double2 vv = v2[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double xd = (double)x[j];
+            a0[j] = fma(xd, vv.x, a0[j]);
+            a1[j] = fma(xd, vv.y, a1[j]);
+          }
+        } else {
+          const double vv = v1[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a0[j] = fma((double)x[j], vv, a0[j]);
+        }
+      }
+      const long long r = t * BC_PTILE + 4 * lane;
+      bc_f4 ub;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float uf = -INFINITY;
+        if (r + j < a.n_rows && a.norms[r + j] != 0.) {
+          double Ub, Lb;
+          bc_score_interval<MODE>(a0[j], a1[j], delta, a.post_div, Ub, Lb);
+          uf = __double2float_ru(Ub);
+          best_l = fmax(best_l, Lb);
+        }
+        ub[j] = uf;
+      }
+      *reinterpret_cast<bc_f4*>(a.ub + r) = ub;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) best_l = fmax(best_l, __shfl_down(best_l, d, BC_WAVE));
+  if (lane == 0) sl[wave] = best_l;
+  __syncthreads();
+  if (threadIdx.x == 0) a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+}
+
+// pass B: candidates = rows whose upper bound reaches the best lower bound
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ ub, long long n_rows4, const double* __restrict__ blk_l,
+                                               int nblk, const int* skip_flag, long long* __restrict__ cand,
+                                               int* __restrict__ ctrl, int cap) {
+  __shared__ double sl[4];
+  if (skip_flag != nullptr && *skip_flag != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double lmax = -INFINITY;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) lmax = fmax(lmax, blk_l[i]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
+  if (lane == 0) sl[wave] = lmax;
+  __syncthreads();
+  lmax = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+  const bc_f4* __restrict__ u4 = reinterpret_cast<const bc_f4*>(ub);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows4; i += (long long)gridDim.x * blockDim.x) {
+    const bc_f4 u = u4[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((double)u[j] >= lmax) {          // -inf entries (padding / zero rows) never qualify unless lmax = -inf too
+        if (u[j] == -INFINITY) continue;
+        const int slot = atomicAdd(&ctrl[0], 1);
+        if (slot < cap) cand[slot] = 4 * i + j;
+      }
+  }
+}
+
+struct RescoreArgs {
+  const double* tiles;
+  const double* norms;
+  const double* v;
+  const int* skip_flag;
+  const long long* cand;
+  int* ctrl;
+  double* rec;
+  long long row_offset;
+  double post_div;
+  int s, cap;
+};
+
+// same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
+template <int MODE>
+__device__ __forceinline__ double bc_exact_score(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
+                                                 int S, double nr, double post_div) {
+  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+  double a0 = 0., a1 = 0.;
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = p[(size_t)(k + u) * BC_TILE];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (MODE == 0) {
+        a0 = fma(x[u], v[2 * (k + u)], a0);
+        a1 = fma(x[u], v[2 * (k + u) + 1], a1);
+      } else {
+        a0 = fma(x[u], v[k + u], a0);
+      }
+    }
+  }
+  for (; k < S; ++k) {
+    const double x = p[(size_t)k * BC_TILE];
+    if (MODE == 0) {
+      a0 = fma(x, v[2 * k], a0);
+      a1 = fma(x, v[2 * k + 1], a1);
+    } else {
+      a0 = fma(x, v[k], a0);
+    }
+  }
+  if (MODE == 0) {
+    const double s0 = a0 / nr, s1 = a1 / nr;
+    const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
+    const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
+    return s0 / den;
+  }
+  return a0 / nr / post_div;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rescore(RescoreArgs a) {
+  __shared__ double sv[4];
+  __shared__ long long si[4];
+  __shared__ long long win;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
+  const int count = a.ctrl[0];
+  __syncthreads();
+  if (skip || count > a.cap) {
+    if (threadIdx.x == 0) {
+      a.ctrl[0] = 0;
+      a.ctrl[1] = skip ? 0 : 1;       // overflow: the fp64 sweep + winner that follow do the step instead
+    }
+    return;
+  }
+  double bv = -INFINITY;
+  long long bi = LLONG_MAX;
+  for (int j = threadIdx.x; j < count; j += blockDim.x) {
+    const long long r = a.cand[j];
+    const double sc = bc_exact_score<MODE>(a.tiles, a.v, r, a.s, a.norms[r], a.post_div);
+    const long long gi = a.row_offset + r;
+    if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
+  }
+  bc_wave_argmax(bv, bi);
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    const bool valid = bi != LLONG_MAX;
+    a.rec[0] = bv;
+    reinterpret_cast<long long*>(a.rec)[1] = valid ? bi : -1;
+    a.rec[2] = valid ? a.norms[bi - a.row_offset] : 0.0;
+    a.rec[3] = valid ? 1.0 : 0.0;
+    win = valid ? bi - a.row_offset : -1;
+    a.ctrl[0] = 0;
+    a.ctrl[1] = 0;
+  }
+  __syncthreads();
+  const long long r = win;
+  for (int k = threadIdx.x; k < a.s; k += blockDim.x) a.rec[BC_REC_HDR + k] = (r >= 0) ? a.tiles[bc_tile_off(r, k, a.s)] : 0.0;
+}
+
+// u32 tile builder: one block per 256-row tile, thread = row
+__global__ __launch_bounds__(256) void k_build_u32(const double* __restrict__ tiles, const double* __restrict__ norms,
+                                                  long long n_rows, int S, float* __restrict__ u32) {
+  const long long t = blockIdx.x;
+  const long long r = t * BC_PTILE + threadIdx.x;
+  const bool live = r < n_rows;
+  const double nr = live ? norms[r] : 0.;
+  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+  float* q = u32 + (size_t)t * S * BC_PTILE + threadIdx.x;
+  for (int k = 0; k < S; ++k) {
+    float u = 0.f;
+    if (live && nr != 0.) u = (float)(p[(size_t)k * BC_TILE] / nr);
+    q[(size_t)k * BC_PTILE] = u;
+  }
+}
+
+// ------------------------------------------------------------------ host side
+int bc_pref_create(bc_phi* phi, bc_pref** out) {
+  bc_ctx* ctx = phi->ctx;
+  bc_pref* p = new bc_pref();
+  p->ctx = ctx;
+  p->phi = phi;
+  p->ptiles = (phi->n_rows + BC_PTILE - 1) / BC_PTILE;
+  if (p->ptiles < 1) p->ptiles = 1;
+  long long want = (p->ptiles + 3) / 4, cap = (long long)ctx->n_cu * 8;
+  p->grid = (int)(want < cap ? want : cap);
+  if (p->grid < 1) p->grid = 1;
+  // the fp64 tiles cover ntiles*128 rows; u32 covers ptiles*256 >= that, reads past the fp64 tiles are masked by `live`
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_u = take((size_t)p->ptiles * phi->s * BC_PTILE * sizeof(float));
+  const size_t o_ub = take((size_t)p->ptiles * BC_PTILE * sizeof(float));
+  const size_t o_bl = take((size_t)p->grid * sizeof(double));
+  const size_t o_c = take((size_t)p->cap * sizeof(long long));
+  const size_t o_ctrl = take(256);
+  hipError_t e = hipMalloc(&p->slab, off);
+  if (e != hipSuccess) { delete p; return bc_hip_fail(e, "hipMalloc(prefilter)", __FILE__, __LINE__); }
+  char* base = (char*)p->slab;
+  p->u32 = (float*)(base + o_u);
+  p->ub = (float*)(base + o_ub);
+  p->blk_l = (double*)(base + o_bl);
+  p->cand = (long long*)(base + o_c);
+  p->ctrl = (int*)(base + o_ctrl);
+  e = hipMemsetAsync(p->ctrl, 0, 256, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_build_u32, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                       (long long)phi->n_rows, phi->s, p->u32);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) { (void)hipFree(p->slab); delete p; return bc_hip_fail(e, "prefilter build", __FILE__, __LINE__); }
+  *out = p;
+  return BC_OK;
+}
+
+void bc_pref_destroy(bc_pref* p) {
+  if (!p) return;
+  if (p->slab) (void)hipFree(p->slab);
+  delete p;
+}
+
+const int* bc_pref_fallback_flag(const bc_pref* p) { return p->ctrl + 1; }
+void bc_pref_set_cap(bc_pref* p, int cap) { if (cap >= 1 && cap <= 4096) p->cap = cap; }
+
+// passes A, B, C.  The caller then enqueues the fp64 sweep + winner gated by bc_pref_fallback_flag().
+int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
+                   const int* skip_flag, double* rec_dev) {
+  bc_ctx* ctx = p->ctx;
+  bc_phi* phi = p->phi;
+  PrefArgs a;
+  a.u32 = p->u32;
+  a.norms = phi->norms;
+  a.v = v_dev;
+  a.skip_flag = skip_flag;
+  a.v_norm = v_norm_dev;
+  a.ub = p->ub;
+  a.blk_l = p->blk_l;
+  a.n_rows = phi->n_rows;
+  a.ptiles = p->ptiles;
+  a.post_div = post_div;
+  a.s = phi->s;
+  int rc = bc_timer_begin(ctx, 0);
+  if (rc) return rc;
+  if (mode == 0) hipLaunchKernelGGL(k_sweep_f32<0>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_sweep_f32<1>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+  BC_HIP(hipGetLastError());
+  rc = bc_timer_end(ctx, 0);
+  if (rc) return rc;
+  const long long n4 = p->ptiles * BC_PTILE / 4;
+  int sgrid = (int)((n4 + 255) / 256);
+  if (sgrid > ctx->n_cu * 4) sgrid = ctx->n_cu * 4;
+  if (sgrid < 1) sgrid = 1;
+  hipLaunchKernelGGL(k_select, dim3(sgrid), dim3(256), 0, ctx->stream, p->ub, n4, p->blk_l, p->grid, skip_flag, p->cand,
+                     p->ctrl, p->cap);
+  BC_HIP(hipGetLastError());
+  RescoreArgs r;
+  r.tiles = phi->tiles;
+  r.norms = phi->norms;
+  r.v = v_dev;
+  r.skip_flag = skip_flag;
+  r.cand = p->cand;
+  r.ctrl = p->ctrl;
+  r.rec = rec_dev;
+  r.row_offset = phi->row_offset;
+  r.post_div = post_div;
+  r.s = phi->s;
+  r.cap = p->cap;
+  if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, ctx->stream, r);
+  else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, ctx->stream, r);
+  BC_HIP(hipGetLastError());
+  return BC_OK;
+}

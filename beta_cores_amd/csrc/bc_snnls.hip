@@ -12,10 +12,19 @@
 #include "bc_internal.h"
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
-int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev);
+int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev,
+                    const int* run_flag);
+struct bc_pref;
+int bc_pref_create(bc_phi* phi, bc_pref** out);
+void bc_pref_destroy(bc_pref* p);
+const int* bc_pref_fallback_flag(const bc_pref* p);
+void bc_pref_set_cap(bc_pref* p, int cap);
+int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
+                   const int* skip_flag, double* rec_dev);
 
 struct SnnlsState {
   long long nnz;        // length of the (idx, val) list, selection order; val may be 0
@@ -34,6 +43,7 @@ struct SnnlsState {
   int last_status;      // status of the last step-wise call
   int overflow;         // list capacity exceeded (host bug guard)
   int pad;
+  double v_norm;        // ||v|| of the dot-mode sweep vector (scales the pre-filter's error bound)
 };
 
 struct SnnlsDev {
@@ -77,6 +87,7 @@ struct bc_snnls {
   double* val2 = nullptr;
   double* cols2 = nullptr;
   double* colnorm2 = nullptr;
+  bc_pref* pref = nullptr;         // fp32 pre-filter of the sweep (large shards), see bc_prefilter.hip
   double* cand_send = nullptr;     // this rank's candidate record (S + 4 doubles)
   bool cand_send_owned = true;     // false once the host bound its own exchange buffers
   long long nnz_upper = 0;   // host-side upper bound on the list length
@@ -176,8 +187,17 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       for (int k = threadIdx.x; k < s; k += blockDim.x) P.v[2 * k] = P.v[2 * k] / cn;
     if (threadIdx.x == 0) S.select_fail = fail ? 1 : 0;
   } else {
-    for (int k = threadIdx.x; k < s; k += blockDim.x) P.v[k] = P.b[k] - P.xw[k];
-    if (threadIdx.x == 0) S.select_fail = 0;
+    double vn = 0.0;
+    for (int k = threadIdx.x; k < s; k += blockDim.x) {
+      const double r = P.b[k] - P.xw[k];
+      P.v[k] = r;
+      vn = fma(r, r, vn);
+    }
+    vn = bc_block_sum(vn, red);
+    if (threadIdx.x == 0) {
+      S.select_fail = 0;
+      S.v_norm = sqrt(vn);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) S.skip = S.select_fail | S.reached_limit;
@@ -717,6 +737,8 @@ static int ensure_trace(bc_snnls* h, long long need) {
 extern "C" int bc_snnls_destroy(bc_snnls* h) {
   if (!h) return BC_OK;
   (void)hipStreamSynchronize(h->ctx->stream);
+  bc_pref_destroy(h->pref);
+  h->pref = nullptr;
   free_lists(h);
   void* ptrs[] = {h->d.st, h->d.b, h->d.bn, h->d.xw, h->d.xw_prev, h->d.v, h->d.xf,
                   h->cand_send_owned ? h->cand_send : nullptr, h->d.tr_f, h->d.tr_status, h->d.tr_err};
@@ -804,7 +826,22 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "snnls init", __FILE__, __LINE__); }
+  // fp32 pre-filter: worth its extra launches once the sweep is long enough; BC_PREFILTER=0/1 forces it off/on
+  const char* env = getenv("BC_PREFILTER");
+  const bool want = env ? atoi(env) != 0 : phi->n_rows >= 262144;
+  if (want && phi->n_rows > 0) {
+    rc = bc_pref_create(phi, &h->pref);
+    if (rc) { bc_snnls_destroy(h); return rc; }
+    const char* cap = getenv("BC_PREFILTER_CAP");
+    if (cap) bc_pref_set_cap(h->pref, atoi(cap));
+  }
   *out = h;
+  return BC_OK;
+}
+
+extern "C" int bc_snnls_prefilter_active(const bc_snnls* h, int* on) {
+  if (!h || !on) return BC_INVALID_ARGUMENT;
+  *on = h->pref != nullptr;
   return BC_OK;
 }
 
@@ -846,7 +883,14 @@ static int launch_prep(bc_snnls* h, int reset_retry) {
 }
 
 static int launch_sweep(bc_snnls* h, bool with_record) {
-  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, with_record ? h->cand_send : nullptr);
+  if (h->pref) {
+    // fp32 pre-filter -> candidates -> exact fp64 rescoring into the record; the full fp64 sweep and its
+    // winner follow as no-ops unless the candidate list overflowed
+    int rc = bc_pref_launch(h->pref, mode_of(h), h->d.v, &h->d.st->v_norm, 1.0, &h->d.st->skip, h->cand_send);
+    if (rc) return rc;
+    return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, h->cand_send, bc_pref_fallback_flag(h->pref));
+  }
+  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, with_record ? h->cand_send : nullptr, nullptr);
 }
 
 // ---- fused loop
@@ -863,7 +907,7 @@ extern "C" int bc_snnls_build_begin(bc_snnls* h, int itrs) {
 }
 
 // the finish kernel may take the sweep's block candidates directly when nobody else needs the record
-static bool fuse_winner(const bc_snnls* h) { return h->d.world == 1 && h->cand_send_owned; }
+static bool fuse_winner(const bc_snnls* h) { return h->d.world == 1 && h->cand_send_owned && !h->pref; }
 
 extern "C" int bc_snnls_step_local(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;

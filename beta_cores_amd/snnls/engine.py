@@ -51,6 +51,9 @@ class HipEngine:
         self.h = h
         self._fin = weakref.finalize(self, N.load().bc_snnls_destroy, h)
         N.call('bc_snnls_set_tolerance', h, float(tol))
+        on = C.c_int()
+        N.call('bc_snnls_prefilter_active', h, C.byref(on))
+        self.prefilter = bool(on.value)          # sweeps stream an fp32 mirror of Phi and rescore candidates in fp64
         self.world = 1 if comm is None else comm.world
         # BC_FORCE_EXCHANGE=1 routes a 1-rank group through the collective too (rehearsal of the RCCL path on one GPU)
         self.exchange = self.world > 1 or (comm is not None and os.environ.get('BC_FORCE_EXCHANGE') == '1')

@@ -1,0 +1,147 @@
+"""The fp32 pre-filter of the sweep (bc_prefilter.hip) must change NOTHING: same selected rows (bit-exact
+trace), same weights (bit-identical, they are computed from the fp64 columns), on generic, adversarial
+(exact ties, near ties at 1e-12, rows parallel to the iterate) and degenerate inputs, and when its
+candidate list overflows into the fp64 fallback."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def bc():
+    import beta_cores_amd as bc
+    bc.default_context()
+    return bc
+
+
+class prefilter:
+    def __init__(self, on, cap=None):
+        self.on, self.cap = on, cap
+
+    def __enter__(self):
+        self.old = (os.environ.get('BC_PREFILTER'), os.environ.get('BC_PREFILTER_CAP'))
+        os.environ['BC_PREFILTER'] = '1' if self.on else '0'
+        if self.cap is not None:
+            os.environ['BC_PREFILTER_CAP'] = str(self.cap)
+        else:
+            os.environ.pop('BC_PREFILTER_CAP', None)
+
+    def __exit__(self, *a):
+        for k, v in zip(('BC_PREFILTER', 'BC_PREFILTER_CAP'), self.old):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def run(bc, cls, phi, steps, on, cap=None, stepwise=False):
+    with prefilter(on, cap):
+        s = cls(phi.T, phi.sum(axis=0))
+    assert s._eng.prefilter == on
+    if stepwise:
+        s.build_stepwise(steps)
+        tr = None
+    else:
+        s.build(steps)
+        tr = s._eng.trace()
+    idx, val = s._eng.sparse_weights()
+    return tr, idx, val, s.error()
+
+
+def same(a, b):
+    (tra, ia, va, ea), (trb, ib, vb, eb) = a, b
+    if tra is not None:
+        assert np.array_equal(tra[0], trb[0]) and np.array_equal(tra[1], trb[1]) and np.array_equal(tra[2], trb[2])
+    assert np.array_equal(ia, ib) and np.array_equal(va, vb) and ea == eb
+
+
+def correlated(rng, n, s):
+    base = rng.randn(n, 12).dot(rng.randn(12, s)) + 0.3 * rng.randn(n, s)
+    return base - base.mean(axis=1)[:, None]
+
+
+@pytest.mark.parametrize('alg', ['giga', 'fw', 'omp'])
+@pytest.mark.parametrize('n,s', [(30000, 100), (5000, 37), (257, 8), (1, 5)])
+def test_identical_to_fp64_sweep(bc, alg, n, s):
+    rng = np.random.RandomState(n + s)
+    phi = correlated(rng, n, s)
+    cls = dict(giga=bc.snnls.GIGA, fw=bc.snnls.FrankWolfe, omp=bc.snnls.OrthoPursuit)[alg]
+    steps = min(n, 60 if alg != 'omp' else 20)
+    same(run(bc, cls, phi, steps, True, stepwise=(alg == 'omp')), run(bc, cls, phi, steps, False, stepwise=(alg == 'omp')))
+
+
+@pytest.mark.parametrize('alg', ['giga', 'fw'])
+def test_exact_and_near_ties(bc, alg):
+    """Duplicated rows (exact ties -> lowest index wins) and rows perturbed in the last bits (scores a few
+    ulps apart: far inside the fp32 uncertainty, so only the fp64 rescoring can order them)."""
+    rng = np.random.RandomState(3)
+    n, s = 6000, 64
+    phi = correlated(rng, n, s)
+    for src in rng.choice(n, 40, replace=False):
+        for dst in rng.choice(n, 3, replace=False):
+            phi[dst] = phi[src]                                            # exact duplicates at scattered indices
+        dst = rng.randint(n)
+        phi[dst] = phi[src] * (1. + 1e-15 * rng.randint(-4, 5, size=s))    # near duplicates
+    cls = bc.snnls.GIGA if alg == 'giga' else bc.snnls.FrankWolfe
+    same(run(bc, cls, phi, 80, True), run(bc, cls, phi, 80, False))
+
+
+@pytest.mark.parametrize('cap', [1, 2, 7])
+def test_candidate_overflow_falls_back_to_fp64(bc, cap):
+    rng = np.random.RandomState(4)
+    n, s = 4000, 32
+    phi = correlated(rng, n, s)
+    phi[rng.choice(n, 200, replace=False)] = phi[17]                       # 200 exact copies of one row
+    same(run(bc, bc.snnls.GIGA, phi, 40, True, cap=cap), run(bc, bc.snnls.GIGA, phi, 40, False))
+    same(run(bc, bc.snnls.FrankWolfe, phi, 40, True, cap=cap), run(bc, bc.snnls.FrankWolfe, phi, 40, False))
+
+
+F1 = load_golden('f1_snnls')
+
+
+@pytest.mark.parametrize('case', list(F1['cases']))
+def test_degenerate_designs_identical(bc, case):
+    """bin / colinear / axis-aligned designs: ties, zero-error states, precision-limit retries."""
+    X = F1[case + '_X']
+    steps = min(X.shape[0], 25)
+    for cls in (bc.snnls.GIGA, bc.snnls.FrankWolfe):
+        same(run(bc, cls, X, steps, True), run(bc, cls, X, steps, False))
+
+
+def test_zero_rows_are_masked(bc):
+    rng = np.random.RandomState(6)
+    phi = correlated(rng, 3000, 20)
+    phi[[0, 5, 1000, 2999]] = 0.
+    for on in (True, False):
+        with prefilter(on):
+            s = bc.snnls.GIGA(phi.T, phi.sum(axis=0), allow_zero_rows=True)
+        s.build(30)
+        res = s._eng.sparse_weights(), s._eng.trace()[0]
+        if on:
+            first = res
+    assert np.array_equal(first[0][0], res[0][0]) and np.array_equal(first[0][1], res[0][1]) and np.array_equal(first[1], res[1])
+    assert not set(first[0][0].tolist()) & {0, 5, 1000, 2999}
+
+
+def test_million_rows_identical(bc):
+    import torch
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    n, d, s = 1_000_000, 32, 100
+    Z = torch.randn((n, d + 1), generator=g, dtype=torch.float64, device='cuda')
+    th = np.random.default_rng(1).standard_normal((s, d)) * 0.3
+    data = bc.DeviceData.from_torch(Z)
+    phi = bc.DeviceProjector(lambda k, w, p: th, s, bc.likelihoods.LinearRegression(1.0)).project(data)
+    out = []
+    for on in (True, False):
+        with prefilter(on):
+            sv = bc.snnls.GIGA(phi.T, phi.colsum())
+        assert sv._eng.prefilter == on
+        sv.build(60)
+        out.append((sv._eng.trace(), sv._eng.sparse_weights(), sv.error()))
+    (ta, wa, ea), (tb, wb, eb) = out
+    assert np.array_equal(ta[0], tb[0]) and np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and ea == eb
