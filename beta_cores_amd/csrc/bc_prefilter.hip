@@ -9,14 +9,14 @@
 //                         delta = 2^-24 * ||u_i|| * ||v|| (Cauchy-Schwarz), propagated through the score
 //                         formula by the mean-value theorem.  Rows the bound cannot handle (|s1| close to 1,
 //                         NaN) get [-inf, +inf].  Writes U_i (fp32, rounded up) and the block maximum of L_i.
-//   pass B  k_select      Lmax = max_i L_i; every row with U_i >= Lmax is a candidate (the true argmax is
-//                         always among them; typically 1-3 rows plus the rows already in the coreset).
-//   pass C  k_rescore     recomputes the candidates' scores from the fp64 Phi with the same arithmetic
-//                         (same fma chain, same epilogue) as k_sweep, takes the argmax with NumPy's
-//                         tie rule, and emits the candidate record.
+//   pass B  k_rescore     (one block) Lmax = max_i L_i; every row with U_i >= Lmax is a candidate -- the true
+//                         argmax is always among them, typically a handful of rows; whole tiles are skipped
+//                         through their maximum U.  The candidates' scores are recomputed from the fp64 Phi
+//                         with the same arithmetic (same fma chain, same epilogue) as k_sweep, the argmax is
+//                         taken with NumPy's tie rule, and the candidate record is emitted.
 //   If the candidate list overflows, a flag makes the (otherwise no-op) fp64 sweep + winner run instead.
 //
-// Algorithmic traffic per row: 4*S (u32) + 8 (norm) + 4 (U written) + 4 (U read) bytes.
+// Algorithmic traffic per row: 4*S (u32) + 8 (norm) + 4 (U written) bytes.
 #include "bc_internal.h"
 #include <climits>
 #include <cmath>
@@ -29,6 +29,7 @@ struct bc_pref {
   bc_phi* phi = nullptr;
   float* u32 = nullptr;       // [ptiles][S][256]
   float* ub = nullptr;        // [ptiles*256] upper bounds of the last sweep
+  float* tile_u = nullptr;    // [ptiles] per-tile maximum of the upper bounds
   double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
   int* ctrl = nullptr;        // [0] candidate count, [1] need-the-full-fp64-sweep flag
@@ -45,6 +46,7 @@ struct PrefArgs {
   const int* skip_flag;
   const double* v_norm;      // dot mode: ||v|| lives in the solver state (device); GIGA: null (= 1)
   float* ub;
+  float* tile_u;
   double* blk_l;
   long long n_rows, ptiles;
   double post_div;
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
       }
       const long long r = t * BC_PTILE + 4 * lane;
       bc_f4 ub;
+      float tmax = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float uf = -INFINITY;
@@ -146,8 +149,12 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
           best_l = fmax(best_l, Lb);
         }
         ub[j] = uf;
+        tmax = fmaxf(tmax, uf);
       }
       *reinterpret_cast<bc_f4*>(a.ub + r) = ub;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_down(tmax, d, BC_WAVE));
+      if (lane == 0) a.tile_u[t] = tmax;       // lets the selection pass skip whole tiles
     }
   }
 #pragma unroll
@@ -157,44 +164,20 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
   if (threadIdx.x == 0) a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
 }
 
-// pass B: candidates = rows whose upper bound reaches the best lower bound
-__global__ __launch_bounds__(256) void k_select(const float* __restrict__ ub, long long n_rows4, const double* __restrict__ blk_l,
-                                               int nblk, const int* skip_flag, long long* __restrict__ cand,
-                                               int* __restrict__ ctrl, int cap) {
-  __shared__ double sl[4];
-  if (skip_flag != nullptr && *skip_flag != 0) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double lmax = -INFINITY;
-  for (int i = threadIdx.x; i < nblk; i += blockDim.x) lmax = fmax(lmax, blk_l[i]);
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
-  if (lane == 0) sl[wave] = lmax;
-  __syncthreads();
-  lmax = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
-  const bc_f4* __restrict__ u4 = reinterpret_cast<const bc_f4*>(ub);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows4; i += (long long)gridDim.x * blockDim.x) {
-    const bc_f4 u = u4[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if ((double)u[j] >= lmax) {          // -inf entries (padding / zero rows) never qualify unless lmax = -inf too
-        if (u[j] == -INFINITY) continue;
-        const int slot = atomicAdd(&ctrl[0], 1);
-        if (slot < cap) cand[slot] = 4 * i + j;
-      }
-  }
-}
-
 struct RescoreArgs {
   const double* tiles;
   const double* norms;
   const double* v;
   const int* skip_flag;
-  const long long* cand;
+  const float* ub;
+  const float* tile_u;
+  const double* blk_l;
+  long long* cand;
   int* ctrl;
   double* rec;
-  long long row_offset;
+  long long row_offset, ptiles;
   double post_div;
-  int s, cap;
+  int s, cap, nblk;
 };
 
 // same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
@@ -204,12 +187,12 @@ __device__ __forceinline__ double bc_exact_score(const double* __restrict__ tile
   const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
   double a0 = 0., a1 = 0.;
   int k = 0;
-  for (; k + 8 <= S; k += 8) {
-    double x[8];
+  for (; k + 32 <= S; k += 32) {     // 32 independent loads in flight: this kernel is pure latency
+    double x[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = p[(size_t)(k + u) * BC_TILE];
+    for (int u = 0; u < 32; ++u) x[u] = p[(size_t)(k + u) * BC_TILE];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 32; ++u) {
       if (MODE == 0) {
         a0 = fma(x[u], v[2 * (k + u)], a0);
         a1 = fma(x[u], v[2 * (k + u) + 1], a1);
@@ -236,20 +219,68 @@ __device__ __forceinline__ double bc_exact_score(const double* __restrict__ tile
   return a0 / nr / post_div;
 }
 
+// passes B + C in one single-block launch: Lmax = max of the block lower bounds; candidates = rows whose
+// upper bound reaches it (whole tiles are skipped through their maximum); exact fp64 rescoring; record.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a) {
   __shared__ double sv[4];
   __shared__ long long si[4];
   __shared__ long long win;
+  __shared__ int cnt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
-  const int count = a.ctrl[0];
+  if (skip) {
+    if (threadIdx.x == 0) a.ctrl[1] = 0;
+    return;
+  }
+  double lmax = -INFINITY;
+  for (int i = threadIdx.x; i < a.nblk; i += blockDim.x) lmax = fmax(lmax, a.blk_l[i]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
+  if (lane == 0) sv[wave] = lmax;
+  if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  if (skip || count > a.cap) {
-    if (threadIdx.x == 0) {
-      a.ctrl[0] = 0;
-      a.ctrl[1] = skip ? 0 : 1;       // overflow: the fp64 sweep + winner that follow do the step instead
+  lmax = fmax(fmax(sv[0], sv[1]), fmax(sv[2], sv[3]));
+  __syncthreads();
+  // phase B1: tiles whose maximum upper bound reaches Lmax (per-tile maxima scanned 16 loads at a time:
+  // independent loads in flight, this phase is latency-bound)
+  __shared__ int tcnt;
+  __shared__ int tlist[1024];
+  if (threadIdx.x == 0) tcnt = 0;
+  __syncthreads();
+  for (long long t0 = 0; t0 < a.ptiles; t0 += 16LL * blockDim.x) {
+    float tu[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const long long t = t0 + (long long)u * blockDim.x + threadIdx.x;
+      tu[u] = t < a.ptiles ? a.tile_u[t] : -INFINITY;
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (tu[u] != -INFINITY && (double)tu[u] >= lmax) {
+        const int slot = atomicAdd(&tcnt, 1);
+        if (slot < 1024) tlist[slot] = (int)(t0 + (long long)u * blockDim.x + threadIdx.x);
+      }
+  }
+  __syncthreads();
+  const int ntl = tcnt;
+  if (ntl > 1024) {
+    if (threadIdx.x == 0) a.ctrl[1] = 1;      // too many tiles in play: the fp64 sweep + winner do the step
+    return;
+  }
+  // phase B2: the block scans each such tile together (thread = row: one coalesced 1 KiB load per tile)
+  for (int q = 0; q < ntl; ++q) {
+    const long long t = tlist[q];
+    const float u = a.ub[t * BC_PTILE + threadIdx.x];
+    if (u != -INFINITY && (double)u >= lmax) {
+      const int slot = atomicAdd(&cnt, 1);
+      if (slot < a.cap) a.cand[slot] = t * BC_PTILE + threadIdx.x;
+    }
+  }
+  __syncthreads();
+  const int count = cnt;
+  if (count > a.cap) {
+    if (threadIdx.x == 0) a.ctrl[1] = 1;      // overflow: the fp64 sweep + winner that follow do the step instead
     return;
   }
   double bv = -INFINITY;
@@ -261,6 +292,7 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a) {
     if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
   }
   bc_wave_argmax(bv, bi);
+  __syncthreads();
   if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -272,7 +304,6 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a) {
     a.rec[2] = valid ? a.norms[bi - a.row_offset] : 0.0;
     a.rec[3] = valid ? 1.0 : 0.0;
     win = valid ? bi - a.row_offset : -1;
-    a.ctrl[0] = 0;
     a.ctrl[1] = 0;
   }
   __syncthreads();
@@ -312,6 +343,7 @@ int bc_pref_create(bc_phi* phi, bc_pref** out) {
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_u = take((size_t)p->ptiles * phi->s * BC_PTILE * sizeof(float));
   const size_t o_ub = take((size_t)p->ptiles * BC_PTILE * sizeof(float));
+  const size_t o_tu = take((size_t)p->ptiles * sizeof(float));
   const size_t o_bl = take((size_t)p->grid * sizeof(double));
   const size_t o_c = take((size_t)p->cap * sizeof(long long));
   const size_t o_ctrl = take(256);
@@ -320,6 +352,7 @@ int bc_pref_create(bc_phi* phi, bc_pref** out) {
   char* base = (char*)p->slab;
   p->u32 = (float*)(base + o_u);
   p->ub = (float*)(base + o_ub);
+  p->tile_u = (float*)(base + o_tu);
   p->blk_l = (double*)(base + o_bl);
   p->cand = (long long*)(base + o_c);
   p->ctrl = (int*)(base + o_ctrl);
@@ -355,6 +388,7 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   a.skip_flag = skip_flag;
   a.v_norm = v_norm_dev;
   a.ub = p->ub;
+  a.tile_u = p->tile_u;
   a.blk_l = p->blk_l;
   a.n_rows = phi->n_rows;
   a.ptiles = p->ptiles;
@@ -367,25 +401,23 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   BC_HIP(hipGetLastError());
   rc = bc_timer_end(ctx, 0);
   if (rc) return rc;
-  const long long n4 = p->ptiles * BC_PTILE / 4;
-  int sgrid = (int)((n4 + 255) / 256);
-  if (sgrid > ctx->n_cu * 4) sgrid = ctx->n_cu * 4;
-  if (sgrid < 1) sgrid = 1;
-  hipLaunchKernelGGL(k_select, dim3(sgrid), dim3(256), 0, ctx->stream, p->ub, n4, p->blk_l, p->grid, skip_flag, p->cand,
-                     p->ctrl, p->cap);
-  BC_HIP(hipGetLastError());
   RescoreArgs r;
   r.tiles = phi->tiles;
   r.norms = phi->norms;
   r.v = v_dev;
   r.skip_flag = skip_flag;
+  r.ub = p->ub;
+  r.tile_u = p->tile_u;
+  r.blk_l = p->blk_l;
   r.cand = p->cand;
   r.ctrl = p->ctrl;
   r.rec = rec_dev;
   r.row_offset = phi->row_offset;
+  r.ptiles = p->ptiles;
   r.post_div = post_div;
   r.s = phi->s;
   r.cap = p->cap;
+  r.nblk = p->grid;
   if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, ctx->stream, r);
   else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, ctx->stream, r);
   BC_HIP(hipGetLastError());

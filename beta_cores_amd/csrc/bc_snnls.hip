@@ -828,7 +828,7 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "snnls init", __FILE__, __LINE__); }
   // fp32 pre-filter: worth its extra launches once the sweep is long enough; BC_PREFILTER=0/1 forces it off/on
   const char* env = getenv("BC_PREFILTER");
-  const bool want = env ? atoi(env) != 0 : phi->n_rows >= 262144;
+  const bool want = env ? atoi(env) != 0 : phi->n_rows >= 393216;   // measured break-even ~262k rows at S = 100
   if (want && phi->n_rows > 0) {
     rc = bc_pref_create(phi, &h->pref);
     if (rc) { bc_snnls_destroy(h); return rc; }

@@ -205,15 +205,18 @@ int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, c
   // (a gated fallback launch is a no-op almost always: keep it out of the K3 timer)
   int rc = run_flag ? BC_OK : bc_timer_begin(ctx, 0);
   if (rc) return rc;
+  // a gated launch almost never runs: one block per CU keeps its no-op cost at ~1.5 us (it is slower when it does run)
+  int grid = p->sweep_blocks;
+  if (run_flag && grid > ctx->n_cu) grid = ctx->n_cu;
   if (mode == 0)
-    hipLaunchKernelGGL(k_sweep<0>, dim3(p->sweep_blocks), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
+    hipLaunchKernelGGL(k_sweep<0>, dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
   else
-    hipLaunchKernelGGL(k_sweep<1>, dim3(p->sweep_blocks), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
+    hipLaunchKernelGGL(k_sweep<1>, dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
   BC_HIP(hipGetLastError());
   rc = run_flag ? BC_OK : bc_timer_end(ctx, 0);
   if (rc) return rc;
   if (!rec_dev) return BC_OK;
-  hipLaunchKernelGGL(k_local_winner, dim3(1), dim3(256), 0, ctx->stream, p->blk_val, p->blk_idx, p->sweep_blocks,
+  hipLaunchKernelGGL(k_local_winner, dim3(1), dim3(256), 0, ctx->stream, p->blk_val, p->blk_idx, grid,
                      p->tiles, p->norms, p->s, (long long)p->row_offset, skip_flag, run_flag, rec_dev);
   BC_HIP(hipGetLastError());
   return BC_OK;

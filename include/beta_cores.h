@@ -139,7 +139,7 @@ int bc_phi_argmax(bc_phi* phi, int mode, const double* v, double post_div, int64
 int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int alg, double norm_sum,
                     int allow_zero_rows, bc_snnls** out);
 int bc_snnls_destroy(bc_snnls* h);
-/* 1 if this solver's sweeps run the fp32 pre-filter (bc_prefilter.hip): shards of >= 262144 rows by
+/* 1 if this solver's sweeps run the fp32 pre-filter (bc_prefilter.hip): shards of >= 393216 rows by
  * default, BC_PREFILTER=0/1 in the environment forces it.  Results are identical either way. */
 int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
 /* bayesiancoresets/util/__init__.py:4-7 (TOL, set_tolerance); default 1e-12 */
