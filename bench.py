@@ -210,7 +210,8 @@ def main():
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'Zellner linear regression N=%d D=%d S=%d, %s via HilbertCoreset (BASELINE configs[3])'
                                    % (N, D, S, args.alg.upper()),
-                       'N': N, 'D': D, 'S': S, 'M': total, 'rows_per_gpu': n_local, 'parallelism': 'rows/%d' % world},
+                       'N': N, 'D': D, 'S': S, 'M': total, 'rows_per_gpu': n_local, 'parallelism': 'rows/%d' % world,
+                       'sweep': 'fp32 pre-filter + exact fp64 rescoring (bit-identical selections)' if pref else 'fp64'},
             'roofline': {'kernel': ('k_sweep_f32<%s> (K3 fp32 pre-filter sweep; winners rescored in fp64, selections '
                                     'identical to the fp64 sweep)' if pref else 'k_sweep<%s> (K3 score+argmax)')
                                    % ('GIGA' if args.alg == 'giga' else 'dot'),
