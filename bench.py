@@ -86,13 +86,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    # rehearsal knobs (not used by the driver): all ranks on one GPU + gloo transport lets a 1-GPU box run
+    # the multi-rank code path end to end:  BC_BENCH_DEVICE=0 BC_BENCH_BACKEND=gloo torchrun --nproc-per-node 2 ...
+    if os.environ.get('BC_BENCH_DEVICE') is not None:
+        local_rank = int(os.environ['BC_BENCH_DEVICE'])
+    backend = os.environ.get('BC_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     comm = None
     force_xchg = os.environ.get('BC_FORCE_EXCHANGE') == '1' and 'RANK' in os.environ   # 1-GPU rehearsal of the RCCL path
     if world > 1 or force_xchg:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import beta_cores_amd as bc
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -148,7 +156,7 @@ def main():
     barrier()
     t_proj = (time.perf_counter() - t0) / args.proj_reps
     if world > 1:
-        tt = torch.tensor([t_proj], dtype=torch.float64, device=dev)
+        tt = torch.tensor([t_proj], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_proj = float(tt.item())
     k1_ms, k1_n = ctx.kernel_time(1)
@@ -173,7 +181,7 @@ def main():
     barrier()
     t_steps = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([t_steps], dtype=torch.float64, device=dev)
+        tt = torch.tensor([t_steps], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_steps = float(tt.item())
     k3_ms, k3_n = ctx.kernel_time(0)

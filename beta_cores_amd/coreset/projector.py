@@ -163,6 +163,18 @@ class _DeviceProjectorBase(Projector):
             pass
         return dd, False
 
+    def forget(self, pts=None):
+        """Drop the cached device copy of `pts` (or of everything).  Arrays of >= 4096 rows are uploaded
+        once per projector and assumed unchanged afterwards; call this after editing one in place."""
+        if pts is None:
+            self._data_cache.clear()
+            self._phi_cache.clear()
+            return
+        hit = self._data_cache.pop(id(pts), None)
+        if hit is not None:
+            for key in [k for k in self._phi_cache if k[0] == id(hit[1])]:
+                del self._phi_cache[key]
+
     def _run(self, pts, model_id, params):
         dd, transient = self.device_data(pts)
         theta = self.model.theta_for_device(self.samples)
