@@ -211,24 +211,43 @@ __device__ void dev_pick(const SnnlsDev& P, SnnlsState& S, double* red) {
   __shared__ int src_rec;
   __shared__ long long src_list;
   const int s = P.s;
-  if (threadIdx.x == 0) {
+  {
+    // one record header per thread (independent loads), then a block argmax on (score, global index);
+    // global indices are unique across ranks, so the winning record is identified by its index
+    __shared__ double pv[16];
+    __shared__ long long pi[16];
     double bv = -INFINITY;
     long long bi = LLONG_MAX;
-    int br = -1;
-    for (int r = 0; r < P.world; ++r) {
+    for (int r = threadIdx.x; r < P.world; r += blockDim.x) {
       const double* rec = P.cand_all + (size_t)r * P.rec_len;
-      if (rec[3] == 0.0) continue;
+      const double sc = rec[0], ok = rec[3];
       const long long gi = reinterpret_cast<const long long*>(rec)[1];
-      if (bc_better(rec[0], gi, bv, bi)) { bv = rec[0]; bi = gi; br = r; }
+      if (ok != 0.0 && bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
     }
-    src_rec = br;
-    src_list = -1;
-    S.sel_valid = br >= 0 ? 1 : 0;
-    S.sel_f = br >= 0 ? bi : -1;
-    S.sel_score = bv;
-    S.sel_norm = br >= 0 ? P.cand_all[(size_t)br * P.rec_len + 2] : 0.0;
+    bc_wave_argmax(bv, bi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { pv[wave] = bv; pi[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nwv = (blockDim.x + 63) >> 6;
+      for (int w = 1; w < nwv; ++w)
+        if (bc_better(pv[w], pi[w], bv, bi)) { bv = pv[w]; bi = pi[w]; }
+      S.sel_valid = bi != LLONG_MAX ? 1 : 0;
+      S.sel_f = S.sel_valid ? bi : -1;
+      S.sel_score = bv;
+      src_rec = -1;
+      src_list = -1;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < P.world; r += blockDim.x) {
+      const double* rec = P.cand_all + (size_t)r * P.rec_len;
+      if (S.sel_valid && rec[3] != 0.0 && reinterpret_cast<const long long*>(rec)[1] == S.sel_f) {
+        src_rec = r;
+        S.sel_norm = rec[2];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (ALG == BC_ALG_OMP && S.sel_valid && S.npos > 0) {
     // neg = max over active j of -(An[:,j] . residual)
     __shared__ double nv[16];
