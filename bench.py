@@ -186,11 +186,11 @@ def main():
         t_steps = float(tt.item())
     k3_ms, k3_n = ctx.kernel_time(0)
     k3_ms_per = k3_ms / max(k3_n, 1)
-    pref = bool(alg.snnls._eng.prefilter)
+    pref = int(alg.snnls._eng.prefilter)      # 0, or the storage precision of the streamed mirror (16 / 32)
     if pref:
-        # the sweep streams the fp32 mirror of the normalised Phi (4 B/element) + the norms, and writes one fp32
-        # upper bound per row; candidates are then rescored in fp64 (selections identical to the fp64 sweep)
-        k3_bytes = 4.0 * n_local * S + 8.0 * n_local + 4.0 * n_local
+        # the sweep streams the fp32 / fp16 mirror of the normalised Phi (4 or 2 B/element) + the norms, and writes
+        # one fp32 upper bound per row; candidates are then rescored in fp64 (selections identical to the fp64 sweep)
+        k3_bytes = (pref / 8.0) * n_local * S + 8.0 * n_local + 4.0 * n_local
     else:
         k3_bytes = 8.0 * n_local * S + 8.0 * n_local      # one streaming read of Phi + the norms
     alg._pull()
@@ -206,7 +206,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            key = 'k_sweep_f32' if pref else 'k_sweep'
+            key = 'k_sweep_f%d' % pref if pref else 'k_sweep'
             if tj['config'] == {'N': N, 'D': D, 'S': S, 'n_gpus': world} and args.alg == 'giga' and key in tj:
                 traffic = tj[key]['traffic_bytes_per_launch']
                 traffic_src = 'profiles/r01_pmc_traffic.json: ' + tj[key]['correction']
@@ -219,10 +219,10 @@ def main():
             'config': {'workload': 'Zellner linear regression N=%d D=%d S=%d, %s via HilbertCoreset (BASELINE configs[3])'
                                    % (N, D, S, args.alg.upper()),
                        'N': N, 'D': D, 'S': S, 'M': total, 'rows_per_gpu': n_local, 'parallelism': 'rows/%d' % world,
-                       'sweep': 'fp32 pre-filter + exact fp64 rescoring (bit-identical selections)' if pref else 'fp64'},
-            'roofline': {'kernel': ('k_sweep_f32<%s> (K3 fp32 pre-filter sweep; winners rescored in fp64, selections '
-                                    'identical to the fp64 sweep)' if pref else 'k_sweep<%s> (K3 score+argmax)')
-                                   % ('GIGA' if args.alg == 'giga' else 'dot'),
+                       'sweep': 'fp%d pre-filter + exact fp64 rescoring (bit-identical selections)' % pref if pref else 'fp64'},
+            'roofline': {'kernel': ('k_sweep_f%d<%s> (K3 fp%d pre-filter sweep; winners rescored in fp64, selections '
+                                    'identical to the fp64 sweep)' % (pref, 'GIGA' if args.alg == 'giga' else 'dot', pref)
+                                    if pref else 'k_sweep<%s> (K3 score+argmax)' % ('GIGA' if args.alg == 'giga' else 'dot')),
                          'fp64_formulation_bytes_per_launch': 8.0 * n_local * S + 8.0 * n_local,
                          'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,

@@ -17,9 +17,15 @@
 //   If the candidate list overflows, a flag makes the (otherwise no-op) fp64 sweep + winner run instead.
 //
 // Algorithmic traffic per row: 4*S (u32) + 8 (norm) + 4 (U written) bytes.
+//
+// The fp16 variant (k_sweep_f16, BC_PREFILTER=16) stores the unit rows as IEEE half and accumulates in fp32
+// (v_fma_mix_f32: the half->float extension is part of the fma).  Its delta is larger (2^-11 input rounding
+// + the fp32 chain, see bc_pref_delta16) so a few more rows reach the exact rescoring, but the streamed bytes
+// halve again: 2*S + 12 per row.  The selection is still provably the fp64 sweep's.
 #include "bc_internal.h"
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #define BC_PTILE 256   // rows per u32 tile: one sample of a tile = 1 KiB = 64 lanes x float4
@@ -27,7 +33,11 @@
 struct bc_pref {
   bc_ctx* ctx = nullptr;
   bc_phi* phi = nullptr;
-  float* u32 = nullptr;       // [ptiles][S][256]
+  float* u32 = nullptr;       // fp32: [ptiles][S][256]
+  _Float16* u16 = nullptr;    // fp16: [ptiles][SP][512]
+  int prec = 32;              // 32 or 16
+  int ptile = BC_PTILE;       // rows per pre-filter tile (256 for fp32, 512 for fp16)
+  int sp = 0;                 // fp16: planes stored per tile
   float* ub = nullptr;        // [ptiles*256] upper bounds of the last sweep
   float* tile_u = nullptr;    // [ptiles] per-tile maximum of the upper bounds
   double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
@@ -41,6 +51,9 @@ struct bc_pref {
 
 struct PrefArgs {
   const float* u32;
+  const _Float16* u16;
+  double delta;              // per-dot-product bound for unit ||v||
+  int sp;                    // fp16: stored planes per tile (S padded to a multiple of BC_HU)
   const double* norms;
   const double* v;
   const int* skip_flag;
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
   if (!skip) {
     const int S = a.s;
-    const double delta = (MODE == 0) ? BC_PREF_DELTA : BC_PREF_DELTA * (*a.v_norm);
+    const double delta = (MODE == 0) ? a.delta : a.delta * (*a.v_norm);
     const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.v);
     const double* __restrict__ v1 = a.v;
     for (long long t = (long long)blockIdx.x * 4 + wave; t < a.ptiles; t += (long long)gridDim.x * 4) {
@@ -164,6 +177,120 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
   if (threadIdx.x == 0) a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
 }
 
+
+// ---- fp16 variant.  Tile = 512 rows, [S][512] halfs: one sample of a tile = 1 KiB = 64 lanes x 8 halfs.
+#define BC_HTILE 512
+typedef _Float16 bc_h8 __attribute__((ext_vector_type(8)));
+
+// bound of |fp64-kernel dot - (fp16 rows, fp32 v, fp32 fma chain) dot| for unit ||v||, ||u|| = 1:
+//   rows:   |u^ - u|_2 <= (2^-11 + 2^-23) (RN to half through float, normal range) + sqrt(S) 2^-25 (subnormal halfs)
+//   v:      2^-24 (RN to float)
+//   chain:  S roundings of 2^-24 relative to sum |u^_i v^_i| <= ||u^|| ||v^||
+// every term taken with margin.
+static double bc_pref_delta16(int S) { return 4.8845e-4 + 3.0e-8 * sqrt((double)S) + 6.1e-8 * (double)(S + 2); }
+
+#define BC_HU 10   // sample planes per batch; the stored plane count is padded to a multiple (zero planes)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sweep_f16(PrefArgs a) {
+  __shared__ double sl[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double best_l = -INFINITY;
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
+  if (!skip) {
+    const int SP = a.sp;
+    const double delta = (MODE == 0) ? a.delta : a.delta * (*a.v_norm);
+    const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.v);
+    const double* __restrict__ v1 = a.v;
+    constexpr int U = BC_HU;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < a.ptiles; t += (long long)gridDim.x * 4) {
+      const bc_h8* __restrict__ p = reinterpret_cast<const bc_h8*>(a.u16 + (size_t)t * SP * BC_HTILE) + lane;
+      float a0[8], a1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a0[j] = a1[j] = 0.f;
+      // register double buffering: the next batch of planes is in flight while this one is consumed
+      bc_h8 x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+      for (int k = 0; k < SP; k += U) {
+        const bool more = k + U < SP;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p + (size_t)(k + U + u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int kk = k + u;        // planes S..SP-1 are zero and so is v's tail (BC_V_PAD in bc_snnls.hip)
+          if (MODE == 0) {
+            const double2 vv = v2[kk];
+            const float vx = (float)vv.x, vy = (float)vv.y;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              a0[j] = fmaf((float)x[u][j], vx, a0[j]);
+              a1[j] = fmaf((float)x[u][j], vy, a1[j]);
+            }
+          } else {
+            const float vx = (float)v1[kk];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a0[j] = fmaf((float)x[u][j], vx, a0[j]);
+          }
+        }
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[u] = y[u];
+        }
+      }
+      const long long r = t * BC_HTILE + 8 * lane;
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bc_f4 ub;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = 4 * h + j;
+          float uf = -INFINITY;
+          if (r + q < a.n_rows && a.norms[r + q] != 0.) {
+            double Ub, Lb;
+            bc_score_interval<MODE>((double)a0[q], (double)a1[q], delta, a.post_div, Ub, Lb);
+            uf = __double2float_ru(Ub);
+            best_l = fmax(best_l, Lb);
+          }
+          ub[j] = uf;
+          tmax = fmaxf(tmax, uf);
+        }
+        *reinterpret_cast<bc_f4*>(a.ub + r + 4 * h) = ub;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_down(tmax, d, BC_WAVE));
+      if (lane == 0) a.tile_u[t] = tmax;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) best_l = fmax(best_l, __shfl_down(best_l, d, BC_WAVE));
+  if (lane == 0) sl[wave] = best_l;
+  __syncthreads();
+  if (threadIdx.x == 0) a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+}
+
+// u16 tile builder: one block per 512-row tile, thread = two rows; planes S..SP-1 are zero
+__global__ __launch_bounds__(256) void k_build_u16(const double* __restrict__ tiles, const double* __restrict__ norms,
+                                                  long long n_rows, int S, int SP, _Float16* __restrict__ u16) {
+  const long long t = blockIdx.x;
+  for (int h = 0; h < 2; ++h) {
+    const int i = threadIdx.x + 256 * h;
+    const long long r = t * BC_HTILE + i;
+    const bool live = r < n_rows;
+    const double nr = live ? norms[r] : 0.;
+    const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+    _Float16* q = u16 + (size_t)t * SP * BC_HTILE + i;
+    for (int k = 0; k < SP; ++k) {
+      _Float16 u = (_Float16)0.f;
+      if (k < S && live && nr != 0.) u = (_Float16)(float)(p[(size_t)k * BC_TILE] / nr);
+      q[(size_t)k * BC_HTILE] = u;
+    }
+  }
+}
+
 struct RescoreArgs {
   const double* tiles;
   const double* norms;
@@ -177,7 +304,7 @@ struct RescoreArgs {
   double* rec;
   long long row_offset, ptiles;
   double post_div;
-  int s, cap, nblk;
+  int s, cap, nblk, ptile;
 };
 
 // same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
@@ -271,10 +398,12 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a) {
   // phase B2: the block scans each such tile together (thread = row: one coalesced 1 KiB load per tile)
   for (int q = 0; q < ntl; ++q) {
     const long long t = tlist[q];
-    const float u = a.ub[t * BC_PTILE + threadIdx.x];
-    if (u != -INFINITY && (double)u >= lmax) {
-      const int slot = atomicAdd(&cnt, 1);
-      if (slot < a.cap) a.cand[slot] = t * BC_PTILE + threadIdx.x;
+    for (int i = threadIdx.x; i < a.ptile; i += blockDim.x) {
+      const float u = a.ub[t * a.ptile + i];
+      if (u != -INFINITY && (double)u >= lmax) {
+        const int slot = atomicAdd(&cnt, 1);
+        if (slot < a.cap) a.cand[slot] = t * a.ptile + i;
+      }
     }
   }
   __syncthreads();
@@ -328,21 +457,31 @@ __global__ __launch_bounds__(256) void k_build_u32(const double* __restrict__ ti
 }
 
 // ------------------------------------------------------------------ host side
-int bc_pref_create(bc_phi* phi, bc_pref** out) {
+int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   bc_ctx* ctx = phi->ctx;
   bc_pref* p = new bc_pref();
   p->ctx = ctx;
   p->phi = phi;
-  p->ptiles = (phi->n_rows + BC_PTILE - 1) / BC_PTILE;
+  p->prec = prec == 16 ? 16 : 32;
+  p->ptile = p->prec == 16 ? BC_HTILE : BC_PTILE;
+  p->sp = p->prec == 16 ? (phi->s + BC_HU - 1) / BC_HU * BC_HU : phi->s;
+  p->ptiles = (phi->n_rows + p->ptile - 1) / p->ptile;
   if (p->ptiles < 1) p->ptiles = 1;
-  long long want = (p->ptiles + 3) / 4, cap = (long long)ctx->n_cu * 8;
-  p->grid = (int)(want < cap ? want : cap);
+  // one wave per tile and a grid-stride loop: size the grid so that all its waves are resident at once
+  // (4 per SIMD) and every wave walks the same number of tiles -- a 2x over-subscribed grid left waves with
+  // 2 or 3 tiles each (79% balance at 10M rows)
+  long long wmax = (long long)ctx->n_cu * 16;
+  const char* genv = getenv("BC_PREF_WAVES_PER_CU");
+  if (genv && atoi(genv) > 0) wmax = (long long)ctx->n_cu * atoi(genv);
+  const long long rounds = (p->ptiles + wmax - 1) / wmax;
+  const long long waves = (p->ptiles + rounds - 1) / rounds;
+  p->grid = (int)((waves + 3) / 4);
   if (p->grid < 1) p->grid = 1;
-  // the fp64 tiles cover ntiles*128 rows; u32 covers ptiles*256 >= that, reads past the fp64 tiles are masked by `live`
+  // the fp64 tiles cover ntiles*128 rows; the unit rows cover ptiles*ptile >= that, reads past the fp64 tiles are masked by `live`
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_u = take((size_t)p->ptiles * phi->s * BC_PTILE * sizeof(float));
-  const size_t o_ub = take((size_t)p->ptiles * BC_PTILE * sizeof(float));
+  const size_t o_u = take((size_t)p->ptiles * p->sp * p->ptile * (p->prec == 16 ? sizeof(_Float16) : sizeof(float)));
+  const size_t o_ub = take((size_t)p->ptiles * p->ptile * sizeof(float));
   const size_t o_tu = take((size_t)p->ptiles * sizeof(float));
   const size_t o_bl = take((size_t)p->grid * sizeof(double));
   const size_t o_c = take((size_t)p->cap * sizeof(long long));
@@ -350,7 +489,8 @@ int bc_pref_create(bc_phi* phi, bc_pref** out) {
   hipError_t e = hipMalloc(&p->slab, off);
   if (e != hipSuccess) { delete p; return bc_hip_fail(e, "hipMalloc(prefilter)", __FILE__, __LINE__); }
   char* base = (char*)p->slab;
-  p->u32 = (float*)(base + o_u);
+  p->u32 = p->prec == 32 ? (float*)(base + o_u) : nullptr;
+  p->u16 = p->prec == 16 ? (_Float16*)(base + o_u) : nullptr;
   p->ub = (float*)(base + o_ub);
   p->tile_u = (float*)(base + o_tu);
   p->blk_l = (double*)(base + o_bl);
@@ -358,8 +498,12 @@ int bc_pref_create(bc_phi* phi, bc_pref** out) {
   p->ctrl = (int*)(base + o_ctrl);
   e = hipMemsetAsync(p->ctrl, 0, 256, ctx->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_build_u32, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
-                       (long long)phi->n_rows, phi->s, p->u32);
+    if (p->prec == 16)
+      hipLaunchKernelGGL(k_build_u16, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                         (long long)phi->n_rows, phi->s, p->sp, p->u16);
+    else
+      hipLaunchKernelGGL(k_build_u32, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                         (long long)phi->n_rows, phi->s, p->u32);
     e = hipGetLastError();
   }
   if (e != hipSuccess) { (void)hipFree(p->slab); delete p; return bc_hip_fail(e, "prefilter build", __FILE__, __LINE__); }
@@ -375,6 +519,7 @@ void bc_pref_destroy(bc_pref* p) {
 
 const int* bc_pref_fallback_flag(const bc_pref* p) { return p->ctrl + 1; }
 void bc_pref_set_cap(bc_pref* p, int cap) { if (cap >= 1 && cap <= 4096) p->cap = cap; }
+int bc_pref_precision(const bc_pref* p) { return p->prec; }
 
 // passes A, B, C.  The caller then enqueues the fp64 sweep + winner gated by bc_pref_fallback_flag().
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
@@ -383,6 +528,9 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   bc_phi* phi = p->phi;
   PrefArgs a;
   a.u32 = p->u32;
+  a.u16 = p->u16;
+  a.delta = p->prec == 16 ? bc_pref_delta16(phi->s) : BC_PREF_DELTA;
+  a.sp = p->sp;
   a.norms = phi->norms;
   a.v = v_dev;
   a.skip_flag = skip_flag;
@@ -396,8 +544,13 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   a.s = phi->s;
   int rc = bc_timer_begin(ctx, 0);
   if (rc) return rc;
-  if (mode == 0) hipLaunchKernelGGL(k_sweep_f32<0>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
-  else hipLaunchKernelGGL(k_sweep_f32<1>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+  if (p->prec == 16) {
+    if (mode == 0) hipLaunchKernelGGL(k_sweep_f16<0>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_sweep_f16<1>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL(k_sweep_f32<0>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_sweep_f32<1>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+  }
   BC_HIP(hipGetLastError());
   rc = bc_timer_end(ctx, 0);
   if (rc) return rc;
@@ -418,6 +571,7 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   r.s = phi->s;
   r.cap = p->cap;
   r.nblk = p->grid;
+  r.ptile = p->ptile;
   if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, ctx->stream, r);
   else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, ctx->stream, r);
   BC_HIP(hipGetLastError());

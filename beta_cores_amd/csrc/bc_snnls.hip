@@ -18,8 +18,11 @@
 
 int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev,
                     const int* run_flag);
+#define BC_PREF_DEFAULT_PREC 16
+#define BC_V_PAD 16            // >= BC_HU - 1 (bc_prefilter.hip): doubles of zero padding after the sweep vector(s)
 struct bc_pref;
-int bc_pref_create(bc_phi* phi, bc_pref** out);
+int bc_pref_create(bc_phi* phi, int prec, bc_pref** out);
+int bc_pref_precision(const bc_pref* p);
 void bc_pref_destroy(bc_pref* p);
 const int* bc_pref_fallback_flag(const bc_pref* p);
 void bc_pref_set_cap(bc_pref* p, int cap);
@@ -822,7 +825,8 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   A((void**)&d.bn, s * sizeof(double));
   A((void**)&d.xw, s * sizeof(double));
   A((void**)&d.xw_prev, s * sizeof(double));
-  A((void**)&d.v, 2 * s * sizeof(double));
+  A((void**)&d.v, 2 * (s + BC_V_PAD) * sizeof(double));   // zero tail: the fp16 sweep reads whole plane batches
+  if (e == hipSuccess) e = hipMemsetAsync(d.v, 0, 2 * (s + BC_V_PAD) * sizeof(double), ctx->stream);
   A((void**)&d.xf, s * sizeof(double));
   A((void**)&h->cand_send, d.rec_len * sizeof(double));
   if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "hipMalloc(snnls)", __FILE__, __LINE__); }
@@ -845,11 +849,13 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "snnls init", __FILE__, __LINE__); }
-  // fp32 pre-filter: worth its extra launches once the sweep is long enough; BC_PREFILTER=0/1 forces it off/on
+  // reduced-precision pre-filter: worth its extra launches once the sweep is long enough.
+  // BC_PREFILTER = 0 (off) / 1 (on, default precision) / 16 / 32 (on, that storage precision)
   const char* env = getenv("BC_PREFILTER");
-  const bool want = env ? atoi(env) != 0 : phi->n_rows >= 393216;   // measured break-even ~262k rows at S = 100
+  const int req = env ? atoi(env) : -1;
+  const bool want = env ? req != 0 : phi->n_rows >= 393216;   // measured break-even ~262k rows at S = 100
   if (want && phi->n_rows > 0) {
-    rc = bc_pref_create(phi, &h->pref);
+    rc = bc_pref_create(phi, req == 16 ? 16 : (req == 32 ? 32 : BC_PREF_DEFAULT_PREC), &h->pref);
     if (rc) { bc_snnls_destroy(h); return rc; }
     const char* cap = getenv("BC_PREFILTER_CAP");
     if (cap) bc_pref_set_cap(h->pref, atoi(cap));
@@ -860,7 +866,7 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
 
 extern "C" int bc_snnls_prefilter_active(const bc_snnls* h, int* on) {
   if (!h || !on) return BC_INVALID_ARGUMENT;
-  *on = h->pref != nullptr;
+  *on = h->pref ? bc_pref_precision(h->pref) : 0;   // 0 = off, else the storage precision (16 / 32)
   return BC_OK;
 }
 

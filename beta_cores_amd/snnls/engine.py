@@ -53,7 +53,8 @@ class HipEngine:
         N.call('bc_snnls_set_tolerance', h, float(tol))
         on = C.c_int()
         N.call('bc_snnls_prefilter_active', h, C.byref(on))
-        self.prefilter = bool(on.value)          # sweeps stream an fp32 mirror of Phi and rescore candidates in fp64
+        self.prefilter = int(on.value)           # 0, or the storage precision (16 / 32) of the mirror of Phi the sweeps
+                                                 # stream; candidates are rescored in fp64, selections are unchanged
         self.world = 1 if comm is None else comm.world
         # BC_FORCE_EXCHANGE=1 routes a 1-rank group through the collective too (rehearsal of the RCCL path on one GPU)
         self.exchange = self.world > 1 or (comm is not None and os.environ.get('BC_FORCE_EXCHANGE') == '1')

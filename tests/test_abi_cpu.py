@@ -158,3 +158,25 @@ def test_host_loop_retry_protocol():
     s.build(5)                                                         # returns immediately (snnls.py:32-34)
     s.reset()
     assert not s.reached_numeric_limit
+
+
+def _build_c_consumer(tmp_path):
+    import subprocess
+    exe = str(tmp_path / 'c_abi_smoke')
+    libdir = os.path.join(ROOT, 'beta_cores_amd')
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'c_abi_smoke.c'),
+           '-L', libdir, '-lbeta_cores', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-lm', '-o', exe]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/beta_cores.h compiles as C99 and a pure-C program links against every entry point."""
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'entry points' in out.stdout
+    n = int(out.stdout.split(',')[1].split()[0])
+    assert n == len(header_functions())

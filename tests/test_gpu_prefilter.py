@@ -1,4 +1,4 @@
-"""The fp32 pre-filter of the sweep (bc_prefilter.hip) must change NOTHING: same selected rows (bit-exact
+"""The reduced-precision (fp32 / fp16 storage) pre-filter of the sweep (bc_prefilter.hip) must change NOTHING: same selected rows (bit-exact
 trace), same weights (bit-identical, they are computed from the fp64 columns), on generic, adversarial
 (exact ties, near ties at 1e-12, rows parallel to the iterate) and degenerate inputs, and when its
 candidate list overflows into the fp64 fallback."""
@@ -10,6 +10,11 @@ import pytest
 from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[32, 16])
+def prec(request):
+    return request.param
 
 
 @pytest.fixture(scope='module')
@@ -25,7 +30,7 @@ class prefilter:
 
     def __enter__(self):
         self.old = (os.environ.get('BC_PREFILTER'), os.environ.get('BC_PREFILTER_CAP'))
-        os.environ['BC_PREFILTER'] = '1' if self.on else '0'
+        os.environ['BC_PREFILTER'] = str(int(self.on))        # 0 = off, 16 / 32 = storage precision
         if self.cap is not None:
             os.environ['BC_PREFILTER_CAP'] = str(self.cap)
         else:
@@ -67,16 +72,16 @@ def correlated(rng, n, s):
 
 @pytest.mark.parametrize('alg', ['giga', 'fw', 'omp'])
 @pytest.mark.parametrize('n,s', [(30000, 100), (5000, 37), (257, 8), (1, 5)])
-def test_identical_to_fp64_sweep(bc, alg, n, s):
+def test_identical_to_fp64_sweep(bc, alg, n, s, prec):
     rng = np.random.RandomState(n + s)
     phi = correlated(rng, n, s)
     cls = dict(giga=bc.snnls.GIGA, fw=bc.snnls.FrankWolfe, omp=bc.snnls.OrthoPursuit)[alg]
     steps = min(n, 60 if alg != 'omp' else 20)
-    same(run(bc, cls, phi, steps, True, stepwise=(alg == 'omp')), run(bc, cls, phi, steps, False, stepwise=(alg == 'omp')))
+    same(run(bc, cls, phi, steps, prec, stepwise=(alg == 'omp')), run(bc, cls, phi, steps, 0, stepwise=(alg == 'omp')))
 
 
 @pytest.mark.parametrize('alg', ['giga', 'fw'])
-def test_exact_and_near_ties(bc, alg):
+def test_exact_and_near_ties(bc, alg, prec):
     """Duplicated rows (exact ties -> lowest index wins) and rows perturbed in the last bits (scores a few
     ulps apart: far inside the fp32 uncertainty, so only the fp64 rescoring can order them)."""
     rng = np.random.RandomState(3)
@@ -88,36 +93,36 @@ def test_exact_and_near_ties(bc, alg):
         dst = rng.randint(n)
         phi[dst] = phi[src] * (1. + 1e-15 * rng.randint(-4, 5, size=s))    # near duplicates
     cls = bc.snnls.GIGA if alg == 'giga' else bc.snnls.FrankWolfe
-    same(run(bc, cls, phi, 80, True), run(bc, cls, phi, 80, False))
+    same(run(bc, cls, phi, 80, prec), run(bc, cls, phi, 80, 0))
 
 
 @pytest.mark.parametrize('cap', [1, 2, 7])
-def test_candidate_overflow_falls_back_to_fp64(bc, cap):
+def test_candidate_overflow_falls_back_to_fp64(bc, cap, prec):
     rng = np.random.RandomState(4)
     n, s = 4000, 32
     phi = correlated(rng, n, s)
     phi[rng.choice(n, 200, replace=False)] = phi[17]                       # 200 exact copies of one row
-    same(run(bc, bc.snnls.GIGA, phi, 40, True, cap=cap), run(bc, bc.snnls.GIGA, phi, 40, False))
-    same(run(bc, bc.snnls.FrankWolfe, phi, 40, True, cap=cap), run(bc, bc.snnls.FrankWolfe, phi, 40, False))
+    same(run(bc, bc.snnls.GIGA, phi, 40, prec, cap=cap), run(bc, bc.snnls.GIGA, phi, 40, 0))
+    same(run(bc, bc.snnls.FrankWolfe, phi, 40, prec, cap=cap), run(bc, bc.snnls.FrankWolfe, phi, 40, 0))
 
 
 F1 = load_golden('f1_snnls')
 
 
 @pytest.mark.parametrize('case', list(F1['cases']))
-def test_degenerate_designs_identical(bc, case):
+def test_degenerate_designs_identical(bc, case, prec):
     """bin / colinear / axis-aligned designs: ties, zero-error states, precision-limit retries."""
     X = F1[case + '_X']
     steps = min(X.shape[0], 25)
     for cls in (bc.snnls.GIGA, bc.snnls.FrankWolfe):
-        same(run(bc, cls, X, steps, True), run(bc, cls, X, steps, False))
+        same(run(bc, cls, X, steps, prec), run(bc, cls, X, steps, 0))
 
 
-def test_zero_rows_are_masked(bc):
+def test_zero_rows_are_masked(bc, prec):
     rng = np.random.RandomState(6)
     phi = correlated(rng, 3000, 20)
     phi[[0, 5, 1000, 2999]] = 0.
-    for on in (True, False):
+    for on in (prec, 0):
         with prefilter(on):
             s = bc.snnls.GIGA(phi.T, phi.sum(axis=0), allow_zero_rows=True)
         s.build(30)
@@ -126,6 +131,24 @@ def test_zero_rows_are_masked(bc):
             first = res
     assert np.array_equal(first[0][0], res[0][0]) and np.array_equal(first[0][1], res[0][1]) and np.array_equal(first[1], res[1])
     assert not set(first[0][0].tolist()) & {0, 5, 1000, 2999}
+
+
+def test_wide_dynamic_range_rows(bc, prec):
+    """Rows dominated by one coordinate: after normalisation most entries fall into (or below) the fp16
+    subnormal range, which the fp16 bound covers with its absolute term."""
+    rng = np.random.RandomState(8)
+    n, s = 20000, 48
+    phi = rng.randn(n, s) * 10. ** rng.uniform(-9, 0, size=(n, s))
+    phi[np.arange(n), rng.randint(s, size=n)] = rng.choice([-1., 1.], n) * rng.uniform(1, 3, n)
+    for cls in (bc.snnls.GIGA, bc.snnls.FrankWolfe):
+        same(run(bc, cls, phi, 60, prec), run(bc, cls, phi, 60, 0))
+
+
+@pytest.mark.parametrize('s', [300, 1000])
+def test_many_samples(bc, s, prec):
+    rng = np.random.RandomState(s)
+    phi = correlated(rng, 4000, s)
+    same(run(bc, bc.snnls.GIGA, phi, 40, prec), run(bc, bc.snnls.GIGA, phi, 40, 0))
 
 
 def test_million_rows_identical(bc):
@@ -137,11 +160,12 @@ def test_million_rows_identical(bc):
     data = bc.DeviceData.from_torch(Z)
     phi = bc.DeviceProjector(lambda k, w, p: th, s, bc.likelihoods.LinearRegression(1.0)).project(data)
     out = []
-    for on in (True, False):
+    for on in (32, 16, 0):
         with prefilter(on):
             sv = bc.snnls.GIGA(phi.T, phi.colsum())
         assert sv._eng.prefilter == on
         sv.build(60)
         out.append((sv._eng.trace(), sv._eng.sparse_weights(), sv.error()))
-    (ta, wa, ea), (tb, wb, eb) = out
-    assert np.array_equal(ta[0], tb[0]) and np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and ea == eb
+    tb, wb, eb = out[-1]
+    for ta, wa, ea in out[:-1]:
+        assert np.array_equal(ta[0], tb[0]) and np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and ea == eb

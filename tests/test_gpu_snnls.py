@@ -291,3 +291,13 @@ def test_large_active_set_growth(bc):
     np.testing.assert_allclose(val, ref.w[ridx], rtol=1e-5)
     f, st, er = dev._eng.trace()
     np.testing.assert_array_equal(f, [t[0] for t in ref.trace])
+
+
+def test_pure_c_consumer_runs(tmp_path, bc):
+    """A plain-C program (tests/c_abi_smoke.c) drives K1 -> K2 -> fused greedy loop through the C ABI alone."""
+    import subprocess
+    from test_abi_cpu import _build_c_consumer
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe, 'run'], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'coreset of' in out.stdout
