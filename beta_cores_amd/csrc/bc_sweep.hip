@@ -90,11 +90,17 @@ __device__ __forceinline__ void bc_emit_record(const double* __restrict__ blk_va
   for (int k = threadIdx.x; k < s; k += blockDim.x) rec[BC_REC_HDR + k] = (r >= 0) ? tiles[bc_tile_off(r, k, s)] : 0.0;
 }
 
-template <int MODE>
+// FUSED: the last block to arrive also merges the block winners and emits the candidate record.  Only the
+// gated pre-filter fallback uses it (one launch instead of two when -- almost always -- it has nothing to
+// do); with the full-size grid of a regular sweep the per-block release costs more than the launch it saves.
+template <int MODE, bool FUSED>
 __global__ __launch_bounds__(256) void k_sweep(bc_sweep_args a, double* __restrict__ blk_val,
-                                              long long* __restrict__ blk_idx) {
+                                              long long* __restrict__ blk_idx, unsigned* __restrict__ arrivals,
+                                              double* __restrict__ rec) {
   __shared__ double sv[4];
   __shared__ long long si[4];
+  __shared__ long long win;
+  __shared__ int is_last;
   if (a.run_flag != nullptr && *a.run_flag == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double best_v = -INFINITY;
@@ -167,12 +173,24 @@ __global__ __launch_bounds__(256) void k_sweep(bc_sweep_args a, double* __restri
       if (bc_better(sv[w], si[w], best_v, best_i)) { best_v = sv[w]; best_i = si[w]; }
     blk_val[blockIdx.x] = best_v;
     blk_idx[blockIdx.x] = best_i;
+    if (FUSED) {
+      __threadfence();                                   // release this block's candidate (agent scope)
+      const unsigned prev = atomicAdd(arrivals, 1u);
+      is_last = prev == gridDim.x - 1;
+    }
+  }
+  if (FUSED) {
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                                     // acquire the other blocks' candidates
+    if (threadIdx.x == 0) *arrivals = 0;                 // ready for the next launch (stream-ordered)
+    bc_emit_record(blk_val, blk_idx, (int)gridDim.x, a.tiles, a.norms, a.s, a.row_offset, skip, rec, sv, si, &win);
   }
 }
 
-// (An in-launch "last block reduces" variant of the winner was measured and dropped: the agent-scope
-// release each of the 2048 blocks needs before its arrival costs more than the launch it saves --
-// sweep 156 -> 243 us at 1.25M rows.  profiles/r01_notes.md)
+// (For the regular, full-grid sweep the in-launch "last block reduces" form was measured and dropped: the
+// agent-scope release each of the 2048 blocks needs before its arrival costs more than the launch it
+// saves -- sweep 156 -> 243 us at 1.25M rows.  profiles/r01_notes.md)
 __global__ __launch_bounds__(256) void k_local_winner(const double* __restrict__ blk_val,
                                                      const long long* __restrict__ blk_idx, int nblk,
                                                      const double* __restrict__ tiles,
@@ -208,10 +226,18 @@ int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, c
   // a gated launch almost never runs: one block per CU keeps its no-op cost at ~1.5 us (it is slower when it does run)
   int grid = p->sweep_blocks;
   if (run_flag && grid > ctx->n_cu) grid = ctx->n_cu;
+  if (run_flag && rec_dev) {       // gated fallback: sweep + winner + record in one launch
+    if (mode == 0)
+      hipLaunchKernelGGL((k_sweep<0, true>), dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx, p->sweep_counter, rec_dev);
+    else
+      hipLaunchKernelGGL((k_sweep<1, true>), dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx, p->sweep_counter, rec_dev);
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+  }
   if (mode == 0)
-    hipLaunchKernelGGL(k_sweep<0>, dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
+    hipLaunchKernelGGL((k_sweep<0, false>), dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(k_sweep<1>, dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx);
+    hipLaunchKernelGGL((k_sweep<1, false>), dim3(grid), dim3(256), 0, ctx->stream, a, p->blk_val, p->blk_idx, nullptr, nullptr);
   BC_HIP(hipGetLastError());
   rc = run_flag ? BC_OK : bc_timer_end(ctx, 0);
   if (rc) return rc;
