@@ -25,6 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TIMING_STRIDE = 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
 FP64_MFMA_PEAK_TF = 78.6
 CHUNK = 1 << 20                # synthetic data is generated in global chunks of 2^20 rows (= 8192 tiles)
@@ -175,6 +176,9 @@ def main():
     # ---------------- greedy iterations: W untimed, then exactly K timed
     alg.build(args.warmup, total)
     barrier()
+    # the K3 launch time for the roofline comes from HIP events around every TIMING_STRIDE-th sweep of the timed
+    # region: an event pair costs ~11 us of stream time, too much to put around all of them next to a 50 us sweep
+    ctx.enable_timing(TIMING_STRIDE)
     ctx.kernel_time_reset()
     t0 = time.perf_counter()
     alg.snnls.build(args.steps)
@@ -186,6 +190,9 @@ def main():
         t_steps = float(tt.item())
     k3_ms, k3_n = ctx.kernel_time(0)
     k3_ms_per = k3_ms / max(k3_n, 1)
+    eng_ = alg.snnls._eng
+    exchange_kind = ('rccl all-gather issued by the C library (native loop)' if eng_.native_exchange else
+                     'torch.distributed all-gather per step (%s)' % backend if eng_.exchange else 'none (single rank)')
     pref = int(alg.snnls._eng.prefilter)      # 0, or the storage precision of the streamed mirror (16 / 32)
     if pref:
         # the sweep streams the fp32 / fp16 mirror of the normalised Phi (4 or 2 B/element) + the norms, and writes
@@ -219,6 +226,7 @@ def main():
             'config': {'workload': 'Zellner linear regression N=%d D=%d S=%d, %s via HilbertCoreset (BASELINE configs[3])'
                                    % (N, D, S, args.alg.upper()),
                        'N': N, 'D': D, 'S': S, 'M': total, 'rows_per_gpu': n_local, 'parallelism': 'rows/%d' % world,
+                       'exchange': exchange_kind,
                        'sweep': 'fp%d pre-filter + exact fp64 rescoring (bit-identical selections)' % pref if pref else 'fp64'},
             'roofline': {'kernel': ('k_sweep_f%d<%s> (K3 fp%d pre-filter sweep; winners rescored in fp64, selections '
                                     'identical to the fp64 sweep)' % (pref, 'GIGA' if args.alg == 'giga' else 'dot', pref)
@@ -226,7 +234,8 @@ def main():
                          'fp64_formulation_bytes_per_launch': 8.0 * n_local * S + 8.0 * n_local,
                          'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'bytes_per_launch': k3_bytes, 'avg_launch_ms': k3_ms_per, 'launches': k3_n},
+                         'bytes_per_launch': k3_bytes, 'avg_launch_ms': k3_ms_per, 'launches': args.steps,
+                         'launches_timed': k3_n},
             'projection': {'points_dims_per_s': N * D / t_proj, 'ms': 1e3 * t_proj, 'kernel_ms': k1_ms_per,
                            'roofline_hbm': {'achieved': k1_bytes / (k1_ms_per * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                                             'unit': 'GB/s', 'frac': k1_bytes / (k1_ms_per * 1e-3) / 1e9 / HBM_PEAK_GBS,

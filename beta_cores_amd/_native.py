@@ -52,7 +52,16 @@ _SIGNATURES = {
     'bc_snnls_create': [vp, vp, vp, C.c_int, C.c_double, C.c_int, vpp],
     'bc_snnls_destroy': [vp],
     'bc_snnls_set_tolerance': [vp, C.c_double],
+    'bc_comm_load': [C.c_char_p],
+    'bc_comm_unique_id': [vp, C.c_int32],
+    'bc_comm_create': [vp, vp, C.c_int32, C.c_int32, vpp],
+    'bc_comm_destroy': [vp],
+    'bc_comm_info': [vp, c_i32p, c_i32p],
+    'bc_comm_all_gather': [vp, vp, vp, C.c_int64],
+    'bc_comm_selftest': [vp],
+    'bc_snnls_bind_comm': [vp, vp],
     'bc_snnls_prefilter_active': [vp, c_ip],
+    'bc_snnls_prefilter_fallbacks': [vp, C.POINTER(C.c_int64)],
     'bc_snnls_bind_exchange': [vp, C.c_int, vp, vp],
     'bc_snnls_record_doubles': [vp, c_i32p],
     'bc_snnls_build_begin': [vp, C.c_int],

@@ -86,13 +86,15 @@ extern "C" int bc_ctx_sync(bc_ctx* ctx) {
 
 extern "C" int bc_ctx_enable_timing(bc_ctx* ctx, int on) {
   if (!ctx) return BC_INVALID_ARGUMENT;
-  ctx->timing = on != 0;
+  ctx->timing = on < 0 ? 0 : on;
   return BC_OK;
 }
 
 int bc_timer_begin(bc_ctx* ctx, int which) {
   if (!ctx->timing) return BC_OK;
   bc_timer& t = ctx->timers[which];
+  t.armed = (t.seq++ % ctx->timing) == 0;
+  if (!t.armed) return BC_OK;
   if (t.used == t.start.size()) {
     hipEvent_t a, b;
     BC_HIP(hipEventCreate(&a));
@@ -105,8 +107,9 @@ int bc_timer_begin(bc_ctx* ctx, int which) {
 }
 
 int bc_timer_end(bc_ctx* ctx, int which) {
-  if (!ctx->timing) return BC_OK;
   bc_timer& t = ctx->timers[which];
+  if (!ctx->timing || !t.armed) return BC_OK;
+  t.armed = false;
   BC_HIP(hipEventRecord(t.stop[t.used], ctx->stream));
   t.used++;
   t.launches++;
@@ -141,6 +144,7 @@ extern "C" int bc_ctx_kernel_time_reset(bc_ctx* ctx) {
     if (rc) return rc;
     t.acc_ms = 0.0;
     t.launches = 0;
+    t.seq = 0;
   }
   return BC_OK;
 }

@@ -24,14 +24,16 @@ struct bc_timer {
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
   double acc_ms = 0.0;     // folded-in time of already collected events
-  int64_t launches = 0;
+  int64_t launches = 0;    // timed launches
+  int64_t seq = 0;         // all launches seen (timed or not)
+  bool armed = false;      // the launch in progress is being timed
 };
 
 struct bc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  bool timing = false;
+  int timing = 0;                // 0 = off, n >= 1: every n-th launch of each kernel class is timed
   bc_timer timers[3];
   int n_cu = 256;
   double* pinned = nullptr;      // small pinned staging area (host)

@@ -14,7 +14,9 @@
 //                         through their maximum U.  The candidates' scores are recomputed from the fp64 Phi
 //                         with the same arithmetic (same fma chain, same epilogue) as k_sweep, the argmax is
 //                         taken with NumPy's tie rule, and the candidate record is emitted.
-//   If the candidate list overflows, a flag makes the (otherwise no-op) fp64 sweep + winner run instead.
+//   If the candidate list overflows, the same launch falls back to the full fp64 sweep: k_rescore runs with one
+//   block per CU; block 0 does the work above while the others wait for its verdict (they exit at once in the
+//   common case) and, on overflow, all of them sweep the fp64 Phi and block 0 merges their winners.
 //
 // Algorithmic traffic per row: 4*S (u32) + 8 (norm) + 4 (U written) bytes.
 //
@@ -22,9 +24,7 @@
 // (v_fma_mix_f32: the half->float extension is part of the fma).  Its delta is larger (2^-11 input rounding
 // + the fp32 chain, see bc_pref_delta16) so a few more rows reach the exact rescoring, but the streamed bytes
 // halve again: 2*S + 12 per row.  The selection is still provably the fp64 sweep's.
-#include "bc_internal.h"
-#include <climits>
-#include <cmath>
+#include "bc_sweep_dev.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -42,7 +42,10 @@ struct bc_pref {
   float* tile_u = nullptr;    // [ptiles] per-tile maximum of the upper bounds
   double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
-  int* ctrl = nullptr;        // [0] candidate count, [1] need-the-full-fp64-sweep flag
+  int* ctrl = nullptr;        // [1] the last launch fell back to the fp64 sweep, [2] hand-shake timeout, [3] fallbacks so far
+  unsigned* sync = nullptr;   // in-launch hand-shake of k_rescore (verdict, arrivals)
+  unsigned epoch = 0;         // launch sequence number of k_rescore
+  int helpers_grid = 1;       // blocks of k_rescore: block 0 + fallback helpers
   int cap = 4096;
   long long ptiles = 0;
   int grid = 1;
@@ -346,72 +349,143 @@ __device__ __forceinline__ double bc_exact_score(const double* __restrict__ tile
   return a0 / nr / post_div;
 }
 
-// passes B + C in one single-block launch: Lmax = max of the block lower bounds; candidates = rows whose
-// upper bound reaches it (whole tiles are skipped through their maximum); exact fp64 rescoring; record.
+// In-launch hand-shake between block 0 (selection + rescoring) and the helper blocks (fp64 fallback).
+//   sync[0]  verdict of launch `epoch`: 4*epoch + 1 = fall back, 4*epoch + 2 = done, nothing to do
+//   sync[1]  arrivals of the helper blocks after their share of the fallback sweep (reset by block 0)
+// Every wait is bounded, so the grid drains even if the protocol were broken (ctrl[2] records a timeout).
+#define BC_RS_SPIN_LIMIT (1 << 24)
+// polling load: relaxed (an acquire per poll would invalidate caches 255 blocks x every poll and slow
+// block 0 down); the one acquire fence follows once the awaited value has been seen
+__device__ __forceinline__ unsigned bc_ld_poll(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// passes B + C: Lmax = max of the block lower bounds; candidates = rows whose upper bound reaches it (whole
+// tiles are skipped through their maximum); exact fp64 rescoring; record.  Grid = 1 + helpers.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_rescore(RescoreArgs a) {
+__global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw, double* __restrict__ blk_val,
+                                                long long* __restrict__ blk_idx, unsigned* __restrict__ sync,
+                                                unsigned epoch) {
   __shared__ double sv[4];
   __shared__ long long si[4];
   __shared__ long long win;
   __shared__ int cnt;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
-  if (skip) {
-    if (threadIdx.x == 0) a.ctrl[1] = 0;
-    return;
-  }
-  double lmax = -INFINITY;
-  for (int i = threadIdx.x; i < a.nblk; i += blockDim.x) lmax = fmax(lmax, a.blk_l[i]);
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
-  if (lane == 0) sv[wave] = lmax;
-  if (threadIdx.x == 0) cnt = 0;
-  __syncthreads();
-  lmax = fmax(fmax(sv[0], sv[1]), fmax(sv[2], sv[3]));
-  __syncthreads();
-  // phase B1: tiles whose maximum upper bound reaches Lmax (per-tile maxima scanned 16 loads at a time:
-  // independent loads in flight, this phase is latency-bound)
   __shared__ int tcnt;
   __shared__ int tlist[1024];
-  if (threadIdx.x == 0) tcnt = 0;
-  __syncthreads();
-  for (long long t0 = 0; t0 < a.ptiles; t0 += 16LL * blockDim.x) {
-    float tu[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const long long t = t0 + (long long)u * blockDim.x + threadIdx.x;
-      tu[u] = t < a.ptiles ? a.tile_u[t] : -INFINITY;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (tu[u] != -INFINITY && (double)tu[u] >= lmax) {
-        const int slot = atomicAdd(&tcnt, 1);
-        if (slot < 1024) tlist[slot] = (int)(t0 + (long long)u * blockDim.x + threadIdx.x);
+  __shared__ unsigned verdict;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
+
+  if (blockIdx.x != 0) {
+    // ---- helper block: wait for block 0's verdict
+    if (threadIdx.x == 0) {
+      unsigned v = 0;
+      for (int spin = 0; spin < BC_RS_SPIN_LIMIT; ++spin) {
+        v = bc_ld_poll(sync);
+        if ((v >> 2) == epoch) break;
+        __builtin_amdgcn_s_sleep(32);
       }
-  }
-  __syncthreads();
-  const int ntl = tcnt;
-  if (ntl > 1024) {
-    if (threadIdx.x == 0) a.ctrl[1] = 1;      // too many tiles in play: the fp64 sweep + winner do the step
+      verdict = ((v >> 2) == epoch) ? (v & 3u) : 2u;
+      if (verdict == 1u) __threadfence();
+    }
+    __syncthreads();
+    if (verdict != 1u) return;
+    double bv;
+    long long bi;
+    bc_sweep_block<MODE>(sw, blockIdx.x, gridDim.x, false, sv, si, bv, bi);
+    if (threadIdx.x == 0) {
+      blk_val[blockIdx.x] = bv;
+      blk_idx[blockIdx.x] = bi;
+      __threadfence();                         // release the candidate before arriving
+      atomicAdd(sync + 1, 1u);
+    }
     return;
   }
-  // phase B2: the block scans each such tile together (thread = row: one coalesced 1 KiB load per tile)
-  for (int q = 0; q < ntl; ++q) {
-    const long long t = tlist[q];
-    for (int i = threadIdx.x; i < a.ptile; i += blockDim.x) {
-      const float u = a.ub[t * a.ptile + i];
-      if (u != -INFINITY && (double)u >= lmax) {
-        const int slot = atomicAdd(&cnt, 1);
-        if (slot < a.cap) a.cand[slot] = t * a.ptile + i;
+
+  // ---- block 0
+  bool overflow = false;
+  if (!skip) {
+    double lmax = -INFINITY;
+    for (int i = threadIdx.x; i < a.nblk; i += blockDim.x) lmax = fmax(lmax, a.blk_l[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
+    if (lane == 0) sv[wave] = lmax;
+    if (threadIdx.x == 0) { cnt = 0; tcnt = 0; }
+    __syncthreads();
+    lmax = fmax(fmax(sv[0], sv[1]), fmax(sv[2], sv[3]));
+    __syncthreads();
+    // phase B1: tiles whose maximum upper bound reaches Lmax (per-tile maxima scanned 16 loads at a time:
+    // independent loads in flight, this phase is latency-bound)
+    for (long long t0 = 0; t0 < a.ptiles; t0 += 16LL * blockDim.x) {
+      float tu[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const long long t = t0 + (long long)u * blockDim.x + threadIdx.x;
+        tu[u] = t < a.ptiles ? a.tile_u[t] : -INFINITY;
       }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (tu[u] != -INFINITY && (double)tu[u] >= lmax) {
+          const int slot = atomicAdd(&tcnt, 1);
+          if (slot < 1024) tlist[slot] = (int)(t0 + (long long)u * blockDim.x + threadIdx.x);
+        }
+    }
+    __syncthreads();
+    const int ntl = tcnt;
+    overflow = ntl > 1024;                     // too many tiles in play
+    if (!overflow) {
+      // phase B2: the block scans each such tile together (coalesced loads of the tile's upper bounds)
+      for (int q = 0; q < ntl; ++q) {
+        const long long t = tlist[q];
+        for (int i = threadIdx.x; i < a.ptile; i += blockDim.x) {
+          const float u = a.ub[t * a.ptile + i];
+          if (u != -INFINITY && (double)u >= lmax) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < a.cap) a.cand[slot] = t * a.ptile + i;
+          }
+        }
+      }
+      __syncthreads();
+      overflow = cnt > a.cap;
     }
   }
-  __syncthreads();
+  // verdict for the helpers (block-uniform: tcnt / cnt are shared)
+  if (threadIdx.x == 0) {
+    a.ctrl[1] = overflow ? 1 : 0;              // observable: the last launch fell back
+    if (overflow) a.ctrl[3] += 1;              // ... and how often since creation
+    if (gridDim.x > 1) {
+      __threadfence();
+      __hip_atomic_store(sync, 4u * epoch + (overflow ? 1u : 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (skip) return;
+
+  if (overflow) {
+    // ---- full fp64 sweep by the whole grid, block 0 merges
+    double bv;
+    long long bi;
+    bc_sweep_block<MODE>(sw, 0, gridDim.x, false, sv, si, bv, bi);
+    if (threadIdx.x == 0) {
+      blk_val[0] = bv;
+      blk_idx[0] = bi;
+      int ok = 1;
+      if (gridDim.x > 1) {
+        ok = 0;
+        for (int spin = 0; spin < BC_RS_SPIN_LIMIT; ++spin) {
+          if (bc_ld_poll(sync + 1) == gridDim.x - 1) { ok = 1; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        sync[1] = 0;                            // ready for the next launch (stream-ordered)
+      }
+      if (!ok) a.ctrl[2] = 1;
+      __threadfence();
+    }
+    __syncthreads();
+    bc_emit_record(blk_val, blk_idx, (int)gridDim.x, a.tiles, a.norms, a.s, a.row_offset, false, a.rec, sv, si, &win);
+    return;
+  }
+
   const int count = cnt;
-  if (count > a.cap) {
-    if (threadIdx.x == 0) a.ctrl[1] = 1;      // overflow: the fp64 sweep + winner that follow do the step instead
-    return;
-  }
   double bv = -INFINITY;
   long long bi = LLONG_MAX;
   for (int j = threadIdx.x; j < count; j += blockDim.x) {
@@ -433,7 +507,6 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a) {
     a.rec[2] = valid ? a.norms[bi - a.row_offset] : 0.0;
     a.rec[3] = valid ? 1.0 : 0.0;
     win = valid ? bi - a.row_offset : -1;
-    a.ctrl[1] = 0;
   }
   __syncthreads();
   const long long r = win;
@@ -486,6 +559,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const size_t o_bl = take((size_t)p->grid * sizeof(double));
   const size_t o_c = take((size_t)p->cap * sizeof(long long));
   const size_t o_ctrl = take(256);
+  const size_t o_sync = take(256);
   hipError_t e = hipMalloc(&p->slab, off);
   if (e != hipSuccess) { delete p; return bc_hip_fail(e, "hipMalloc(prefilter)", __FILE__, __LINE__); }
   char* base = (char*)p->slab;
@@ -496,7 +570,13 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->blk_l = (double*)(base + o_bl);
   p->cand = (long long*)(base + o_c);
   p->ctrl = (int*)(base + o_ctrl);
-  e = hipMemsetAsync(p->ctrl, 0, 256, ctx->stream);
+  p->sync = (unsigned*)(base + o_sync);
+  // helpers: one block per CU, all resident next to block 0; never more than the fp64 block-candidate arrays hold
+  p->helpers_grid = ctx->n_cu < phi->sweep_blocks ? ctx->n_cu : phi->sweep_blocks;
+  { const char* hg = getenv("BC_PREF_HELPERS"); if (hg && atoi(hg) >= 1 && atoi(hg) < p->helpers_grid) p->helpers_grid = atoi(hg); }
+  if ((long long)p->helpers_grid * 4 > phi->ntiles) p->helpers_grid = (int)((phi->ntiles + 3) / 4);
+  if (p->helpers_grid < 1) p->helpers_grid = 1;
+  e = hipMemsetAsync(p->ctrl, 0, 512, ctx->stream);
   if (e == hipSuccess) {
     if (p->prec == 16)
       hipLaunchKernelGGL(k_build_u16, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
@@ -517,11 +597,11 @@ void bc_pref_destroy(bc_pref* p) {
   delete p;
 }
 
-const int* bc_pref_fallback_flag(const bc_pref* p) { return p->ctrl + 1; }
+const int* bc_pref_ctrl(const bc_pref* p) { return p->ctrl; }
 void bc_pref_set_cap(bc_pref* p, int cap) { if (cap >= 1 && cap <= 4096) p->cap = cap; }
 int bc_pref_precision(const bc_pref* p) { return p->prec; }
 
-// passes A, B, C.  The caller then enqueues the fp64 sweep + winner gated by bc_pref_fallback_flag().
+// passes A, B, C (and the in-launch fp64 fallback)
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
                    const int* skip_flag, double* rec_dev) {
   bc_ctx* ctx = p->ctx;
@@ -572,8 +652,21 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   r.cap = p->cap;
   r.nblk = p->grid;
   r.ptile = p->ptile;
-  if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, ctx->stream, r);
-  else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, ctx->stream, r);
+  bc_sweep_args sw;
+  sw.tiles = phi->tiles;
+  sw.norms = phi->norms;
+  sw.v = v_dev;
+  sw.skip_flag = nullptr;
+  sw.n_rows = phi->n_rows;
+  sw.ntiles = phi->ntiles;
+  sw.row_offset = phi->row_offset;
+  sw.post_div = post_div;
+  sw.s = phi->s;
+  p->epoch = (p->epoch + 1) & 0x3fffffffu;
+  if (p->epoch == 0) p->epoch = 1;            // sync[0] starts at 0: epoch 0 would match before any verdict
+  const int g = p->helpers_grid;
+  if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(g), dim3(256), 0, ctx->stream, r, sw, phi->blk_val, phi->blk_idx, p->sync, p->epoch);
+  else hipLaunchKernelGGL(k_rescore<1>, dim3(g), dim3(256), 0, ctx->stream, r, sw, phi->blk_val, phi->blk_idx, p->sync, p->epoch);
   BC_HIP(hipGetLastError());
   return BC_OK;
 }

@@ -16,16 +16,18 @@
 #include <cstring>
 #include <algorithm>
 
-int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev,
-                    const int* run_flag);
+int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev);
 #define BC_PREF_DEFAULT_PREC 16
 #define BC_V_PAD 16            // >= BC_HU - 1 (bc_prefilter.hip): doubles of zero padding after the sweep vector(s)
+struct bc_comm;
+int bc_comm_all_gather_dev(bc_comm* c, const double* send_dev, double* recv_dev, size_t count);
+extern "C" int bc_comm_info(const bc_comm* c, int32_t* rank, int32_t* world);
 struct bc_pref;
 int bc_pref_create(bc_phi* phi, int prec, bc_pref** out);
 int bc_pref_precision(const bc_pref* p);
 void bc_pref_destroy(bc_pref* p);
-const int* bc_pref_fallback_flag(const bc_pref* p);
 void bc_pref_set_cap(bc_pref* p, int cap);
+const int* bc_pref_ctrl(const bc_pref* p);
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
                    const int* skip_flag, double* rec_dev);
 
@@ -93,6 +95,8 @@ struct bc_snnls {
   bc_pref* pref = nullptr;         // fp32 pre-filter of the sweep (large shards), see bc_prefilter.hip
   double* cand_send = nullptr;     // this rank's candidate record (S + 4 doubles)
   bool cand_send_owned = true;     // false once the host bound its own exchange buffers
+  bc_comm* comm = nullptr;         // native RCCL exchange (bc_comm.hip): the loop all-gathers by itself
+  double* cand_all_owned = nullptr;
   long long nnz_upper = 0;   // host-side upper bound on the list length
   long long iter_upper = 0;
 };
@@ -762,7 +766,7 @@ extern "C" int bc_snnls_destroy(bc_snnls* h) {
   bc_pref_destroy(h->pref);
   h->pref = nullptr;
   free_lists(h);
-  void* ptrs[] = {h->d.st, h->d.b, h->d.bn, h->d.xw, h->d.xw_prev, h->d.v, h->d.xf,
+  void* ptrs[] = {h->d.st, h->d.b, h->d.bn, h->d.xw, h->d.xw_prev, h->d.v, h->d.xf, h->cand_all_owned,
                   h->cand_send_owned ? h->cand_send : nullptr, h->d.tr_f, h->d.tr_status, h->d.tr_err};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -870,6 +874,18 @@ extern "C" int bc_snnls_prefilter_active(const bc_snnls* h, int* on) {
   return BC_OK;
 }
 
+extern "C" int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n) {
+  if (!h || !n) return BC_INVALID_ARGUMENT;
+  *n = 0;
+  if (!h->pref) return BC_OK;
+  int ctrl[4] = {0, 0, 0, 0};
+  BC_HIP(hipMemcpyAsync(ctrl, bc_pref_ctrl(h->pref), sizeof(ctrl), hipMemcpyDeviceToHost, h->ctx->stream));
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  if (ctrl[2]) { bc_set_error("pre-filter fallback hand-shake timed out"); return -1; }
+  *n = ctrl[3];
+  return BC_OK;
+}
+
 extern "C" int bc_snnls_set_tolerance(bc_snnls* h, double tol) {
   if (!h) return BC_INVALID_ARGUMENT;
   h->d.tol = tol;
@@ -900,6 +916,27 @@ extern "C" int bc_snnls_bind_exchange(bc_snnls* h, int world, void* cand_send_de
   return BC_OK;
 }
 
+extern "C" int bc_snnls_bind_comm(bc_snnls* h, bc_comm* c) {
+  if (!h || !c) { bc_set_error("bc_snnls_bind_comm: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (!h->cand_send_owned || h->comm) { bc_set_error("bc_snnls_bind_comm: an exchange is already bound"); return BC_INVALID_ARGUMENT; }
+  int32_t rank = 0, world = 1;
+  bc_comm_info(c, &rank, &world);
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  const size_t bytes = (size_t)world * h->d.rec_len * sizeof(double);
+  BC_HIP(hipMalloc((void**)&h->cand_all_owned, bytes));
+  BC_HIP(hipMemsetAsync(h->cand_all_owned, 0, bytes, h->ctx->stream));
+  h->d.cand_all = h->cand_all_owned;
+  h->d.world = world;
+  h->comm = c;
+  return BC_OK;
+}
+
+// the record all-gather between the local sweep and the replicated finish / pick (native exchange only)
+static int exchange(bc_snnls* h) {
+  if (!h->comm) return BC_OK;
+  return bc_comm_all_gather_dev(h->comm, h->cand_send, h->cand_all_owned, (size_t)h->d.rec_len);
+}
+
 static int mode_of(const bc_snnls* h) { return h->alg == BC_ALG_GIGA ? 0 : 1; }
 
 static int launch_prep(bc_snnls* h, int reset_retry) {
@@ -909,13 +946,11 @@ static int launch_prep(bc_snnls* h, int reset_retry) {
 
 static int launch_sweep(bc_snnls* h, bool with_record) {
   if (h->pref) {
-    // fp32 pre-filter -> candidates -> exact fp64 rescoring into the record; the full fp64 sweep and its
-    // winner follow as no-ops unless the candidate list overflowed
-    int rc = bc_pref_launch(h->pref, mode_of(h), h->d.v, &h->d.st->v_norm, 1.0, &h->d.st->skip, h->cand_send);
-    if (rc) return rc;
-    return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, h->cand_send, bc_pref_fallback_flag(h->pref));
+    // reduced-precision pre-filter -> candidates -> exact fp64 rescoring into the record (a candidate
+    // overflow is handled inside the rescoring launch by a full fp64 sweep)
+    return bc_pref_launch(h->pref, mode_of(h), h->d.v, &h->d.st->v_norm, 1.0, &h->d.st->skip, h->cand_send);
   }
-  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, with_record ? h->cand_send : nullptr, nullptr);
+  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, with_record ? h->cand_send : nullptr);
 }
 
 // ---- fused loop
@@ -932,7 +967,7 @@ extern "C" int bc_snnls_build_begin(bc_snnls* h, int itrs) {
 }
 
 // the finish kernel may take the sweep's block candidates directly when nobody else needs the record
-static bool fuse_winner(const bc_snnls* h) { return h->d.world == 1 && h->cand_send_owned && !h->pref; }
+static bool fuse_winner(const bc_snnls* h) { return h->d.world == 1 && h->cand_send_owned && !h->pref && !h->comm; }
 
 extern "C" int bc_snnls_step_local(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
@@ -972,13 +1007,14 @@ extern "C" int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* 
 
 extern "C" int bc_snnls_build(bc_snnls* h, int itrs, int* reached_numeric_limit) {
   if (!h) return BC_INVALID_ARGUMENT;
-  if (h->d.world != 1) {
-    bc_set_error("bc_snnls_build: world > 1 needs the host to all-gather between step_local and step_finish");
+  if (h->d.world != 1 && !h->comm) {
+    bc_set_error("bc_snnls_build: world > 1 without a bound bc_comm: the host must all-gather between step_local and step_finish");
     return BC_INVALID_ARGUMENT;
   }
   int rc = bc_snnls_build_begin(h, itrs);
   for (int i = 0; i < itrs && !rc; ++i) {
     rc = bc_snnls_step_local(h);
+    if (!rc) rc = exchange(h);
     if (!rc) rc = bc_snnls_step_finish(h);
   }
   if (rc) return rc;
@@ -1007,11 +1043,12 @@ extern "C" int bc_snnls_select_pick(bc_snnls* h, int64_t* f) {
 
 extern "C" int bc_snnls_select(bc_snnls* h, int64_t* f) {
   if (!h || !f) return BC_INVALID_ARGUMENT;
-  if (h->d.world != 1) {
-    bc_set_error("bc_snnls_select: world > 1: use select_local / all-gather / select_pick");
+  if (h->d.world != 1 && !h->comm) {
+    bc_set_error("bc_snnls_select: world > 1 without a bound bc_comm: use select_local / all-gather / select_pick");
     return BC_INVALID_ARGUMENT;
   }
   int rc = bc_snnls_select_local(h);
+  if (!rc) rc = exchange(h);
   if (rc) return rc;
   return bc_snnls_select_pick(h, f);
 }

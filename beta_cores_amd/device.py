@@ -47,7 +47,8 @@ class Context:
         N.call('bc_ctx_sync', self.h)
 
     def enable_timing(self, on=True):
-        N.call('bc_ctx_enable_timing', self.h, 1 if on else 0)
+        """on: False/0 = off, True/1 = time every launch of the dominant kernels, n > 1 = every n-th launch."""
+        N.call('bc_ctx_enable_timing', self.h, int(on))
 
     def kernel_time(self, which):
         """(total_ms, launches) of kernel class `which` (0 = K3 sweep, 1 = K1 projection, 2 = K4 gram)."""

@@ -6,10 +6,23 @@ replicated.  The only data-path collective per greedy step is ONE all-gather of 
 (S + 4)-double candidate record per rank (score, global index, row norm, valid flag,
 the un-normalised column), after which every rank runs the identical device finish
 kernel -- so the replicated state stays bit-identical and independent of the world
-size.  torch.distributed is the transport: backend "nccl" (= RCCL over xGMI) gathers
-the device buffers in place; backend "gloo" (CPU tests, or several ranks sharing one
-GPU) stages the record through pinned host tensors.
+size.
+
+Transports of that all-gather, in order of preference:
+  * native  -- backend "nccl": the C library calls RCCL itself on its own stream (bc_comm.hip).  The
+               communicator is bootstrapped here (rank 0's ncclUniqueId broadcast through
+               torch.distributed) and checked with a rank-coded pattern; the whole multi-rank greedy loop
+               then runs inside bc_snnls_build, no Python between steps.  BC_NATIVE_RCCL=0 disables it.
+  * torch   -- backend "nccl": torch.distributed.all_gather_into_tensor on the kernels' stream, one
+               Python round trip per step (fallback if the native bootstrap fails).
+  * staged  -- backend "gloo" (CPU tests, or several ranks sharing one GPU): the record goes through
+               pinned host tensors.
 """
+import ctypes as C
+import os
+import warnings
+import weakref
+
 import numpy as np
 
 
@@ -105,6 +118,66 @@ class ShardComm:
 
     def make_exchange(self, rec_len, ctx):
         return _Exchange(self, rec_len, ctx)
+
+    def native_comm(self, ctx):
+        """bc_comm handle (RCCL communicator owned by the C library) for `ctx`, or None when the native
+        exchange is unavailable (backend is not nccl, BC_NATIVE_RCCL=0, bootstrap or self-test failed)."""
+        if self.backend != 'nccl' or os.environ.get('BC_NATIVE_RCCL', '1') == '0':
+            return None
+        cache = self.__dict__.setdefault('_native', {})
+        key = id(ctx)
+        if key in cache:
+            return cache[key][0]
+        import torch
+        from . import _native as N
+        dev = torch.device('cuda', ctx.device)
+
+        def agreed(flag):
+            # every rank must take the same branch: one rank falling back alone would dead-lock the collectives
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+            return int(t.item()) == 1
+
+        handle, why = None, None
+        uid = (C.c_ubyte * 128)()
+        try:                              # local part: find RCCL, rank 0 draws the communicator id
+            lib = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            N.call('bc_comm_load', lib.encode() if os.path.exists(lib) else None)
+            if self.rank == 0:
+                N.call('bc_comm_unique_id', C.cast(uid, C.c_void_p), 128)
+        except Exception as e:            # noqa: BLE001 -- any failure here means "use the torch transport"
+            why = e
+        if agreed(why is None):
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+            root = self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            self.dist.broadcast(t, src=root, group=self.group)
+            uid = (C.c_ubyte * 128)(*t.cpu().tolist())
+            try:                          # collective part: communicator + wiring check (rank-coded pattern)
+                h = C.c_void_p()
+                N.call('bc_comm_create', ctx.h, C.cast(uid, C.c_void_p), self.rank, self.world, C.byref(h))
+                handle = h
+                N.call('bc_comm_selftest', h)
+            except Exception as e:        # noqa: BLE001
+                why = e
+            if not agreed(why is None):
+                if handle is not None:
+                    N.load().bc_comm_destroy(handle)
+                handle = None
+        if handle is None:
+            warnings.warn('native RCCL exchange unavailable (rank %d: %s); using torch.distributed per step'
+                          % (self.rank, why if why is not None else 'another rank failed'))
+        fin = None
+        if handle is not None:
+            fin = weakref.finalize(self, N.load().bc_comm_destroy, handle)
+            fin.atexit = False            # at interpreter exit the process teardown reclaims it; peers may be gone
+        cache[key] = (handle, fin, ctx)      # keeps ctx alive as long as the communicator
+        return handle
+
+    def close(self):
+        """Destroy the native communicators (call before torch.distributed.destroy_process_group)."""
+        for handle, fin, _ in self.__dict__.pop('_native', {}).values():
+            if fin is not None:
+                fin()
 
     def barrier(self):
         self.dist.barrier(group=self.group)

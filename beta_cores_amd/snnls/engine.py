@@ -58,11 +58,18 @@ class HipEngine:
         self.world = 1 if comm is None else comm.world
         # BC_FORCE_EXCHANGE=1 routes a 1-rank group through the collective too (rehearsal of the RCCL path on one GPU)
         self.exchange = self.world > 1 or (comm is not None and os.environ.get('BC_FORCE_EXCHANGE') == '1')
+        self.native_exchange = False     # the C library all-gathers by itself (RCCL on its stream): no Python per step
         if self.exchange:
-            n = C.c_int32()
-            N.call('bc_snnls_record_doubles', h, C.byref(n))
-            self._xchg = comm.make_exchange(n.value, self.ctx)
-            N.call('bc_snnls_bind_exchange', h, self.world, C.c_void_p(self._xchg.send_ptr), C.c_void_p(self._xchg.all_ptr))
+            nc = comm.native_comm(self.ctx) if hasattr(comm, 'native_comm') else None
+            if nc is not None:
+                N.call('bc_snnls_bind_comm', h, nc)
+                self.native_exchange = True
+                self.exchange = False    # build / select go straight to the fused entry points
+            else:
+                n = C.c_int32()
+                N.call('bc_snnls_record_doubles', h, C.byref(n))
+                self._xchg = comm.make_exchange(n.value, self.ctx)
+                N.call('bc_snnls_bind_exchange', h, self.world, C.c_void_p(self._xchg.send_ptr), C.c_void_p(self._xchg.all_ptr))
 
     # ---- fused loop (snnls.py:31-79 on the device)
     def build_fused(self, itrs):
@@ -136,6 +143,12 @@ class HipEngine:
 
     def set_limit(self, flag):
         N.call('bc_snnls_set_flags', self.h, 1 if flag else 0)
+
+    def prefilter_fallbacks(self):
+        """Sweeps whose pre-filter candidate list overflowed and were redone by the full fp64 sweep (diagnostic)."""
+        n = C.c_int64()
+        N.call('bc_snnls_prefilter_fallbacks', self.h, C.byref(n))
+        return int(n.value)
 
     def trace(self):
         n = C.c_int64()

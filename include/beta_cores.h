@@ -74,10 +74,30 @@ int bc_ctx_destroy(bc_ctx* ctx);
 int bc_ctx_sync(bc_ctx* ctx);
 /* time (ms) spent inside the dominant kernels since the last reset, measured
  * with HIP events on the launch stream; which: 0 = K3 score/argmax sweep,
- * 1 = K1 projection, 2 = K4 XtWX.  launches returns the launch count. */
+ * 1 = K1 projection, 2 = K4 XtWX.  launches returns the number of TIMED launches.
+ * bc_ctx_enable_timing(ctx, n): 0 = off (default), n >= 1 = time every n-th launch of each class
+ * (an event pair costs ~11 us of stream time on MI355X, which matters next to a 50 us sweep). */
 int bc_ctx_kernel_time(bc_ctx* ctx, int which, double* total_ms, int64_t* launches);
 int bc_ctx_kernel_time_reset(bc_ctx* ctx);
 int bc_ctx_enable_timing(bc_ctx* ctx, int on);
+
+/* ---- native candidate exchange (RCCL on the context's stream) ---------- */
+/* the one data-path collective of the sharded greedy loop is an all-gather of an (S+4)-double
+ * record per rank and step.  With a bc_comm bound to a solver (bc_snnls_bind_comm) the library issues
+ * ncclAllGather itself, so bc_snnls_build / bc_snnls_select run the multi-rank loop without returning to
+ * the host language between steps.  Bootstrap: rank 0 calls bc_comm_unique_id and ships the 128 bytes to
+ * all ranks (any channel), every rank calls bc_comm_create (collective).  RCCL is resolved with dlopen:
+ * bc_comm_load(path) picks a specific library (e.g. the one PyTorch bundles), otherwise "librccl.so". */
+typedef struct bc_comm bc_comm;
+int bc_comm_load(const char* rccl_library_path);
+int bc_comm_unique_id(void* id_out, int32_t capacity /* >= 128 */);
+int bc_comm_create(bc_ctx* ctx, const void* id, int32_t rank, int32_t world, bc_comm** out);
+int bc_comm_destroy(bc_comm* c);
+int bc_comm_info(const bc_comm* c, int32_t* rank, int32_t* world);
+/* all-gather `count` doubles per rank between device buffers, enqueued on the context's stream */
+int bc_comm_all_gather(bc_comm* c, const void* send_dev, void* recv_dev, int64_t count);
+/* collective wiring check: rank-coded pattern gathered and verified element by element */
+int bc_comm_selftest(bc_comm* c);
 
 /* ---- data rows (Z) resident on the device ----------------------------- */
 /* replaces the `data`/`pts` ndarray argument of Projector.project (projector.py:23,51) */
@@ -139,15 +159,23 @@ int bc_phi_argmax(bc_phi* phi, int mode, const double* v, double post_div, int64
 int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int alg, double norm_sum,
                     int allow_zero_rows, bc_snnls** out);
 int bc_snnls_destroy(bc_snnls* h);
-/* 1 if this solver's sweeps run the fp32 pre-filter (bc_prefilter.hip): shards of >= 393216 rows by
- * default, BC_PREFILTER=0/1 in the environment forces it.  Results are identical either way. */
+/* *on = 0, or the storage precision (16 / 32) of the mirror of Phi this solver's sweeps stream through the
+ * reduced-precision pre-filter (bc_prefilter.hip): fp16 for shards of >= 393216 rows by default;
+ * BC_PREFILTER=0 / 16 / 32 in the environment forces it.  Selections and weights are identical either way
+ * (candidates are rescored from the fp64 Phi with the arithmetic of the fp64 sweep). */
 int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
+/* Diagnostic: how many sweeps since creation overflowed the pre-filter's candidate list and were redone,
+ * inside the same launch, by the full fp64 sweep. */
+int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n);
 /* bayesiancoresets/util/__init__.py:4-7 (TOL, set_tolerance); default 1e-12 */
 int bc_snnls_set_tolerance(bc_snnls* h, double tol);
 /* multi-rank: device buffers (world*(S+4) and (S+4) doubles) through which the
  * host all-gathers the per-rank candidate records between step_local and
  * step_finish.  With world == 1 nothing needs binding. */
 int bc_snnls_bind_exchange(bc_snnls* h, int world, void* cand_send_dev, void* cand_all_dev);
+/* native exchange: the solver all-gathers its candidate records through `c` by itself (owns the buffers);
+ * afterwards bc_snnls_build and bc_snnls_select work for world > 1.  Exclusive with bc_snnls_bind_exchange. */
+int bc_snnls_bind_comm(bc_snnls* h, bc_comm* c);
 int bc_snnls_record_doubles(const bc_snnls* h, int32_t* n);
 
 /* fused greedy loop, all on device, no host round trip per iteration

@@ -28,12 +28,15 @@ int main(int argc, char** argv) {
                   (void*)bc_project, (void*)bc_phi_shape, (void*)bc_phi_colsum, (void*)bc_phi_norms, (void*)bc_phi_norm_stats,
                   (void*)bc_phi_to_host, (void*)bc_phi_gather_rows, (void*)bc_phi_matvec, (void*)bc_phi_destroy,
                   (void*)bc_phi_argmax, (void*)bc_snnls_create, (void*)bc_snnls_destroy, (void*)bc_snnls_prefilter_active,
+                  (void*)bc_snnls_prefilter_fallbacks,
                   (void*)bc_snnls_set_tolerance, (void*)bc_snnls_bind_exchange, (void*)bc_snnls_record_doubles,
                   (void*)bc_snnls_build_begin, (void*)bc_snnls_step_local, (void*)bc_snnls_step_finish, (void*)bc_snnls_build_end,
                   (void*)bc_snnls_build, (void*)bc_snnls_select, (void*)bc_snnls_select_local, (void*)bc_snnls_select_pick,
                   (void*)bc_snnls_reweight, (void*)bc_snnls_error, (void*)bc_snnls_size, (void*)bc_snnls_weights,
                   (void*)bc_snnls_set_weights, (void*)bc_snnls_columns, (void*)bc_snnls_reset, (void*)bc_snnls_get_flags,
-                  (void*)bc_snnls_set_flags, (void*)bc_snnls_trace, (void*)bc_weighted_gram};
+                  (void*)bc_snnls_set_flags, (void*)bc_snnls_trace, (void*)bc_weighted_gram, (void*)bc_comm_load, (void*)bc_comm_unique_id, (void*)bc_comm_create,
+                  (void*)bc_comm_destroy, (void*)bc_comm_info, (void*)bc_comm_all_gather, (void*)bc_comm_selftest,
+                  (void*)bc_snnls_bind_comm};
   printf("abi %d, %d entry points\n", bc_version(), (int)(sizeof(syms) / sizeof(syms[0])));
   if (bc_ctx_sync(NULL) != BC_INVALID_ARGUMENT || bc_snnls_build(NULL, 1, NULL) != BC_INVALID_ARGUMENT) return 2;
   if (argc < 2 || strcmp(argv[1], "run") != 0) return 0;

@@ -29,7 +29,7 @@ def main():
     mode, out = sys.argv[1], sys.argv[2]
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    if mode == 'gpu_nccl1':
+    if mode in ('gpu_nccl1', 'gpu_nccl1_torch'):
         import torch
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
@@ -62,10 +62,12 @@ def main():
         idx, val = s.sparse_weights()
         res['idx'], res['val'], res['err'] = idx, val, np.array(s.error())
         res['w_dense'] = s.weights()
-    elif mode == 'gpu_nccl1':
+    elif mode in ('gpu_nccl1', 'gpu_nccl1_torch'):
         # one rank, RCCL backend, exchange forced on: the exact code path of `bench.py --gpus N`
+        # (native: RCCL called by the C library inside bc_snnls_build; torch: one torch.distributed call per step)
         import torch
         os.environ['BC_FORCE_EXCHANGE'] = '1'
+        os.environ['BC_NATIVE_RCCL'] = '1' if mode == 'gpu_nccl1' else '0'
         Z, th = linreg_problem()
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)
@@ -74,7 +76,10 @@ def main():
         prj = bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0), ctx=ctx)
         data = bc.DeviceData.from_torch(torch.from_numpy(Z).cuda(), ctx=ctx, row_offset=0)
         h = bc.HilbertCoreset(data, prj, comm=comm)
-        assert h.snnls._eng.exchange and h.snnls._eng._xchg.on_device
+        if mode == 'gpu_nccl1':
+            assert h.snnls._eng.native_exchange and not h.snnls._eng.exchange
+        else:
+            assert h.snnls._eng.exchange and h.snnls._eng._xchg.on_device and not h.snnls._eng.native_exchange
         h.build(25, 25)
         wts, pts, idcs = h.get()
         res['idx'], res['val'], res['err'] = idcs, wts, np.array(h.error())

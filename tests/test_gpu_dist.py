@@ -62,14 +62,16 @@ def test_two_ranks_one_gpu_beta_coreset(tmp_path):
         assert np.array_equal(r['pts'], ref.pts)                        # selected rows are broadcast exactly
 
 
-def test_rccl_exchange_path_single_rank(tmp_path):
-    """`bench.py --gpus N` drives the fused loop through torch.distributed/RCCL on the kernels' stream;
-    rehearse exactly that code path with a 1-rank NCCL group (all this box has is one GPU)."""
+@pytest.mark.parametrize('mode', ['gpu_nccl1', 'gpu_nccl1_torch'])
+def test_rccl_exchange_path_single_rank(tmp_path, mode):
+    """`bench.py --gpus N` runs the fused loop with the record all-gather over RCCL -- issued by the C library
+    itself (native, default) or by torch.distributed on the kernels' stream (fallback); rehearse exactly those
+    code paths with a 1-rank NCCL group (all this box has is one GPU)."""
     import beta_cores_amd as bc
     Z, th = linreg_problem()
     single = bc.HilbertCoreset(Z, bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0)))
     single.build(25, 25)
-    (r0,) = launch('gpu_nccl1', tmp_path, world=1)
+    (r0,) = launch(mode, tmp_path, world=1)
     np.testing.assert_array_equal(r0['idx'], single.idcs)
     assert np.array_equal(r0['val'], single.wts)                       # same kernels, same order: bit identical
     np.testing.assert_array_equal(r0['trace_f'], single.snnls._eng.trace()[0])

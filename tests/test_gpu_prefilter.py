@@ -104,6 +104,28 @@ def test_candidate_overflow_falls_back_to_fp64(bc, cap, prec):
     phi[rng.choice(n, 200, replace=False)] = phi[17]                       # 200 exact copies of one row
     same(run(bc, bc.snnls.GIGA, phi, 40, prec, cap=cap), run(bc, bc.snnls.GIGA, phi, 40, 0))
     same(run(bc, bc.snnls.FrankWolfe, phi, 40, prec, cap=cap), run(bc, bc.snnls.FrankWolfe, phi, 40, 0))
+    # the fallback really ran (and only then): the copies tie at the top in the first sweeps
+    with prefilter(prec, cap):
+        s = bc.snnls.GIGA(phi.T, phi.sum(axis=0))
+    s.build(5)
+    assert s._eng.prefilter_fallbacks() >= 1
+    with prefilter(prec):
+        s = bc.snnls.GIGA(correlated(rng, 3000, 32).T, np.ones(32))
+    s.build(5)
+    assert s._eng.prefilter_fallbacks() == 0
+
+
+def test_fallback_with_many_tiles_and_partial_last_tile(bc, prec):
+    """Overflow on a shard large enough that every helper block of the in-launch fp64 fallback has tiles,
+    with a ragged last tile; stepwise (select/reweight) and fused paths."""
+    rng = np.random.RandomState(12)
+    n, s = 150_001, 24
+    phi = correlated(rng, n, s)
+    phi[rng.choice(n, 3000, replace=False)] = phi[5]
+    a = run(bc, bc.snnls.GIGA, phi, 30, prec, cap=3)
+    same(a, run(bc, bc.snnls.GIGA, phi, 30, 0))
+    b = run(bc, bc.snnls.FrankWolfe, phi, 30, prec, cap=3, stepwise=True)
+    same(b, run(bc, bc.snnls.FrankWolfe, phi, 30, 0, stepwise=True))
 
 
 F1 = load_golden('f1_snnls')
