@@ -124,6 +124,12 @@ __device__ __forceinline__ double bc_wave_sum(double v) {
   return v;
 }
 
+// wave-wide sum, result in every lane (fixed shuffle tree: deterministic)
+__device__ __forceinline__ double bc_wave_sum_all(double v) {
+  v = bc_wave_sum(v);
+  return __shfl(v, 0, BC_WAVE);
+}
+
 // block-wide sum, result broadcast to every thread; red must hold >= 17 doubles
 __device__ __forceinline__ double bc_block_sum(double v, double* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

@@ -102,112 +102,139 @@ struct bc_snnls {
 };
 
 // ------------------------------------------------------------------ device building blocks (single block)
-__device__ __forceinline__ double dev_dot(const double* a, const double* b, int s, double* red) {
-  double acc = 0.0;
-  for (int k = threadIdx.x; k < s; k += blockDim.x) acc = fma(a[k], b[k], acc);
-  return bc_block_sum(acc, red);
-}
-
-// xw = sum_j val[j] * cols[j], err = ||xw - b||, ||xw||^2 and the positive count, all threads busy:
-// the list is split over G = blockDim/S thread groups (fixed split => deterministic), partial
-// vectors are combined in group order through LDS.
+// The S-vector algebra of a step (dot products, step sizes, the next sweep vectors) is done by WAVE 0 alone:
+// lane l owns elements l, l+64, ... of every vector and reductions are shuffle trees, so a step needs a handful
+// of block barriers instead of three per reduction.  Only the O(nnz*S) work -- rebuilding xw from the list,
+// scaling / searching the list -- uses the whole block.  Every kernel goes through the same helpers, so the
+// fused loop and the step-wise protocol produce the same bits.
 #define BC_FIN_THREADS 512
+
+// xw = sum_j val[j] * cols[j], err = ||xw - b||, ||xw||^2 and the positive count.  The list is split over
+// G = blockDim/S thread groups (fixed split => deterministic), partial vectors are combined in group order.
 __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
   __shared__ double part[BC_FIN_THREADS];
+  __shared__ int npos_sh;
   const int s = P.s;
   const long long nnz = S.nnz;
-  double e = 0.0, q = 0.0, np = 0.0;
-  for (long long j = threadIdx.x; j < nnz; j += blockDim.x) np += (P.val[j] > 0.) ? 1.0 : 0.0;
+  if (threadIdx.x == 0) npos_sh = 0;
+  __syncthreads();
+  int np = 0;
+  for (long long j = threadIdx.x; j < nnz; j += blockDim.x) np += (P.val[j] > 0.) ? 1 : 0;
+  if (np) atomicAdd(&npos_sh, np);
   if (s <= (int)blockDim.x) {
     const int G = blockDim.x / s;
     const int g = threadIdx.x / s, k = threadIdx.x - g * s;
     double acc = 0.0;
     if (g < G) {
-      // 8 independent loads in flight per thread: the list lives in global memory and a dependent
+      // 16 independent loads in flight per thread: the list lives in global memory (L2) and a dependent
       // load per term would cost a full memory latency each
       long long j = g;
-      for (; j + 7 * (long long)G < nnz; j += 8 * (long long)G) {
-        double v8[8], c8[8];
+      for (; j + 15 * (long long)G < nnz; j += 16 * (long long)G) {
+        double v8[16], c8[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
           v8[u] = P.val[j + u * (long long)G];
           c8[u] = P.cols[(size_t)(j + u * (long long)G) * s + k];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fma(v8[u], c8[u], acc);
+        for (int u = 0; u < 16; ++u) acc = fma(v8[u], c8[u], acc);
+      }
+      for (; j + 3 * (long long)G < nnz; j += 4 * (long long)G) {
+        double v4[4], c4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v4[u] = P.val[j + u * (long long)G];
+          c4[u] = P.cols[(size_t)(j + u * (long long)G) * s + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = fma(v4[u], c4[u], acc);
       }
       for (; j < nnz; j += G) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
     }
     part[threadIdx.x] = acc;
     __syncthreads();
-    if (threadIdx.x < s) {
-      double t = part[threadIdx.x];
-      for (int gg = 1; gg < G; ++gg) t += part[gg * s + threadIdx.x];
-      P.xw[threadIdx.x] = t;
-      const double d = t - P.b[threadIdx.x];
-      e = d * d;
-      q = t * t;
+    if (threadIdx.x < BC_WAVE) {
+      double e = 0.0, q = 0.0;
+      for (int kk = threadIdx.x; kk < s; kk += BC_WAVE) {
+        double t = part[kk];
+        for (int gg = 1; gg < G; ++gg) t += part[gg * s + kk];
+        P.xw[kk] = t;
+        const double d = t - P.b[kk];
+        e = fma(d, d, e);
+        q = fma(t, t, q);
+      }
+      e = bc_wave_sum(e);
+      q = bc_wave_sum(q);
+      if (threadIdx.x == 0) {
+        S.err_cur = sqrt(e);
+        S.xw_sq = q;
+        S.npos = npos_sh;
+      }
     }
   } else {
+    double e = 0.0, q = 0.0;
     for (int k = threadIdx.x; k < s; k += blockDim.x) {
       double acc = 0.0;
       for (long long j = 0; j < nnz; ++j) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
       P.xw[k] = acc;
       const double d = acc - P.b[k];
-      e += d * d;
-      q += acc * acc;
+      e = fma(d, d, e);
+      q = fma(acc, acc, q);
     }
-  }
-  double r3[3] = {e, q, np};
-  bc_block_sum_n<3>(r3, red);
-  if (threadIdx.x == 0) {
-    S.err_cur = sqrt(r3[0]);
-    S.xw_sq = r3[1];
-    S.npos = (long long)r3[2];
+    double r2[2] = {e, q};
+    bc_block_sum_n<2>(r2, red);
+    if (threadIdx.x == 0) {
+      S.err_cur = sqrt(r2[0]);
+      S.xw_sq = r2[1];
+      S.npos = npos_sh;
+    }
   }
   __syncthreads();
 }
 
-// vectors for the next sweep.  GIGA: giga.py:21-30 ; FW / OMP: residual b - A.w
+// vectors for the next sweep.  GIGA: giga.py:21-30 ; FW / OMP: residual b - A.w          (wave 0 + one barrier)
 template <int ALG>
 __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
   const int s = P.s;
-  if (ALG == BC_ALG_GIGA) {
-    double nw = sqrt(S.xw_sq);
-    nw = (nw == 0.) ? 1. : nw;
-    double bd = 0.0;
-    for (int k = threadIdx.x; k < s; k += blockDim.x) {
-      const double xn = P.xw[k] / nw;
-      P.v[2 * k + 1] = xn;
-      bd = fma(P.bn[k], xn, bd);
+  if (threadIdx.x < BC_WAVE) {
+    const int lane = threadIdx.x;
+    if (ALG == BC_ALG_GIGA) {
+      double nw = sqrt(S.xw_sq);
+      nw = (nw == 0.) ? 1. : nw;
+      double bd = 0.0;
+      for (int k = lane; k < s; k += BC_WAVE) {
+        const double xn = P.xw[k] / nw;
+        P.v[2 * k + 1] = xn;
+        bd = fma(P.bn[k], xn, bd);
+      }
+      bd = bc_wave_sum_all(bd);
+      double cn = 0.0;
+      for (int k = lane; k < s; k += BC_WAVE) {
+        const double c = P.bn[k] - bd * (P.xw[k] / nw);
+        cn = fma(c, c, cn);
+      }
+      cn = sqrt(bc_wave_sum_all(cn));
+      const bool fail = cn < P.tol;
+      for (int k = lane; k < s; k += BC_WAVE) {
+        const double c = P.bn[k] - bd * (P.xw[k] / nw);
+        P.v[2 * k] = fail ? c : c / cn;
+      }
+      if (lane == 0) S.select_fail = fail ? 1 : 0;
+    } else {
+      double vn = 0.0;
+      for (int k = lane; k < s; k += BC_WAVE) {
+        const double r = P.b[k] - P.xw[k];
+        P.v[k] = r;
+        vn = fma(r, r, vn);
+      }
+      vn = bc_wave_sum(vn);
+      if (lane == 0) {
+        S.select_fail = 0;
+        S.v_norm = sqrt(vn);
+      }
     }
-    bd = bc_block_sum(bd, red);
-    double cn = 0.0;
-    for (int k = threadIdx.x; k < s; k += blockDim.x) {
-      const double c = P.bn[k] - bd * P.v[2 * k + 1];
-      P.v[2 * k] = c;
-      cn = fma(c, c, cn);
-    }
-    cn = sqrt(bc_block_sum(cn, red));
-    const bool fail = cn < P.tol;
-    if (!fail)
-      for (int k = threadIdx.x; k < s; k += blockDim.x) P.v[2 * k] = P.v[2 * k] / cn;
-    if (threadIdx.x == 0) S.select_fail = fail ? 1 : 0;
-  } else {
-    double vn = 0.0;
-    for (int k = threadIdx.x; k < s; k += blockDim.x) {
-      const double r = P.b[k] - P.xw[k];
-      P.v[k] = r;
-      vn = fma(r, r, vn);
-    }
-    vn = bc_block_sum(vn, red);
-    if (threadIdx.x == 0) {
-      S.select_fail = 0;
-      S.v_norm = sqrt(vn);
-    }
+    if (lane == 0) S.skip = S.select_fail | S.reached_limit;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) S.skip = S.select_fail | S.reached_limit;
   __syncthreads();
 }
 
@@ -218,43 +245,42 @@ __device__ void dev_pick(const SnnlsDev& P, SnnlsState& S, double* red) {
   __shared__ int src_rec;
   __shared__ long long src_list;
   const int s = P.s;
-  {
-    // one record header per thread (independent loads), then a block argmax on (score, global index);
-    // global indices are unique across ranks, so the winning record is identified by its index
-    __shared__ double pv[16];
-    __shared__ long long pi[16];
+  if (threadIdx.x < BC_WAVE) {
+    // wave 0: one record header per lane (independent loads), shuffle argmax on (score, global index)
+    // carrying the record slot; the winner's column is copied straight from its record
+    const int lane = threadIdx.x;
     double bv = -INFINITY;
     long long bi = LLONG_MAX;
-    for (int r = threadIdx.x; r < P.world; r += blockDim.x) {
+    int br = -1;
+    for (int r = lane; r < P.world; r += BC_WAVE) {
       const double* rec = P.cand_all + (size_t)r * P.rec_len;
       const double sc = rec[0], ok = rec[3];
       const long long gi = reinterpret_cast<const long long*>(rec)[1];
-      if (ok != 0.0 && bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
+      if (ok != 0.0 && bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; br = r; }
     }
-    bc_wave_argmax(bv, bi);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { pv[wave] = bv; pi[wave] = bi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int nwv = (blockDim.x + 63) >> 6;
-      for (int w = 1; w < nwv; ++w)
-        if (bc_better(pv[w], pi[w], bv, bi)) { bv = pv[w]; bi = pi[w]; }
-      S.sel_valid = bi != LLONG_MAX ? 1 : 0;
-      S.sel_f = S.sel_valid ? bi : -1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const double ov = __shfl_down(bv, d, BC_WAVE);
+      const long long oi = bc_shfl_down_ll(bi, d);
+      const int orr = __shfl_down(br, d, BC_WAVE);
+      if (bc_better(ov, oi, bv, bi)) { bv = ov; bi = oi; br = orr; }
+    }
+    br = __shfl(br, 0, BC_WAVE);
+    const bool valid = br >= 0;
+    const double* win = P.cand_all + (size_t)(valid ? br : 0) * P.rec_len;
+    if (lane == 0) {
+      S.sel_valid = valid ? 1 : 0;
+      S.sel_f = valid ? bi : -1;
       S.sel_score = bv;
-      src_rec = -1;
+      if (valid) S.sel_norm = win[2];
+      src_rec = br;
       src_list = -1;
     }
-    __syncthreads();
-    for (int r = threadIdx.x; r < P.world; r += blockDim.x) {
-      const double* rec = P.cand_all + (size_t)r * P.rec_len;
-      if (S.sel_valid && rec[3] != 0.0 && reinterpret_cast<const long long*>(rec)[1] == S.sel_f) {
-        src_rec = r;
-        S.sel_norm = rec[2];
-      }
-    }
-    __syncthreads();
+    if (ALG != BC_ALG_OMP && valid)
+      for (int k = lane; k < s; k += BC_WAVE) P.xf[k] = win[BC_REC_HDR + k];
   }
+  __syncthreads();
+  if (ALG != BC_ALG_OMP) return;
   if (ALG == BC_ALG_OMP && S.sel_valid && S.npos > 0) {
     // neg = max over active j of -(An[:,j] . residual)
     __shared__ double nv[16];
@@ -330,67 +356,86 @@ __device__ void dev_pick_blocks(const SnnlsDev& P, SnnlsState& S) {
 }
 
 // closed-form step sizes.  Returns 1 when the reference would raise NumericalPrecisionError
-// (w untouched), else 0 with (alpha, beta) set.
+// (w untouched), else 0 with (alpha, beta) set.                                    (wave 0 + one barrier)
 template <int ALG>
 __device__ int dev_step_sizes(const SnnlsDev& P, const SnnlsState& S, double* red, double& alpha, double& beta) {
+  __shared__ double ab[2];
+  __shared__ int ab_fail;
   const int s = P.s;
-  if (ALG == BC_ALG_GIGA) {   // giga.py:42-61
-    double nw = sqrt(S.xw_sq);
-    nw = (nw == 0.) ? 1. : nw;
-    const double nf = sqrt(dev_dot(P.xf, P.xf, s, red));
-    double r3[3] = {0., 0., 0.};
-    for (int k = threadIdx.x; k < s; k += blockDim.x) {
-      const double fn = P.xf[k] / nf, wn = P.xw[k] / nw;
-      r3[0] = fma(P.bn[k], fn, r3[0]);
-      r3[1] = fma(P.bn[k], wn, r3[1]);
-      r3[2] = fma(wn, fn, r3[2]);
+  if (threadIdx.x < BC_WAVE) {
+    const int lane = threadIdx.x;
+    int fail = 0;
+    double al = 0., be = 0.;
+    if (ALG == BC_ALG_GIGA) {   // giga.py:42-61
+      double nw = sqrt(S.xw_sq);
+      nw = (nw == 0.) ? 1. : nw;
+      double ff = 0.;
+      for (int k = lane; k < s; k += BC_WAVE) ff = fma(P.xf[k], P.xf[k], ff);
+      const double nf = sqrt(bc_wave_sum_all(ff));
+      double r0 = 0., r1 = 0., r2 = 0.;
+      for (int k = lane; k < s; k += BC_WAVE) {
+        const double fn = P.xf[k] / nf, wn = P.xw[k] / nw;
+        r0 = fma(P.bn[k], fn, r0);
+        r1 = fma(P.bn[k], wn, r1);
+        r2 = fma(wn, fn, r2);
+      }
+      const double bxf = bc_wave_sum_all(r0), bxw = bc_wave_sum_all(r1), xwxf = bc_wave_sum_all(r2);
+      const double gA = bxf - bxw * xwxf;
+      const double gB = bxw - bxf * xwxf;
+      if (gA <= 0. || gB < 0.) {
+        fail = 1;
+      } else {
+        const double a = gB / (gA + gB) / nw;
+        const double b = gA / (gA + gB) / nf;
+        double nx = 0.;
+        for (int k = lane; k < s; k += BC_WAVE) {
+          const double x = a * P.xw[k] + b * P.xf[k];
+          nx = fma(x, x, nx);
+        }
+        nx = sqrt(bc_wave_sum_all(nx));
+        double xb = 0.;
+        for (int k = lane; k < s; k += BC_WAVE) {
+          const double x = a * P.xw[k] + b * P.xf[k];
+          xb = fma(x / nx, P.bn[k], xb);
+        }
+        xb = bc_wave_sum_all(xb);
+        const double scale = P.bnorm / nx * xb;
+        al = a * scale;
+        be = b * scale;
+      }
+    } else {                    // frankwolfe.py:20-37
+      const double nf = S.sel_norm;
+      if (S.npos == 0) {
+        al = 0.;
+        be = P.norm_sum / nf;
+      } else {
+        const double c = P.norm_sum / nf;
+        double num = 0., den = 0.;
+        for (int k = lane; k < s; k += BC_WAVE) {
+          const double d = c * P.xf[k] - P.xw[k];
+          num = fma(d, P.b[k] - P.xw[k], num);
+          den = fma(d, d, den);
+        }
+        num = bc_wave_sum_all(num);
+        den = bc_wave_sum_all(den);
+        if (num < 0. || den == 0. || num > den) {
+          fail = 1;
+        } else {
+          al = 1. - num / den;
+          be = c * num / den;
+        }
+      }
     }
-    bc_block_sum_n<3>(r3, red);
-    const double bxf = r3[0], bxw = r3[1], xwxf = r3[2];
-    const double gA = bxf - bxw * xwxf;
-    const double gB = bxw - bxf * xwxf;
-    if (gA <= 0. || gB < 0.) return 1;
-    const double a = gB / (gA + gB) / nw;
-    const double b = gA / (gA + gB) / nf;
-    double nx = 0.;
-    for (int k = threadIdx.x; k < s; k += blockDim.x) {
-      const double x = a * P.xw[k] + b * P.xf[k];
-      nx = fma(x, x, nx);
+    if (lane == 0) {
+      ab[0] = al;
+      ab[1] = be;
+      ab_fail = fail;
     }
-    nx = sqrt(bc_block_sum(nx, red));
-    double xb = 0.;
-    for (int k = threadIdx.x; k < s; k += blockDim.x) {
-      const double x = a * P.xw[k] + b * P.xf[k];
-      xb = fma(x / nx, P.bn[k], xb);
-    }
-    xb = bc_block_sum(xb, red);
-    const double scale = P.bnorm / nx * xb;
-    alpha = a * scale;
-    beta = b * scale;
-    return 0;
-  } else {                    // frankwolfe.py:20-37
-    const double nf = S.sel_norm;
-    if (S.npos == 0) {
-      alpha = 0.;
-      beta = P.norm_sum / nf;
-      return 0;
-    }
-    const double c = P.norm_sum / nf;
-    double num = 0., den = 0.;
-    for (int k = threadIdx.x; k < s; k += blockDim.x) {
-      const double d = c * P.xf[k] - P.xw[k];
-      num = fma(d, P.b[k] - P.xw[k], num);
-      den = fma(d, d, den);
-    }
-    double r2[2] = {num, den};
-    bc_block_sum_n<2>(r2, red);
-    num = r2[0];
-    den = r2[1];
-    if (num < 0. || den == 0. || num > den) return 1;
-    alpha = 1. - num / den;
-    beta = c * num / den;
-    return 0;
   }
+  __syncthreads();
+  alpha = ab[0];
+  beta = ab[1];
+  return ab_fail;
 }
 
 // w = alpha*w ; w[f] = max(0, w[f] + beta)   (giga.py:63-64, frankwolfe.py:39-40)
@@ -499,9 +544,10 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P0, int
       // keep what is needed to revert (snnls.py:46-47)
       const long long nnz0 = S.nnz, npos0 = S.npos;
       const double err0 = S.err_cur, xwsq0 = S.xw_sq;
+      // (no barrier needed here: each thread later rescales exactly the val[j] it saved, and xw is only
+      //  overwritten behind dev_xw_err's barriers)
       for (long long j = threadIdx.x; j < nnz0; j += blockDim.x) P.prev_val[j] = P.val[j];
       for (int k = threadIdx.x; k < s; k += blockDim.x) P.xw_prev[k] = P.xw[k];
-      __syncthreads();
       dev_apply(P, S, alpha, beta);
       dev_xw_err(P, S, red);
       if (guard) {
