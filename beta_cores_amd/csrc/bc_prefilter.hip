@@ -1,15 +1,19 @@
-// K3 with an fp32 pre-filter: halves the bytes of the per-iteration sweep while returning EXACTLY
-// the row the fp64 sweep (bc_sweep.hip) would return.
+// K3 with a reduced-precision pre-filter: the per-iteration sweep streams a fp16 (default) or fp32 mirror of
+// the normalised rows -- a quarter / half of the bytes -- while returning EXACTLY the row the fp64 sweep
+// (bc_sweep.hip) would return.
 //
-//   u32[i, :] = fp32( Phi[i, :] / ||Phi[i, :]|| )      built once per solver (4*N*S bytes)
+//   u[i, :] = round( Phi[i, :] / ||Phi[i, :]|| )       built once per solver (2*N*S or 4*N*S bytes)
 //
-//   pass A  k_sweep_f32   streams u32 (non-temporal, fp64 accumulation), and for every row computes an
-//                         interval [L_i, U_i] that provably contains the fp64 kernel's score of that row:
-//                         fp32 rounding moves each normalised dot product by at most
-//                         delta = 2^-24 * ||u_i|| * ||v|| (Cauchy-Schwarz), propagated through the score
-//                         formula by the mean-value theorem.  Rows the bound cannot handle (|s1| close to 1,
-//                         NaN) get [-inf, +inf].  Writes U_i (fp32, rounded up) and the block maximum of L_i.
-//   pass B  k_rescore     (one block) Lmax = max_i L_i; every row with U_i >= Lmax is a candidate -- the true
+//   pass A  k_sweep_f16 / k_sweep_f32
+//                         streams u (non-temporal) and for every row computes an interval [L_i, U_i] that
+//                         provably contains the fp64 kernel's score of that row: the rounding of the inputs and
+//                         of the accumulation moves each normalised dot product by at most delta * ||v||
+//                         (Cauchy-Schwarz; delta32 = 6.2e-8 with fp64 accumulation, delta16 ~ 4.9e-4 with the
+//                         fp32 fma chain, see bc_pref_delta16), propagated through the score formula by the
+//                         mean-value theorem.  Rows the bound cannot handle (|s1| close to 1, NaN) get
+//                         [-inf, +inf].  Writes U_i (fp32, rounded up), the tile maxima of U and the block maxima
+//                         of L.
+//   pass B  k_rescore     (block 0) Lmax = max_i L_i; every row with U_i >= Lmax is a candidate -- the true
 //                         argmax is always among them, typically a handful of rows; whole tiles are skipped
 //                         through their maximum U.  The candidates' scores are recomputed from the fp64 Phi
 //                         with the same arithmetic (same fma chain, same epilogue) as k_sweep, the argmax is
@@ -18,12 +22,11 @@
 //   block per CU; block 0 does the work above while the others wait for its verdict (they exit at once in the
 //   common case) and, on overflow, all of them sweep the fp64 Phi and block 0 merges their winners.
 //
-// Algorithmic traffic per row: 4*S (u32) + 8 (norm) + 4 (U written) bytes.
+// Algorithmic traffic per row: fp16 2*S + 8 (norm) + 4 (U written) bytes; fp32 4*S + 12.
 //
-// The fp16 variant (k_sweep_f16, BC_PREFILTER=16) stores the unit rows as IEEE half and accumulates in fp32
-// (v_fma_mix_f32: the half->float extension is part of the fma).  Its delta is larger (2^-11 input rounding
-// + the fp32 chain, see bc_pref_delta16) so a few more rows reach the exact rescoring, but the streamed bytes
-// halve again: 2*S + 12 per row.  The selection is still provably the fp64 sweep's.
+// The fp16 kernel accumulates in fp32 (v_cvt_f32_f16 + v_pk_fma_f32: both dot products of a row in one packed
+// FMA) and double-buffers its loads in registers; its planes are padded with zeros to a multiple of BC_HU and
+// the sweep vectors carry a zero tail (BC_V_PAD, bc_snnls.hip), so there is no remainder loop.
 #include "bc_sweep_dev.h"
 #include <cstdlib>
 #include <cstring>

@@ -92,7 +92,7 @@ struct bc_snnls {
   double* val2 = nullptr;
   double* cols2 = nullptr;
   double* colnorm2 = nullptr;
-  bc_pref* pref = nullptr;         // fp32 pre-filter of the sweep (large shards), see bc_prefilter.hip
+  bc_pref* pref = nullptr;         // reduced-precision pre-filter of the sweep (large shards), see bc_prefilter.hip
   double* cand_send = nullptr;     // this rank's candidate record (S + 4 doubles)
   bool cand_send_owned = true;     // false once the host bound its own exchange buffers
   bc_comm* comm = nullptr;         // native RCCL exchange (bc_comm.hip): the loop all-gathers by itself

@@ -81,6 +81,14 @@ def test_status_translation():
     assert lib.bc_ctx_sync(None) == 2
     assert lib.bc_phi_colsum(None, None) == 2
     assert lib.bc_snnls_build(None, 3, None) == 2
+    # native exchange: validated before RCCL or the device is touched
+    import ctypes as C
+    buf = (C.c_ubyte * 128)()
+    assert lib.bc_comm_unique_id(None, 128) == 2 and lib.bc_comm_unique_id(C.cast(buf, C.c_void_p), 64) == 2
+    h = C.c_void_p()
+    assert lib.bc_comm_create(None, C.cast(buf, C.c_void_p), 0, 1, C.byref(h)) == 2
+    assert lib.bc_comm_selftest(None) == 2 and lib.bc_comm_all_gather(None, None, None, 4) == 2
+    assert lib.bc_snnls_bind_comm(None, None) == 2 and lib.bc_comm_destroy(None) == 0
 
 
 def test_nn_opt_matches_reference_bits():
