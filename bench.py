@@ -296,6 +296,7 @@ def main():
         sys.stdout.flush()
     if world > 1 or force_xchg:
         dist.barrier()
+        comm.close()                      # the library's own RCCL communicator, before torch's
         dist.destroy_process_group()
 
 
