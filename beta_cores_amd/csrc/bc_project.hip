@@ -90,20 +90,27 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
   }
 }
 
-// NT = number of 16-sample accumulator tiles (S <= 16*NT), KC = D-chunk staged per LDS pass,
+// NT = number of 16-sample accumulator tiles, KC = D-chunk staged per LDS pass,
 // JT = 16-row sub-tiles per wave (2 -> 4 waves per 128-row tile, 1 -> 8 waves; the latter keeps
 // the accumulators of a 200+-sample projection within the register file).
-template <int MODEL, int NT, int KC, int JT, bool RAW = false>
+// TL = 0 or 4 "tail" samples beyond the NT tiles (S <= 16*NT + TL), contracted on the vector pipe from the
+// B-operand registers the MFMAs already hold: lane (g, row) accumulates sum_{d = g mod 4} x[row][d]*theta[16*NT+t][d]
+// for t = 0..3 and two shuffles across the four g-lanes of a row finish the dot products.  S = 100 (every
+// BASELINE config) thus runs 6 MFMA tiles + 4 tail samples instead of 7 tiles with 12 padded samples: the tail's
+// 8 v_fma_f64 per k-step hide behind 12 MFMAs, and the matrix pipe does 6/7 of the work.
+template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0>
 __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2) void k_project(ProjArgs a) {
+  static_assert(TL == 0 || (TL == 4 && !RAW), "tail: exactly one extra sample per g-lane");
   constexpr int NTHR = 128 / (16 * JT) * 64;
+  constexpr int NR = NT * 16 + TL;                // rows of (padded) Theta this kernel contracts with
   constexpr int LDZ = KC + 1;    // odd stride: rows (2j, 2j+1) of a lane pair hit distinct banks
   constexpr int LDT = KC + 2;
   constexpr int ZP = (128 * KC) / NTHR;           // 8-byte loads of Z per thread per chunk
-  constexpr int TN = NT * 16 * KC / 2;            // 16-byte loads of Theta per chunk (whole block)
+  constexpr int TN = NR * KC / 2;                 // 16-byte loads of Theta per chunk (whole block)
   constexpr int TP = (TN + NTHR - 1) / NTHR;
   extern __shared__ double lds[];
   double* Zl = lds;                    // [128][LDZ]
-  double* Tl = lds + 128 * LDZ;        // [NT*16][LDT]   (reused for the column partials after the loop)
+  double* Tl = lds + 128 * LDZ;        // [NR][LDT]   (reused for the column partials after the loop)
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -117,6 +124,11 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
     for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
+  double tl[JT][TL > 0 ? TL : 1];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int t = 0; t < (TL > 0 ? TL : 1); ++t) tl[jt][t] = 0.;
 
   // Staging through buffer loads: a wave-uniform descriptor per operand (SGPRs), ONE 32-bit
   // per-thread byte offset shared by all passes, and a scalar offset per pass -- no 64-bit
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   const long long rows_here = (a.n_rows - r0) < BC_TILE ? (a.n_rows - r0) : BC_TILE;
   const auto zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0,
                                                        (int)(rows_here * a.dz * 8), 0x00020000);
-  const auto trsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.theta, 0, NT * 16 * a.dk * 8, 0x00020000);
+  const auto trsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.theta, 0, NR * a.dk * 8, 0x00020000);
   const int toff = (trw * a.dk + tc) * 8;
   double zr[ZP];
   double2 tr[TP];
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     for (int q = 0; q < ZP; ++q)
       zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * ZROWS * a.dz * 8, BC_K1_Z_AUX));
 #pragma unroll
-    for (int q = 0; q < TP; ++q)   // rows past NT*16 are outside the descriptor and read as 0
+    for (int q = 0; q < TP; ++q)   // rows past NR are outside the descriptor and read as 0
       tr[q] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, (q * TROWS * a.dk + d0) * 8, 0));
   };
   auto store_chunk = [&]() {
@@ -174,9 +186,34 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bz[jt], acc[jt][st], 0, 0, 0);
       }
+      if (TL > 0) {
+        const double* ttail = Tl + (NT * 16) * LDT + g;
+#pragma unroll
+        for (int t = 0; t < TL; ++t) {
+          const double at = ttail[t * LDT + kk * 4];
+#pragma unroll
+          for (int jt = 0; jt < JT; ++jt) tl[jt][t] = fma(at, bz[jt], tl[jt][t]);
+        }
+      }
     }
     __syncthreads();
   }
+  // tail samples: combine the four d-residue classes of a row, lane g keeps sample 16*NT + g
+  double tv[JT];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+    tv[jt] = 0.;
+    if (TL > 0) {
+#pragma unroll
+      for (int t = 0; t < TL; ++t) {
+        double x = tl[jt][t];
+        x += __shfl_xor(x, 16, BC_WAVE);
+        x += __shfl_xor(x, 32, BC_WAVE);
+        if (t == g) tv[jt] = x;
+      }
+    }
+  }
+  const int s_tail = NT * 16 + g;
 
   // ---- epilogue: lane holds, for data rows (row_base + jt), samples s = 16*st + g + 4*reg
   if (RAW) {
@@ -230,6 +267,16 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         sum += v;
       }
     }
+    if (TL > 0) {
+      double v = 0.;
+      if (s_tail < S && live) {
+        v = bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c);
+        vmin = fmin(vmin, v);
+        vmax = fmax(vmax, v);
+      }
+      tv[jt] = v;
+      sum += v;
+    }
     sum += __shfl_xor(sum, 16, BC_WAVE);
     sum += __shfl_xor(sum, 32, BC_WAVE);
     vmin = fmin(vmin, __shfl_xor(vmin, 16, BC_WAVE));
@@ -251,6 +298,11 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         acc[jt][st][reg] = v;
         sq = fma(v, v, sq);
       }
+    }
+    if (TL > 0) {
+      const double v = (s_tail < S && live) ? tv[jt] - mean : 0.;
+      tv[jt] = v;
+      sq = fma(v, v, sq);
     }
     sq += __shfl_xor(sq, 16, BC_WAVE);
     sq += __shfl_xor(sq, 32, BC_WAVE);
@@ -276,15 +328,30 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       cp += __shfl_xor(cp, 2, BC_WAVE);
       cp += __shfl_xor(cp, 4, BC_WAVE);
       cp += __shfl_xor(cp, 8, BC_WAVE);
-      if (j == 0) colpart[w * (NT * 16) + s] = cp;
+      if (j == 0) colpart[w * NR + s] = cp;
     }
+  }
+  if (TL > 0) {
+    double cp;
+    if (JT == 2) {
+      if (s_tail < S) bc_store2(tbase + (size_t)s_tail * BC_TILE, tv[0], tv[JT - 1]);
+      cp = tv[0] + tv[JT - 1];
+    } else {
+      if (s_tail < S) tbase[(size_t)s_tail * BC_TILE] = tv[0];
+      cp = tv[0];
+    }
+    cp += __shfl_xor(cp, 1, BC_WAVE);
+    cp += __shfl_xor(cp, 2, BC_WAVE);
+    cp += __shfl_xor(cp, 4, BC_WAVE);
+    cp += __shfl_xor(cp, 8, BC_WAVE);
+    if (j == 0) colpart[w * NR + s_tail] = cp;
   }
   __syncthreads();
   constexpr int NW = NTHR / 64;
   for (int s = tid; s < S; s += NTHR) {
     double t = colpart[s];
 #pragma unroll
-    for (int ww = 1; ww < NW; ++ww) t += colpart[ww * NT * 16 + s];
+    for (int ww = 1; ww < NW; ++ww) t += colpart[ww * NR + s];
     a.tile_part[(size_t)tile * S + s] = t;
   }
 }
@@ -623,16 +690,16 @@ static int model_constants(int model, const double* p, int np, int d, double* c,
   return BC_INVALID_ARGUMENT;
 }
 
-template <int MODEL, int NT, int KC, int JT, bool RAW = false>
+template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0>
 static int launch_project(bc_ctx* ctx, const ProjArgs& a, long long ntiles) {
-  const size_t lds = (size_t)(128 * (KC + 1) + NT * 16 * (KC + 2)) * sizeof(double);
+  const size_t lds = (size_t)(128 * (KC + 1) + (NT * 16 + TL) * (KC + 2)) * sizeof(double);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT, RAW>),
+    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT, RAW, TL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_project<MODEL, NT, KC, JT, RAW>), dim3((unsigned)ntiles), dim3(128 / (16 * JT) * 64), lds, ctx->stream, a);
+  hipLaunchKernelGGL((k_project<MODEL, NT, KC, JT, RAW, TL>), dim3((unsigned)ntiles), dim3(128 / (16 * JT) * 64), lds, ctx->stream, a);
   BC_HIP(hipGetLastError());
   return BC_OK;
 }
@@ -641,6 +708,7 @@ template <int MODEL>
 static int launch_project_nt(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int ntsel) {
   switch (ntsel) {
     case 4: return launch_project<MODEL, 4, 32, 2>(ctx, a, ntiles);
+    case 6: return launch_project<MODEL, 6, 32, 2, false, 4>(ctx, a, ntiles);      // 96 < S <= 100: 6 tiles + 4 tail samples
     case 7: {
       static const int jt1 = getenv("BC_K1_JT1") ? atoi(getenv("BC_K1_JT1")) : 0;
       if (jt1) return launch_project<MODEL, 7, 32, 1>(ctx, a, ntiles);
@@ -690,7 +758,10 @@ static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const doubl
   phi->stats_valid = false;
 
   const int nt = (s + 15) / 16;
-  const int NTsel = raw ? 16 : nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 16;
+  static const int no_tail = getenv("BC_K1_NOTAIL") ? atoi(getenv("BC_K1_NOTAIL")) : 0;
+  const bool tail = !raw && s > 96 && s <= 100 && !no_tail;      // 6 MFMA tiles + 4 vector-pipe samples
+  const int NTsel = raw ? 16 : tail ? 6 : nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 16;
+  const int NRsel = NTsel * 16 + (tail ? 4 : 0);                 // rows of the zero-padded Theta / saux
   // The vector-FMA kernel is parity-clean but measured SLOWER than the MFMA kernel in round 1
   // (N=4M, D=128: 3.73 ms vs 3.11 ms; its scalar theta loads are not software-pipelined yet), so it is
   // opt-in: BC_K1_VALU=1.
@@ -700,7 +771,7 @@ static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const doubl
   const int KC = NTsel <= 7 ? 32 : 16;                    // dk is a multiple of 8 (the VALU kernel's chunk) either way
   const int dk = ((d + KC - 1) / KC) * KC;
   ProjScratch& sc = g_scr[ctx->device & 15];
-  const size_t th_n = (size_t)NTsel * 16 * dk, sa_n = (size_t)NTsel * 16;
+  const size_t th_n = (size_t)NRsel * dk, sa_n = (size_t)NRsel;
   const size_t thv_n = use_valu ? (size_t)dk * 4 * SWv : 0;
   int rc = grow_dev(&sc.theta, &sc.theta_cap, th_n);
   if (!rc) rc = grow_dev(&sc.saux, &sc.saux_cap, sa_n);
