@@ -44,6 +44,7 @@ struct bc_pref {
   float* ub = nullptr;        // [ptiles*256] upper bounds of the last sweep
   float* tile_u = nullptr;    // [ptiles] per-tile maximum of the upper bounds
   double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
+  float* blk_u = nullptr;     // [grid] block maxima of the upper bounds (lets the selection skip whole blocks of tiles)
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
   int* ctrl = nullptr;        // [1] the last launch fell back to the fp64 sweep, [2] hand-shake timeout, [3] fallbacks so far
   unsigned* sync = nullptr;   // in-launch hand-shake of k_rescore (verdict, arrivals)
@@ -67,6 +68,7 @@ struct PrefArgs {
   float* ub;
   float* tile_u;
   double* blk_l;
+  float* blk_u;
   long long n_rows, ptiles;
   double post_div;
   int s;
@@ -105,8 +107,10 @@ __device__ __forceinline__ void bc_score_interval(double s0, double s1, double d
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
   __shared__ double sl[4];
+  __shared__ float su[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double best_l = -INFINITY;
+  float umax = -INFINITY;
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
   if (!skip) {
     const int S = a.s;
@@ -174,13 +178,17 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_down(tmax, d, BC_WAVE));
       if (lane == 0) a.tile_u[t] = tmax;       // lets the selection pass skip whole tiles
+      umax = fmaxf(umax, tmax);                // (meaningful in lane 0)
     }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) best_l = fmax(best_l, __shfl_down(best_l, d, BC_WAVE));
-  if (lane == 0) sl[wave] = best_l;
+  if (lane == 0) { sl[wave] = best_l; su[wave] = umax; }
   __syncthreads();
-  if (threadIdx.x == 0) a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+  if (threadIdx.x == 0) {
+    a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+    a.blk_u[blockIdx.x] = fmaxf(fmaxf(su[0], su[1]), fmaxf(su[2], su[3]));
+  }
 }
 
 
@@ -200,8 +208,10 @@ static double bc_pref_delta16(int S) { return 4.8845e-4 + 3.0e-8 * sqrt((double)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sweep_f16(PrefArgs a) {
   __shared__ double sl[4];
+  __shared__ float su[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double best_l = -INFINITY;
+  float umax = -INFINITY;
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
   if (!skip) {
     const int SP = a.sp;
@@ -269,13 +279,17 @@ __global__ __launch_bounds__(256) void k_sweep_f16(PrefArgs a) {
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_down(tmax, d, BC_WAVE));
       if (lane == 0) a.tile_u[t] = tmax;
+      umax = fmaxf(umax, tmax);                // (meaningful in lane 0)
     }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) best_l = fmax(best_l, __shfl_down(best_l, d, BC_WAVE));
-  if (lane == 0) sl[wave] = best_l;
+  if (lane == 0) { sl[wave] = best_l; su[wave] = umax; }
   __syncthreads();
-  if (threadIdx.x == 0) a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+  if (threadIdx.x == 0) {
+    a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+    a.blk_u[blockIdx.x] = fmaxf(fmaxf(su[0], su[1]), fmaxf(su[2], su[3]));
+  }
 }
 
 // u16 tile builder: one block per 512-row tile, thread = two rows; planes S..SP-1 are zero
@@ -305,12 +319,14 @@ struct RescoreArgs {
   const float* ub;
   const float* tile_u;
   const double* blk_l;
+  const float* blk_u;
   long long* cand;
   int* ctrl;
   double* rec;
   long long row_offset, ptiles;
   double post_div;
   int s, cap, nblk, ptile;
+  int tile_rounds;           // tiles per sweep wave = ceil(ptiles / (4 * nblk)): block b swept tiles 4b+w + 4*nblk*i
 };
 
 // same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
@@ -352,6 +368,66 @@ __device__ __forceinline__ double bc_exact_score(const double* __restrict__ tile
   return a0 / nr / post_div;
 }
 
+// The same score, computed by a whole wave for ONE row: the lanes fetch the row (and the sweep vectors) with one
+// round of independent loads -- lane l holds elements l, l+64, ... -- and then every lane runs the identical
+// sequential fma chain on broadcast values (v_readlane), so the result has the bits of bc_exact_score / k_sweep.
+// With a handful of candidates this replaces ~4 dependent load batches per candidate by one.
+// The same score, computed by a whole wave for ONE row: the lanes fetch the row and the sweep vectors with one
+// round of independent loads -- lane l holds elements l, l+64, ... --, park them in a wave-private LDS strip
+// and every lane then runs the identical sequential fma chain on broadcast LDS reads, so the result has the
+// bits of bc_exact_score / k_sweep.  With a handful of candidates this replaces four dependent load batches and
+// a one-lane chain by one round trip and a pipelined chain.  (Wave-private strip: LDS serves a wave's requests in
+// order, the wavefront-scope fences only keep the compiler from reordering.)
+template <int MODE>
+__device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
+                                                      int S, double nr, double post_div, double* strip /* [3][256] */) {
+  const int lane = threadIdx.x & 63;
+  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+  double* sx = strip;
+  double* sa = strip + 256;
+  double* sb = strip + 512;
+  double a0 = 0., a1 = 0.;
+  for (int base = 0; base < S; base += 256) {
+    double x[4], vx[4], vy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = base + 64 * e + lane;
+      const bool in = k < S;
+      x[e] = in ? p[(size_t)k * BC_TILE] : 0.;
+      if (MODE == 0) {
+        vx[e] = in ? v[2 * k] : 0.;
+        vy[e] = in ? v[2 * k + 1] : 0.;
+      } else {
+        vx[e] = in ? v[k] : 0.;
+        vy[e] = 0.;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous block's reads come first
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sx[64 * e + lane] = x[e];
+      sa[64 * e + lane] = vx[e];
+      if (MODE == 0) sb[64 * e + lane] = vy[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = (S - base) < 256 ? (S - base) : 256;
+#pragma unroll 8
+    for (int kk = 0; kk < n; ++kk) {
+      const double xk = sx[kk];
+      a0 = fma(xk, sa[kk], a0);
+      if (MODE == 0) a1 = fma(xk, sb[kk], a1);
+    }
+  }
+  if (MODE == 0) {
+    const double s0 = a0 / nr, s1 = a1 / nr;
+    const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
+    const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
+    return s0 / den;
+  }
+  return a0 / nr / post_div;
+}
+
 // In-launch hand-shake between block 0 (selection + rescoring) and the helper blocks (fp64 fallback).
 //   sync[0]  verdict of launch `epoch`: 4*epoch + 1 = fall back, 4*epoch + 2 = done, nothing to do
 //   sync[1]  arrivals of the helper blocks after their share of the fallback sweep (reset by block 0)
@@ -376,6 +452,10 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw
   __shared__ int tcnt;
   __shared__ int tlist[1024];
   __shared__ unsigned verdict;
+  __shared__ int bcnt;
+  __shared__ int blist[64];                  // sweep blocks whose maximum upper bound reaches Lmax
+  __shared__ long long scand[32];            // the first candidates, kept on chip (the usual case has 1-3)
+  __shared__ double strips[4][3 * 256];      // bc_exact_score_wave: one strip per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
 
@@ -409,44 +489,92 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw
   bool overflow = false;
   if (!skip) {
     double lmax = -INFINITY;
-    for (int i = threadIdx.x; i < a.nblk; i += blockDim.x) lmax = fmax(lmax, a.blk_l[i]);
+    float bu[4];                               // this thread's share of the block upper bounds (nblk <= 1024)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = threadIdx.x + q * 256;
+      bu[q] = -INFINITY;
+      if (i < a.nblk) {
+        lmax = fmax(lmax, a.blk_l[i]);
+        bu[q] = a.blk_u[i];
+      }
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
     if (lane == 0) sv[wave] = lmax;
-    if (threadIdx.x == 0) { cnt = 0; tcnt = 0; }
+    if (threadIdx.x == 0) { cnt = 0; tcnt = 0; bcnt = 0; }
     __syncthreads();
     lmax = fmax(fmax(sv[0], sv[1]), fmax(sv[2], sv[3]));
-    __syncthreads();
-    // phase B1: tiles whose maximum upper bound reaches Lmax (per-tile maxima scanned 16 loads at a time:
-    // independent loads in flight, this phase is latency-bound)
-    for (long long t0 = 0; t0 < a.ptiles; t0 += 16LL * blockDim.x) {
-      float tu[16];
+    // phase B1: tiles whose maximum upper bound reaches Lmax -- first the sweep blocks whose maximum does
+    // (usually one or two), then only the tiles those blocks walked
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const long long t = t0 + (long long)u * blockDim.x + threadIdx.x;
-        tu[u] = t < a.ptiles ? a.tile_u[t] : -INFINITY;
+    for (int q = 0; q < 4; ++q)
+      if (bu[q] != -INFINITY && (double)bu[q] >= lmax) {
+        const int slot = atomicAdd(&bcnt, 1);
+        if (slot < 64) blist[slot] = threadIdx.x + q * 256;
       }
+    __syncthreads();
+    const int nbl = bcnt;
+    if (nbl <= 64) {
+      const int per = 4 * a.tile_rounds, total = nbl * per;
+      for (int i0 = 0; i0 < total; i0 += 8 * blockDim.x) {
+        float tu[8];
+        long long tt[8];
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (tu[u] != -INFINITY && (double)tu[u] >= lmax) {
-          const int slot = atomicAdd(&tcnt, 1);
-          if (slot < 1024) tlist[slot] = (int)(t0 + (long long)u * blockDim.x + threadIdx.x);
+        for (int u = 0; u < 8; ++u) {
+          const int idx = i0 + u * blockDim.x + threadIdx.x;
+          tt[u] = -1;
+          tu[u] = -INFINITY;
+          if (idx < total) {
+            const int b = blist[idx / per], q = idx % per;
+            const long long t = (long long)b * 4 + (q & 3) + (long long)(q >> 2) * 4 * a.nblk;
+            if (t < a.ptiles) { tt[u] = t; tu[u] = a.tile_u[t]; }
+          }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (tt[u] >= 0 && tu[u] != -INFINITY && (double)tu[u] >= lmax) {
+            const int slot = atomicAdd(&tcnt, 1);
+            if (slot < 1024) tlist[slot] = (int)tt[u];
+          }
+      }
+    } else {
+      // many blocks in play: scan all per-tile maxima, 16 independent loads at a time
+      for (long long t0 = 0; t0 < a.ptiles; t0 += 16LL * blockDim.x) {
+        float tu[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const long long t = t0 + (long long)u * blockDim.x + threadIdx.x;
+          tu[u] = t < a.ptiles ? a.tile_u[t] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (tu[u] != -INFINITY && (double)tu[u] >= lmax) {
+            const int slot = atomicAdd(&tcnt, 1);
+            if (slot < 1024) tlist[slot] = (int)(t0 + (long long)u * blockDim.x + threadIdx.x);
+          }
+      }
     }
     __syncthreads();
     const int ntl = tcnt;
     overflow = ntl > 1024;                     // too many tiles in play
     if (!overflow) {
-      // phase B2: the block scans each such tile together (coalesced loads of the tile's upper bounds)
-      for (int q = 0; q < ntl; ++q) {
+      // phase B2: one wave per such tile, all of the tile's upper bounds in flight at once (ptile = 256 / 512)
+      for (int q = wave; q < ntl; q += 4) {
         const long long t = tlist[q];
-        for (int i = threadIdx.x; i < a.ptile; i += blockDim.x) {
-          const float u = a.ub[t * a.ptile + i];
-          if (u != -INFINITY && (double)u >= lmax) {
-            const int slot = atomicAdd(&cnt, 1);
-            if (slot < a.cap) a.cand[slot] = t * a.ptile + i;
-          }
+        float u8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int i = lane + 64 * e;
+          u8[e] = i < a.ptile ? a.ub[t * a.ptile + i] : -INFINITY;
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (u8[e] != -INFINITY && (double)u8[e] >= lmax) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < a.cap) a.cand[slot] = t * a.ptile + lane + 64 * e;
+            if (slot < 32) scand[slot] = t * a.ptile + lane + 64 * e;
+          }
       }
       __syncthreads();
       overflow = cnt > a.cap;
@@ -491,11 +619,21 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw
   const int count = cnt;
   double bv = -INFINITY;
   long long bi = LLONG_MAX;
-  for (int j = threadIdx.x; j < count; j += blockDim.x) {
-    const long long r = a.cand[j];
-    const double sc = bc_exact_score<MODE>(a.tiles, a.v, r, a.s, a.norms[r], a.post_div);
-    const long long gi = a.row_offset + r;
-    if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
+  if (count <= 32) {
+    // the usual case, a handful of candidates: a wave per candidate
+    for (int j = wave; j < count; j += 4) {
+      const long long r = scand[j];
+      const double sc = bc_exact_score_wave<MODE>(a.tiles, a.v, r, a.s, a.norms[r], a.post_div, strips[wave]);
+      const long long gi = a.row_offset + r;
+      if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
+    }
+  } else {
+    for (int j = threadIdx.x; j < count; j += blockDim.x) {
+      const long long r = a.cand[j];
+      const double sc = bc_exact_score<MODE>(a.tiles, a.v, r, a.s, a.norms[r], a.post_div);
+      const long long gi = a.row_offset + r;
+      if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
+    }
   }
   bc_wave_argmax(bv, bi);
   __syncthreads();
@@ -553,6 +691,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const long long waves = (p->ptiles + rounds - 1) / rounds;
   p->grid = (int)((waves + 3) / 4);
   if (p->grid < 1) p->grid = 1;
+  if (p->grid > 1024) p->grid = 1024;       // k_rescore keeps the block bounds in 4 registers per thread
   // the fp64 tiles cover ntiles*128 rows; the unit rows cover ptiles*ptile >= that, reads past the fp64 tiles are masked by `live`
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -560,6 +699,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const size_t o_ub = take((size_t)p->ptiles * p->ptile * sizeof(float));
   const size_t o_tu = take((size_t)p->ptiles * sizeof(float));
   const size_t o_bl = take((size_t)p->grid * sizeof(double));
+  const size_t o_bu = take((size_t)p->grid * sizeof(float));
   const size_t o_c = take((size_t)p->cap * sizeof(long long));
   const size_t o_ctrl = take(256);
   const size_t o_sync = take(256);
@@ -571,6 +711,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->ub = (float*)(base + o_ub);
   p->tile_u = (float*)(base + o_tu);
   p->blk_l = (double*)(base + o_bl);
+  p->blk_u = (float*)(base + o_bu);
   p->cand = (long long*)(base + o_c);
   p->ctrl = (int*)(base + o_ctrl);
   p->sync = (unsigned*)(base + o_sync);
@@ -621,6 +762,7 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   a.ub = p->ub;
   a.tile_u = p->tile_u;
   a.blk_l = p->blk_l;
+  a.blk_u = p->blk_u;
   a.n_rows = phi->n_rows;
   a.ptiles = p->ptiles;
   a.post_div = post_div;
@@ -645,6 +787,8 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   r.ub = p->ub;
   r.tile_u = p->tile_u;
   r.blk_l = p->blk_l;
+  r.blk_u = p->blk_u;
+  r.tile_rounds = (int)((p->ptiles + 4LL * p->grid - 1) / (4LL * p->grid));
   r.cand = p->cand;
   r.ctrl = p->ctrl;
   r.rec = rec_dev;
