@@ -119,15 +119,14 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
   if (threadIdx.x == 0) npos_sh = 0;
   __syncthreads();
   int np = 0;
-  for (long long j = threadIdx.x; j < nnz; j += blockDim.x) np += (P.val[j] > 0.) ? 1 : 0;
-  if (np) atomicAdd(&npos_sh, np);
   if (s <= (int)blockDim.x) {
     const int G = blockDim.x / s;
     const int g = threadIdx.x / s, k = threadIdx.x - g * s;
     double acc = 0.0;
     if (g < G) {
       // 16 independent loads in flight per thread: the list lives in global memory (L2) and a dependent
-      // load per term would cost a full memory latency each
+      // load per term would cost a full memory latency each.  The k == 0 thread of each group also counts
+      // the positive weights it walks over (every list slot belongs to exactly one group).
       long long j = g;
       for (; j + 15 * (long long)G < nnz; j += 16 * (long long)G) {
         double v8[16], c8[16];
@@ -137,7 +136,10 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
           c8[u] = P.cols[(size_t)(j + u * (long long)G) * s + k];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = fma(v8[u], c8[u], acc);
+        for (int u = 0; u < 16; ++u) {
+          acc = fma(v8[u], c8[u], acc);
+          np += (v8[u] > 0.) ? 1 : 0;
+        }
       }
       for (; j + 3 * (long long)G < nnz; j += 4 * (long long)G) {
         double v4[4], c4[4];
@@ -147,9 +149,17 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
           c4[u] = P.cols[(size_t)(j + u * (long long)G) * s + k];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = fma(v4[u], c4[u], acc);
+        for (int u = 0; u < 4; ++u) {
+          acc = fma(v4[u], c4[u], acc);
+          np += (v4[u] > 0.) ? 1 : 0;
+        }
       }
-      for (; j < nnz; j += G) acc = fma(P.val[j], P.cols[(size_t)j * s + k], acc);
+      for (; j < nnz; j += G) {
+        const double vj = P.val[j];
+        acc = fma(vj, P.cols[(size_t)j * s + k], acc);
+        np += (vj > 0.) ? 1 : 0;
+      }
+      if (k == 0 && np) atomicAdd(&npos_sh, np);
     }
     part[threadIdx.x] = acc;
     __syncthreads();
@@ -172,6 +182,8 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
       }
     }
   } else {
+    for (long long j = threadIdx.x; j < nnz; j += blockDim.x) np += (P.val[j] > 0.) ? 1 : 0;
+    if (np) atomicAdd(&npos_sh, np);
     double e = 0.0, q = 0.0;
     for (int k = threadIdx.x; k < s; k += blockDim.x) {
       double acc = 0.0;
