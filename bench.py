@@ -195,9 +195,13 @@ def main():
                      'torch.distributed all-gather per step (%s)' % backend if eng_.exchange else 'none (single rank)')
     pref = int(alg.snnls._eng.prefilter)      # 0, or the storage precision of the streamed mirror (16 / 32)
     if pref:
-        # the sweep streams the fp32 / fp16 mirror of the normalised Phi (4 or 2 B/element) + the norms, and writes
-        # one fp32 upper bound per row; candidates are then rescored in fp64 (selections identical to the fp64 sweep)
-        k3_bytes = (pref / 8.0) * n_local * S + 8.0 * n_local + 4.0 * n_local
+        # fp16: the sweep streams the fp16 mirror of the normalised Phi (2 B/element, planes padded to a multiple of
+        # 10) and one live-mask byte per 8 rows; it writes only per-tile / per-block bounds.  fp32: 4 B/element + the
+        # norms, and one fp32 upper bound written per row.  Candidates are rescored in fp64 either way.
+        if pref == 16:
+            k3_bytes = 2.0 * n_local * (-(-S // 10) * 10) + n_local / 8.0
+        else:
+            k3_bytes = 4.0 * n_local * S + 8.0 * n_local + 4.0 * n_local
     else:
         k3_bytes = 8.0 * n_local * S + 8.0 * n_local      # one streaming read of Phi + the norms
     alg._pull()

@@ -38,6 +38,7 @@ struct bc_pref {
   bc_phi* phi = nullptr;
   float* u32 = nullptr;       // fp32: [ptiles][S][256]
   _Float16* u16 = nullptr;    // fp16: [ptiles][SP][512]
+  unsigned char* live = nullptr;   // fp16: [ptiles][64] live-row mask
   int prec = 32;              // 32 or 16
   int ptile = BC_PTILE;       // rows per pre-filter tile (256 for fp32, 512 for fp16)
   int sp = 0;                 // fp16: planes stored per tile
@@ -59,6 +60,7 @@ struct bc_pref {
 struct PrefArgs {
   const float* u32;
   const _Float16* u16;
+  const unsigned char* live; // fp16: [ptiles][64] bytes, bit q of byte l = row 8*l + q of the tile is live
   double delta;              // per-dot-product bound for unit ||v||
   int sp;                    // fp16: stored planes per tile (S padded to a multiple of BC_HU)
   const double* norms;
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256) void k_sweep_f16(PrefArgs a) {
       bc_h8 x[U], y[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+      const unsigned lv = a.live[t * 64 + lane];     // bit q: row 8*lane + q of the tile exists and has a non-zero norm
       for (int k = 0; k < SP; k += U) {
         const bool more = k + U < SP;
         if (more) {
@@ -256,25 +259,18 @@ __global__ __launch_bounds__(256) void k_sweep_f16(PrefArgs a) {
           for (int u = 0; u < U; ++u) x[u] = y[u];
         }
       }
-      const long long r = t * BC_HTILE + 8 * lane;
+      // Nothing is written per row: the per-row bounds of the (one or two) tiles that matter are recomputed by
+      // k_rescore from the same mirror.  A trickle of 4 B/row stores cost 15 % of the sweep's bandwidth, the
+      // 8 B/row norm reads another 5 %; the live mask is one byte per lane and tile.
       float tmax = -INFINITY;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        bc_f4 ub;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = 4 * h + j;
-          float uf = -INFINITY;
-          if (r + q < a.n_rows && a.norms[r + q] != 0.) {
-            double Ub, Lb;
-            bc_score_interval<MODE>((double)a0[q], (double)a1[q], delta, a.post_div, Ub, Lb);
-            uf = __double2float_ru(Ub);
-            best_l = fmax(best_l, Lb);
-          }
-          ub[j] = uf;
-          tmax = fmaxf(tmax, uf);
+      for (int q = 0; q < 8; ++q) {
+        if ((lv >> q) & 1u) {
+          double Ub, Lb;
+          bc_score_interval<MODE>((double)a0[q], (double)a1[q], delta, a.post_div, Ub, Lb);
+          tmax = fmaxf(tmax, __double2float_ru(Ub));
+          best_l = fmax(best_l, Lb);
         }
-        *reinterpret_cast<bc_f4*>(a.ub + r + 4 * h) = ub;
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_down(tmax, d, BC_WAVE));
@@ -292,15 +288,18 @@ __global__ __launch_bounds__(256) void k_sweep_f16(PrefArgs a) {
   }
 }
 
-// u16 tile builder: one block per 512-row tile, thread = two rows; planes S..SP-1 are zero
+// u16 tile builder: one block per 512-row tile, thread = two rows; planes S..SP-1 are zero.  Also the live mask.
 __global__ __launch_bounds__(256) void k_build_u16(const double* __restrict__ tiles, const double* __restrict__ norms,
-                                                  long long n_rows, int S, int SP, _Float16* __restrict__ u16) {
+                                                  long long n_rows, int S, int SP, _Float16* __restrict__ u16,
+                                                  unsigned char* __restrict__ live_mask) {
+  __shared__ unsigned char flags[BC_HTILE];
   const long long t = blockIdx.x;
   for (int h = 0; h < 2; ++h) {
     const int i = threadIdx.x + 256 * h;
     const long long r = t * BC_HTILE + i;
     const bool live = r < n_rows;
     const double nr = live ? norms[r] : 0.;
+    flags[i] = (live && nr != 0.) ? 1 : 0;
     const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
     _Float16* q = u16 + (size_t)t * SP * BC_HTILE + i;
     for (int k = 0; k < SP; ++k) {
@@ -308,6 +307,12 @@ __global__ __launch_bounds__(256) void k_build_u16(const double* __restrict__ ti
       if (k < S && live && nr != 0.) u = (_Float16)(float)(p[(size_t)k * BC_TILE] / nr);
       q[(size_t)k * BC_HTILE] = u;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    unsigned b = 0;
+    for (int q = 0; q < 8; ++q) b |= (unsigned)flags[8 * threadIdx.x + q] << q;
+    live_mask[t * 64 + threadIdx.x] = (unsigned char)b;
   }
 }
 
@@ -320,6 +325,11 @@ struct RescoreArgs {
   const float* tile_u;
   const double* blk_l;
   const float* blk_u;
+  const _Float16* u16;       // fp16 mode: the per-row bounds of candidate tiles are recomputed from the mirror
+  const unsigned char* live;
+  const double* v_norm;
+  double delta;
+  int sp;
   long long* cand;
   int* ctrl;
   double* rec;
@@ -433,10 +443,28 @@ __device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__
 //   sync[1]  arrivals of the helper blocks after their share of the fallback sweep (reset by block 0)
 // Every wait is bounded, so the grid drains even if the protocol were broken (ctrl[2] records a timeout).
 #define BC_RS_SPIN_LIMIT (1 << 24)
+#define BC_RS_TILE_LIMIT16 64   // fp16 mode recomputes candidate tiles (~3 us each): past this the fp64 sweep is cheaper
+typedef _Float16 bc_h2 __attribute__((ext_vector_type(2)));
 // polling load: relaxed (an acquire per poll would invalidate caches 255 blocks x every poll and slow
 // block 0 down); the one acquire fence follows once the awaited value has been seen
 __device__ __forceinline__ unsigned bc_ld_poll(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one plane of the fp32 chain for a thread's two rows (k_rescore's recomputation of a candidate tile)
+template <int MODE>
+__device__ __forceinline__ void bc_rs_accumulate(bc_h2 x, const double* __restrict__ v, int k, float (&a0)[2], float (&a1)[2]) {
+  if (MODE == 0) {
+    const float vx = (float)v[2 * k], vy = (float)v[2 * k + 1];
+    a0[0] = fmaf((float)x[0], vx, a0[0]);
+    a1[0] = fmaf((float)x[0], vy, a1[0]);
+    a0[1] = fmaf((float)x[1], vx, a0[1]);
+    a1[1] = fmaf((float)x[1], vy, a1[1]);
+  } else {
+    const float vx = (float)v[k];
+    a0[0] = fmaf((float)x[0], vx, a0[0]);
+    a0[1] = fmaf((float)x[1], vx, a0[1]);
+  }
 }
 
 // passes B + C: Lmax = max of the block lower bounds; candidates = rows whose upper bound reaches it (whole
@@ -557,9 +585,51 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw
     }
     __syncthreads();
     const int ntl = tcnt;
-    overflow = ntl > 1024;                     // too many tiles in play
-    if (!overflow) {
-      // phase B2: one wave per such tile, all of the tile's upper bounds in flight at once (ptile = 256 / 512)
+    overflow = ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
+    if (!overflow && a.u16) {
+      // phase B2 (fp16 mirror): recompute the per-row intervals of each such tile from the mirror -- the sweep
+      // wrote none.  Thread = two adjacent rows of the tile (one 4-byte load per plane, 1 KiB per plane and
+      // block), up to 64 planes in flight; fp32 chain, same interval formula and delta as the sweep.
+      const double delta = (MODE == 0) ? a.delta : a.delta * (*a.v_norm);
+      for (int q = 0; q < ntl; ++q) {
+        const long long t = tlist[q];
+        const bc_h2* __restrict__ tp = reinterpret_cast<const bc_h2*>(a.u16 + (size_t)t * a.sp * BC_HTILE) + threadIdx.x;
+        float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+        // sp is a multiple of BC_HU = 10: batches of 50 planes (all loads of a batch in flight), then of 10
+        int k0 = 0;
+        for (; k0 + 50 <= a.sp; k0 += 50) {
+          bc_h2 x[50];
+#pragma unroll
+          for (int u = 0; u < 50; ++u) x[u] = tp[(size_t)(k0 + u) * (BC_HTILE / 2)];
+#pragma unroll
+          for (int u = 0; u < 50; ++u) bc_rs_accumulate<MODE>(x[u], a.v, k0 + u, a0, a1);
+        }
+        for (; k0 < a.sp; k0 += BC_HU) {
+          bc_h2 x[BC_HU];
+#pragma unroll
+          for (int u = 0; u < BC_HU; ++u) x[u] = tp[(size_t)(k0 + u) * (BC_HTILE / 2)];
+#pragma unroll
+          for (int u = 0; u < BC_HU; ++u) bc_rs_accumulate<MODE>(x[u], a.v, k0 + u, a0, a1);
+        }
+        const unsigned lv = a.live[t * 64 + (threadIdx.x >> 2)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int i = 2 * threadIdx.x + j;                    // row within the tile
+          if ((lv >> (i & 7)) & 1u) {
+            double Ub, Lb;
+            bc_score_interval<MODE>((double)a0[j], (double)a1[j], delta, a.post_div, Ub, Lb);
+            if (Ub >= lmax) {
+              const int slot = atomicAdd(&cnt, 1);
+              if (slot < a.cap) a.cand[slot] = t * BC_HTILE + i;
+              if (slot < 32) scand[slot] = t * BC_HTILE + i;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      overflow = cnt > a.cap;
+    } else if (!overflow) {
+      // phase B2 (fp32 mirror): one wave per such tile, all of the tile's stored upper bounds in flight at once
       for (int q = wave; q < ntl; q += 4) {
         const long long t = tlist[q];
         float u8[8];
@@ -696,7 +766,8 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_u = take((size_t)p->ptiles * p->sp * p->ptile * (p->prec == 16 ? sizeof(_Float16) : sizeof(float)));
-  const size_t o_ub = take((size_t)p->ptiles * p->ptile * sizeof(float));
+  const size_t o_ub = take(p->prec == 16 ? 0 : (size_t)p->ptiles * p->ptile * sizeof(float));
+  const size_t o_lv = take(p->prec == 16 ? (size_t)p->ptiles * 64 : 0);
   const size_t o_tu = take((size_t)p->ptiles * sizeof(float));
   const size_t o_bl = take((size_t)p->grid * sizeof(double));
   const size_t o_bu = take((size_t)p->grid * sizeof(float));
@@ -708,7 +779,8 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   char* base = (char*)p->slab;
   p->u32 = p->prec == 32 ? (float*)(base + o_u) : nullptr;
   p->u16 = p->prec == 16 ? (_Float16*)(base + o_u) : nullptr;
-  p->ub = (float*)(base + o_ub);
+  p->ub = p->prec == 16 ? nullptr : (float*)(base + o_ub);
+  p->live = p->prec == 16 ? (unsigned char*)(base + o_lv) : nullptr;
   p->tile_u = (float*)(base + o_tu);
   p->blk_l = (double*)(base + o_bl);
   p->blk_u = (float*)(base + o_bu);
@@ -724,7 +796,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   if (e == hipSuccess) {
     if (p->prec == 16)
       hipLaunchKernelGGL(k_build_u16, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
-                         (long long)phi->n_rows, phi->s, p->sp, p->u16);
+                         (long long)phi->n_rows, phi->s, p->sp, p->u16, p->live);
     else
       hipLaunchKernelGGL(k_build_u32, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
                          (long long)phi->n_rows, phi->s, p->u32);
@@ -753,6 +825,7 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   PrefArgs a;
   a.u32 = p->u32;
   a.u16 = p->u16;
+  a.live = p->live;
   a.delta = p->prec == 16 ? bc_pref_delta16(phi->s) : BC_PREF_DELTA;
   a.sp = p->sp;
   a.norms = phi->norms;
@@ -788,6 +861,11 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   r.tile_u = p->tile_u;
   r.blk_l = p->blk_l;
   r.blk_u = p->blk_u;
+  r.u16 = p->u16;
+  r.live = p->live;
+  r.v_norm = v_norm_dev;
+  r.delta = a.delta;
+  r.sp = p->sp;
   r.tile_rounds = (int)((p->ptiles + 4LL * p->grid - 1) / (4LL * p->grid));
   r.cand = p->cand;
   r.ctrl = p->ctrl;
