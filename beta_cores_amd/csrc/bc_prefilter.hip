@@ -39,7 +39,12 @@ struct bc_pref {
   float* u32 = nullptr;       // fp32: [ptiles][S][256]
   _Float16* u16 = nullptr;    // fp16: [ptiles][SP][512]
   unsigned char* live = nullptr;   // fp16: [ptiles][64] live-row mask
-  int prec = 32;              // 32 or 16
+  int* u8 = nullptr;          // int8: [ptiles][sp4][256] dwords (bc_prefilter_i8.h)
+  float2* rowq = nullptr;     // int8: (scale, delta) per row
+  float2* tile_cand = nullptr;   // int8: [ptiles][4]
+  int* tile_ncand = nullptr;     // int8: [ptiles]
+  int sp4 = 0;                // int8: k-groups stored per tile
+  int prec = 32;              // 32, 16 or 8
   int ptile = BC_PTILE;       // rows per pre-filter tile (256 for fp32, 512 for fp16)
   int sp = 0;                 // fp16: planes stored per tile
   float* ub = nullptr;        // [ptiles*256] upper bounds of the last sweep
@@ -194,6 +199,8 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
 }
 
 
+#include "bc_prefilter_i8.h"
+
 // ---- fp16 variant.  Tile = 512 rows, [S][512] halfs: one sample of a tile = 1 KiB = 64 lanes x 8 halfs.
 #define BC_HTILE 512
 typedef _Float16 bc_h8 __attribute__((ext_vector_type(8)));
@@ -330,6 +337,8 @@ struct RescoreArgs {
   const double* v_norm;
   double delta;
   int sp;
+  const float2* tile_cand;   // int8 mode: the sweep left up to 4 (upper bound, row) pairs per tile
+  const int* tile_ncand;
   long long* cand;
   int* ctrl;
   double* rec;
@@ -585,8 +594,46 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw
     }
     __syncthreads();
     const int ntl = tcnt;
+    if (threadIdx.x == 0) bcnt = 0;            // reused by the int8 branch below
+    __syncthreads();
     overflow = ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
-    if (!overflow && a.u16) {
+    if (!overflow && a.tile_cand) {
+      // phase B2 (int8 mirror): the pairs the sweep left for each such tile; a tile with more than four local
+      // candidates hands over all of its rows
+      for (int q = threadIdx.x; q < ntl; q += blockDim.x) {
+        const long long t = tlist[q];
+        const int n = a.tile_ncand[t];
+        if (n <= 4) {
+          for (int i = 0; i < n; ++i) {
+            const float2 pr = a.tile_cand[t * 4 + i];
+            if ((double)pr.x >= lmax) {
+              const int slot = atomicAdd(&cnt, 1);
+              const long long row = t * a.ptile + (int)pr.y;
+              if (slot < a.cap) a.cand[slot] = row;
+              if (slot < 32) scand[slot] = row;
+            }
+          }
+        } else {
+          const int o = atomicAdd(&bcnt, 1);      // (bcnt is free again after phase B1)
+          if (o < 64) blist[o] = (int)t;
+        }
+      }
+      __syncthreads();
+      const int no = bcnt;
+      overflow = no > 64;
+      if (!overflow) {
+        for (int o = 0; o < no; ++o) {
+          const long long row = (long long)blist[o] * a.ptile + threadIdx.x;      // ptile == blockDim.x == 256
+          if (row < sw.n_rows && a.norms[row] != 0.) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < a.cap) a.cand[slot] = row;
+            if (slot < 32) scand[slot] = row;
+          }
+        }
+        __syncthreads();
+        overflow = cnt > a.cap;
+      }
+    } else if (!overflow && a.u16) {
       // phase B2 (fp16 mirror): recompute the per-row intervals of each such tile from the mirror -- the sweep
       // wrote none.  Thread = two adjacent rows of the tile (one 4-byte load per plane, 1 KiB per plane and
       // block), up to 64 planes in flight; fp32 chain, same interval formula and delta as the sweep.
@@ -746,9 +793,11 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   bc_pref* p = new bc_pref();
   p->ctx = ctx;
   p->phi = phi;
-  p->prec = prec == 16 ? 16 : 32;
-  p->ptile = p->prec == 16 ? BC_HTILE : BC_PTILE;
+  p->prec = prec == 16 ? 16 : (prec == 8 ? 8 : 32);
+  if (p->prec == 8 && (phi->s + 3) / 4 > BC_IMAXG - BC_IU) p->prec = 16;      // the digit table of k_sweep_i8 holds S <= ~1260
+  p->ptile = p->prec == 16 ? BC_HTILE : (p->prec == 8 ? BC_ITILE : BC_PTILE);
   p->sp = p->prec == 16 ? (phi->s + BC_HU - 1) / BC_HU * BC_HU : phi->s;
+  p->sp4 = ((phi->s + 3) / 4 + BC_IU - 1) / BC_IU * BC_IU;
   p->ptiles = (phi->n_rows + p->ptile - 1) / p->ptile;
   if (p->ptiles < 1) p->ptiles = 1;
   // one wave per tile and a grid-stride loop: size the grid so that all its waves are resident at once
@@ -765,8 +814,12 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   // the fp64 tiles cover ntiles*128 rows; the unit rows cover ptiles*ptile >= that, reads past the fp64 tiles are masked by `live`
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_u = take((size_t)p->ptiles * p->sp * p->ptile * (p->prec == 16 ? sizeof(_Float16) : sizeof(float)));
-  const size_t o_ub = take(p->prec == 16 ? 0 : (size_t)p->ptiles * p->ptile * sizeof(float));
+  const size_t o_u = take(p->prec == 8 ? (size_t)p->ptiles * p->sp4 * BC_ITILE * sizeof(int)
+                                       : (size_t)p->ptiles * p->sp * p->ptile * (p->prec == 16 ? sizeof(_Float16) : sizeof(float)));
+  const size_t o_ub = take(p->prec != 32 ? 0 : (size_t)p->ptiles * p->ptile * sizeof(float));
+  const size_t o_rq = take(p->prec == 8 ? (size_t)p->ptiles * BC_ITILE * sizeof(float2) : 0);
+  const size_t o_tc = take(p->prec == 8 ? (size_t)p->ptiles * 4 * sizeof(float2) : 0);
+  const size_t o_tn = take(p->prec == 8 ? (size_t)p->ptiles * sizeof(int) : 0);
   const size_t o_lv = take(p->prec == 16 ? (size_t)p->ptiles * 64 : 0);
   const size_t o_tu = take((size_t)p->ptiles * sizeof(float));
   const size_t o_bl = take((size_t)p->grid * sizeof(double));
@@ -779,7 +832,13 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   char* base = (char*)p->slab;
   p->u32 = p->prec == 32 ? (float*)(base + o_u) : nullptr;
   p->u16 = p->prec == 16 ? (_Float16*)(base + o_u) : nullptr;
-  p->ub = p->prec == 16 ? nullptr : (float*)(base + o_ub);
+  p->ub = p->prec != 32 ? nullptr : (float*)(base + o_ub);
+  if (p->prec == 8) {
+    p->u8 = (int*)(base + o_u);
+    p->rowq = (float2*)(base + o_rq);
+    p->tile_cand = (float2*)(base + o_tc);
+    p->tile_ncand = (int*)(base + o_tn);
+  }
   p->live = p->prec == 16 ? (unsigned char*)(base + o_lv) : nullptr;
   p->tile_u = (float*)(base + o_tu);
   p->blk_l = (double*)(base + o_bl);
@@ -794,7 +853,10 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   if (p->helpers_grid < 1) p->helpers_grid = 1;
   e = hipMemsetAsync(p->ctrl, 0, 512, ctx->stream);
   if (e == hipSuccess) {
-    if (p->prec == 16)
+    if (p->prec == 8)
+      hipLaunchKernelGGL(k_build_i8, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                         (long long)phi->n_rows, phi->s, p->sp4, p->u8, p->rowq);
+    else if (p->prec == 16)
       hipLaunchKernelGGL(k_build_u16, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
                          (long long)phi->n_rows, phi->s, p->sp, p->u16, p->live);
     else
@@ -842,7 +904,25 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   a.s = phi->s;
   int rc = bc_timer_begin(ctx, 0);
   if (rc) return rc;
-  if (p->prec == 16) {
+  if (p->prec == 8) {
+    I8Args ia;
+    ia.u8 = p->u8;
+    ia.rowq = p->rowq;
+    ia.v = v_dev;
+    ia.skip_flag = skip_flag;
+    ia.v_norm = v_norm_dev;
+    ia.tile_u = p->tile_u;
+    ia.tile_cand = p->tile_cand;
+    ia.tile_ncand = p->tile_ncand;
+    ia.blk_l = p->blk_l;
+    ia.blk_u = p->blk_u;
+    ia.ptiles = p->ptiles;
+    ia.post_div = post_div;
+    ia.s = phi->s;
+    ia.sp4 = p->sp4;
+    if (mode == 0) hipLaunchKernelGGL(k_sweep_i8<0>, dim3(p->grid), dim3(256), 0, ctx->stream, ia);
+    else hipLaunchKernelGGL(k_sweep_i8<1>, dim3(p->grid), dim3(256), 0, ctx->stream, ia);
+  } else if (p->prec == 16) {
     if (mode == 0) hipLaunchKernelGGL(k_sweep_f16<0>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_sweep_f16<1>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
   } else {
@@ -862,6 +942,8 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   r.blk_l = p->blk_l;
   r.blk_u = p->blk_u;
   r.u16 = p->u16;
+  r.tile_cand = p->tile_cand;
+  r.tile_ncand = p->tile_ncand;
   r.live = p->live;
   r.v_norm = v_norm_dev;
   r.delta = a.delta;

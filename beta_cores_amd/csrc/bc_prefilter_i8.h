@@ -1,0 +1,243 @@
+// K3 pre-filter, int8 mirror (BC_PREFILTER=8): one byte per element.
+//
+//   q[i, k] = rint( u[i, k] / scale_i ),  scale_i = max_k |u[i, k]| / 127,   u = Phi[i, :] / ||Phi[i, :]||
+//   rowq[i] = (scale_i, delta_i)   with delta_i >= || q[i, :] * scale_i - u[i, :] ||_2   measured at build time
+//
+// The sweep vectors are quantised per launch to 14 bits + sign, v^_k = (128 d0_k + d1_k) * vstep with int8
+// digits d0 in [-127, 127], d1 in [-64, 64] and vstep = max|v| / 16256, so that
+//   u^ . v^ = scale_i * vstep * (128 * sum_k q d0 + sum_k q d1)
+// is computed EXACTLY with v_dot4_i32_i8 (four products per instruction, no conversions in the loop), and
+//   | u^.v^ - u.v |  <=  delta_i ||v||  +  (1 + delta_i) * sqrt(S) * vstep / 2
+// bounds the distance to the fp64 kernel's dot product (Cauchy-Schwarz twice).  The interval formula and the
+// rest of the pipeline are those of the fp16 / fp32 mirrors (bc_prefilter.hip).
+//
+// Layout: tiles of 256 rows, [SP4][256] dwords, dword (g, r) = samples 4g..4g+3 of row r; lane l of the wave that
+// owns the tile holds rows 4l..4l+3, so one k-group of a tile is one 1 KiB dwordx4 load.  SP4 = ceil(S/4) rounded
+// up to a multiple of BC_IU (zero groups).  Bytes per row: 4*SP4 + 8.
+//
+// Candidates: the sweep writes nothing per row.  Per tile it stores the maximum upper bound and up to four
+// (upper bound, row) pairs -- the rows whose upper bound reaches the TILE's own best lower bound, a superset of
+// the rows that can reach the global one.  k_rescore reads the pairs of the tiles whose maximum reaches Lmax;
+// a tile with more than four such rows hands over all of its rows.
+#pragma once
+
+#define BC_ITILE 256
+#define BC_IU 5          // k-groups per batch (5 KiB in flight per wave and buffer)
+#define BC_IMAXG 320     // k-groups the digit table holds: S <= 1280
+typedef int bc_i4 __attribute__((ext_vector_type(4)));
+
+struct I8Args {
+  const int* u8;            // [ptiles][sp4][256]
+  const float2* rowq;       // [ptiles*256] (scale, delta); delta < 0: dead row (padding or zero norm)
+  const double* v;
+  const int* skip_flag;
+  const double* v_norm;     // dot mode: ||v|| from the solver state
+  float* tile_u;            // [ptiles]
+  float2* tile_cand;        // [ptiles][4] (upper bound, row-in-tile as float)
+  int* tile_ncand;          // [ptiles]
+  double* blk_l;
+  float* blk_u;
+  long long ptiles;
+  double post_div;
+  int s, sp4;
+};
+
+// one block per 256-row tile, thread = row
+__global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ tiles, const double* __restrict__ norms,
+                                                 long long n_rows, int S, int SP4, int* __restrict__ u8,
+                                                 float2* __restrict__ rowq) {
+  const long long t = blockIdx.x;
+  const long long r = t * BC_ITILE + threadIdx.x;
+  const bool live = r < n_rows && norms[r < n_rows ? r : 0] != 0.;
+  const double nr = live ? norms[r] : 1.;
+  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+  double mx = 0.;
+  bool has_nan = false;
+  if (live)
+    for (int k = 0; k < S; ++k) {
+      const double u = p[(size_t)k * BC_TILE] / nr;
+      has_nan |= !(fabs(u) <= 1.7976931348623157e308);   // NaN or inf
+      mx = fmax(mx, fabs(u));
+    }
+  const bool ok = live && !has_nan && mx > 0.;
+  const double scale = ok ? mx / 127. : 0.;
+  double err2 = 0.;
+  int* q = u8 + (size_t)t * SP4 * BC_ITILE + threadIdx.x;
+  for (int g = 0; g < SP4; ++g) {
+    unsigned w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * g + j;
+      int qi = 0;
+      if (ok && k < S) {
+        const double u = p[(size_t)k * BC_TILE] / nr;
+        qi = (int)rint(u / scale);
+        qi = qi > 127 ? 127 : (qi < -127 ? -127 : qi);
+        const double d = (double)qi * scale - u;
+        err2 = fma(d, d, err2);
+      }
+      w |= ((unsigned)qi & 0xffu) << (8 * j);
+    }
+    q[(size_t)g * BC_ITILE] = (int)w;
+  }
+  float2 rq;
+  if (!live) {
+    rq = make_float2(0.f, -1.f);
+  } else if (!ok) {
+    rq = make_float2(0.f, NAN);      // NaN / inf in the row (or a unit row that underflowed): kept, with [-inf, inf]
+  } else {
+    // rounded up, with room for the fp64 evaluation above and the float conversion of scale
+    const double sc_f = (double)(float)scale;
+    const double extra = fabs(sc_f - scale) * 127. * sqrt((double)S);   // the kernel multiplies by the float scale
+    rq = make_float2((float)scale, __double2float_ru((sqrt(err2) + extra) * (1. + 1e-6) + 1e-12));
+  }
+  rowq[r - 0] = rq;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
+  constexpr int NV = (MODE == 0) ? 4 : 2;           // (vector, digit) combinations
+  __shared__ __attribute__((aligned(16))) int dig[BC_IMAXG][4];   // packed digits of k-group g: [v0 d0, v0 d1, v1 d0, v1 d1]
+  __shared__ double vmx[2][4];
+  __shared__ double sl[4];
+  __shared__ float su[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double best_l = -INFINITY;
+  float umax = -INFINITY;
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
+  if (!skip) {
+    const int S = a.s, SP4 = a.sp4;
+    // ---- prologue: quantise the sweep vector(s) of this launch (every block does the same tiny job)
+    double m0 = 0., m1 = 0.;
+    for (int k = threadIdx.x; k < S; k += blockDim.x) {
+      if (MODE == 0) {
+        m0 = fmax(m0, fabs(a.v[2 * k]));
+        m1 = fmax(m1, fabs(a.v[2 * k + 1]));
+      } else {
+        m0 = fmax(m0, fabs(a.v[k]));
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      m0 = fmax(m0, __shfl_down(m0, d, BC_WAVE));
+      m1 = fmax(m1, __shfl_down(m1, d, BC_WAVE));
+    }
+    if (lane == 0) { vmx[0][wave] = m0; vmx[1][wave] = m1; }
+    __syncthreads();
+    const double vmax0 = fmax(fmax(vmx[0][0], vmx[0][1]), fmax(vmx[0][2], vmx[0][3]));
+    const double vmax1 = fmax(fmax(vmx[1][0], vmx[1][1]), fmax(vmx[1][2], vmx[1][3]));
+    // a NaN / inf in v makes every score NaN in the fp64 kernel: hand all rows over (delta = inf below)
+    const bool vbad = !(vmax0 < INFINITY) || !(vmax1 < INFINITY) || vmax0 != vmax0 || vmax1 != vmax1;
+    const double vstep0 = vmax0 / 16256., vstep1 = vmax1 / 16256.;
+    for (int g = threadIdx.x; g < SP4; g += blockDim.x) {
+      unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * g + j;
+        if (k < S && !vbad) {
+#pragma unroll
+          for (int vv = 0; vv < (MODE == 0 ? 2 : 1); ++vv) {
+            const double val = (MODE == 0) ? a.v[2 * k + vv] : a.v[k];
+            const double st = vv == 0 ? vstep0 : vstep1;
+            int Q = st > 0. ? (int)rint(val / st) : 0;
+            Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
+            const int d0 = (int)rint((double)Q / 128.);
+            const int d1 = Q - 128 * d0;
+            w[2 * vv] |= ((unsigned)d0 & 0xffu) << (8 * j);
+            w[2 * vv + 1] |= ((unsigned)d1 & 0xffu) << (8 * j);
+          }
+        }
+      }
+      dig[g][0] = (int)w[0]; dig[g][1] = (int)w[1]; dig[g][2] = (int)w[2]; dig[g][3] = (int)w[3];
+    }
+    __syncthreads();
+    const double vn = (MODE == 0) ? 1. : *a.v_norm;
+    const double rs = sqrt((double)S) * 0.5;
+    const double ev0 = rs * vstep0, ev1 = rs * vstep1;   // ||v^ - v|| bounds
+
+    constexpr int U = BC_IU;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < a.ptiles; t += (long long)gridDim.x * 4) {
+      const bc_i4* __restrict__ p = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
+      int acc[4][NV];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < NV; ++c) acc[j][c] = 0;
+      bc_i4 x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+      const float4 rq01 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane];
+      const float4 rq23 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane + 1];
+      for (int g0 = 0; g0 < SP4; g0 += U) {
+        const bool more = g0 + U < SP4;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p + (size_t)(g0 + U + u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bc_i4 dg = *reinterpret_cast<const bc_i4*>(&dig[g0 + u][0]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < NV; ++c) acc[j][c] = __builtin_amdgcn_sdot4(x[u][j], dg[c], acc[j][c], false);
+        }
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[u] = y[u];
+        }
+      }
+      // ---- per-row intervals (4 rows per lane)
+      const float sc[4] = {rq01.x, rq01.z, rq23.x, rq23.z};
+      const float dl[4] = {rq01.y, rq01.w, rq23.y, rq23.w};
+      double Ub[4], Lb[4];
+      double tl = -INFINITY;
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        Ub[j] = -INFINITY;
+        Lb[j] = -INFINITY;
+        if (!(dl[j] < 0.f)) {                           // live (a NaN delta counts as live and yields [-inf, inf])
+          const double scale = (double)sc[j], dr = (double)dl[j];
+          const double s0 = scale * vstep0 * (128. * (double)acc[j][0] + (double)acc[j][1]);
+          const double s1 = (MODE == 0) ? scale * vstep1 * (128. * (double)acc[j][2] + (double)acc[j][3]) : 0.;
+          double delta = fmax(dr * vn + (1. + dr) * ev0, (MODE == 0) ? dr * vn + (1. + dr) * ev1 : 0.) * (1. + 1e-9) + 1e-12;
+          if (vbad || dr != dr) delta = INFINITY;
+          if (delta == INFINITY) { Ub[j] = INFINITY; Lb[j] = -INFINITY; }
+          else bc_score_interval<MODE>(s0, s1, delta, a.post_div, Ub[j], Lb[j]);
+          tl = fmax(tl, Lb[j]);
+          tmax = fmaxf(tmax, __double2float_ru(Ub[j]));
+        }
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        tl = fmax(tl, __shfl_xor(tl, d, BC_WAVE));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, d, BC_WAVE));
+      }
+      // local candidates: rows whose upper bound reaches the tile's best lower bound (ballot compaction, <= 4 kept)
+      int base = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool c = Ub[j] >= tl && Ub[j] != -INFINITY;
+        const unsigned long long m = __ballot(c);
+        if (c) {
+          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (slot < 4) a.tile_cand[t * 4 + slot] = make_float2(__double2float_ru(Ub[j]), (float)(4 * lane + j));
+        }
+        base += __popcll(m);
+      }
+      if (lane == 0) {
+        a.tile_u[t] = tmax;
+        a.tile_ncand[t] = base;
+      }
+      best_l = fmax(best_l, tl);
+      umax = fmaxf(umax, tmax);
+    }
+  }
+  if (lane == 0) { sl[wave] = best_l; su[wave] = umax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+    a.blk_u[blockIdx.x] = fmaxf(fmaxf(su[0], su[1]), fmaxf(su[2], su[3]));
+  }
+}

@@ -912,12 +912,12 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "snnls init", __FILE__, __LINE__); }
   // reduced-precision pre-filter: worth its extra launches once the sweep is long enough.
-  // BC_PREFILTER = 0 (off) / 1 (on, default precision) / 16 / 32 (on, that storage precision)
+  // BC_PREFILTER = 0 (off) / 1 (on, default precision) / 8 / 16 / 32 (on, that storage precision)
   const char* env = getenv("BC_PREFILTER");
   const int req = env ? atoi(env) : -1;
   const bool want = env ? req != 0 : phi->n_rows >= 393216;   // measured break-even ~262k rows at S = 100
   if (want && phi->n_rows > 0) {
-    rc = bc_pref_create(phi, req == 16 ? 16 : (req == 32 ? 32 : BC_PREF_DEFAULT_PREC), &h->pref);
+    rc = bc_pref_create(phi, (req == 8 || req == 16 || req == 32) ? req : BC_PREF_DEFAULT_PREC, &h->pref);
     if (rc) { bc_snnls_destroy(h); return rc; }
     const char* cap = getenv("BC_PREFILTER_CAP");
     if (cap) bc_pref_set_cap(h->pref, atoi(cap));

@@ -12,7 +12,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[32, 16])
+@pytest.fixture(params=[32, 16, 8])
 def prec(request):
     return request.param
 
@@ -30,7 +30,7 @@ class prefilter:
 
     def __enter__(self):
         self.old = (os.environ.get('BC_PREFILTER'), os.environ.get('BC_PREFILTER_CAP'))
-        os.environ['BC_PREFILTER'] = str(int(self.on))        # 0 = off, 16 / 32 = storage precision
+        os.environ['BC_PREFILTER'] = str(int(self.on))        # 0 = off, 8 / 16 / 32 = storage precision
         if self.cap is not None:
             os.environ['BC_PREFILTER_CAP'] = str(self.cap)
         else:
@@ -182,7 +182,7 @@ def test_million_rows_identical(bc):
     data = bc.DeviceData.from_torch(Z)
     phi = bc.DeviceProjector(lambda k, w, p: th, s, bc.likelihoods.LinearRegression(1.0)).project(data)
     out = []
-    for on in (32, 16, 0):
+    for on in (32, 16, 8, 0):
         with prefilter(on):
             sv = bc.snnls.GIGA(phi.T, phi.colsum())
         assert sv._eng.prefilter == on
