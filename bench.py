@@ -212,6 +212,8 @@ def main():
     err = alg.error()
     f_tr, st_tr, _ = alg.snnls._eng.trace()
 
+    pname = 'int8' if pref == 8 else 'fp%d' % pref
+    kname = 'k_sweep_i8' if pref == 8 else 'k_sweep_f%d' % pref
     out = None
     if rank == 0:
         ach = k3_bytes / (k3_ms_per * 1e-3) / 1e9 if k3_ms_per > 0 else 0.0
@@ -220,7 +222,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            key = 'k_sweep_f%d' % pref if pref else 'k_sweep'
+            key = ('k_sweep_i8' if pref == 8 else 'k_sweep_f%d' % pref) if pref else 'k_sweep'
             if tj['config'] == {'N': N, 'D': D, 'S': S, 'n_gpus': world} and args.alg == 'giga' and key in tj:
                 traffic = tj[key]['traffic_bytes_per_launch']
                 traffic_src = 'profiles/r01_pmc_traffic.json: ' + tj[key]['correction']
@@ -234,9 +236,9 @@ def main():
                                    % (N, D, S, args.alg.upper()),
                        'N': N, 'D': D, 'S': S, 'M': total, 'rows_per_gpu': n_local, 'parallelism': 'rows/%d' % world,
                        'exchange': exchange_kind,
-                       'sweep': 'fp%d pre-filter + exact fp64 rescoring (bit-identical selections)' % pref if pref else 'fp64'},
-            'roofline': {'kernel': ('k_sweep_f%d<%s> (K3 fp%d pre-filter sweep; winners rescored in fp64, selections '
-                                    'identical to the fp64 sweep)' % (pref, 'GIGA' if args.alg == 'giga' else 'dot', pref)
+                       'sweep': '%s pre-filter + exact fp64 rescoring (bit-identical selections)' % pname if pref else 'fp64'},
+            'roofline': {'kernel': ('%s<%s> (K3 %s pre-filter sweep; winners rescored in fp64, selections '
+                                    'identical to the fp64 sweep)' % (kname, 'GIGA' if args.alg == 'giga' else 'dot', pname)
                                     if pref else 'k_sweep<%s> (K3 score+argmax)' % ('GIGA' if args.alg == 'giga' else 'dot')),
                          'fp64_formulation_bytes_per_launch': 8.0 * n_local * S + 8.0 * n_local,
                          'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

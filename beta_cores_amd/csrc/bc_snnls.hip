@@ -17,7 +17,7 @@
 #include <algorithm>
 
 int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, const int* skip_flag, double* rec_dev);
-#define BC_PREF_DEFAULT_PREC 16
+#define BC_PREF_DEFAULT_PREC 8
 #define BC_V_PAD 16            // >= BC_HU - 1 (bc_prefilter.hip): doubles of zero padding after the sweep vector(s)
 struct bc_comm;
 int bc_comm_all_gather_dev(bc_comm* c, const double* send_dev, double* recv_dev, size_t count);
