@@ -42,6 +42,32 @@ struct I8Args {
   int s, sp4;
 };
 
+// The interval of bc_score_interval evaluated in fp32.  The int8 mirror's delta is ~1e-2, five orders of magnitude
+// above fp32 rounding, so single precision costs nothing in selectivity; every fp32 evaluation error is covered
+// explicitly: g = 1 - s1^2 carries an absolute error <= 2^-23, i.e. a relative one <= 2^-23 / c (c <= g), rsq and
+// the products add <= 4e-7, and the slope term is inflated by another 0.2 %.  Rows with c <= 1e-3 are "uncertain".
+template <int MODE>
+__device__ __forceinline__ void bc_score_interval_f32(float s0, float s1, float delta, float post_div, float& U, float& L) {
+  if (MODE == 0) {
+    const float a = fabsf(s1) + delta;
+    const float c = 1.f - a * a;
+    if (!(s0 == s0) || !(s1 == s1) || !(c > 1e-3f)) { U = INFINITY; L = -INFINITY; return; }
+    const float rc2 = __frcp_rn(c) * 1.000001f;             // >= 1/c
+    const float rc = sqrtf(rc2) * 1.000001f;                // >= 1/sqrt(c)
+    const float f = s0 * __frsqrt_rn(1.f - s1 * s1);
+    const float e = delta * (rc + (fabsf(s0) + delta) * a * rc * rc2) * 1.003f + fabsf(f) * (6.1e-8f * rc2 + 6e-7f) + 2e-7f;
+    U = f + e;
+    L = f - e;
+  } else {
+    if (!(s0 == s0)) { U = INFINITY; L = -INFINITY; return; }
+    const float ip = __frcp_rn(fabsf(post_div)) * 1.000001f;
+    const float f = s0 / post_div;
+    const float e = (delta * 1.002f + 3e-7f * fabsf(s0)) * ip + 2e-7f * fabsf(f) + 1e-30f;
+    U = f + e;
+    L = f - e;
+  }
+}
+
 // one block per 256-row tile, thread = row
 __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ tiles, const double* __restrict__ norms,
                                                  long long n_rows, int S, int SP4, int* __restrict__ u8,
@@ -99,14 +125,26 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
   constexpr int NV = (MODE == 0) ? 4 : 2;           // (vector, digit) combinations
   __shared__ __attribute__((aligned(16))) int dig[BC_IMAXG][4];   // packed digits of k-group g: [v0 d0, v0 d1, v1 d0, v1 d1]
   __shared__ double vmx[2][4];
-  __shared__ double sl[4];
+  __shared__ float sl[4];
   __shared__ float su[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double best_l = -INFINITY;
+  float best_l = -INFINITY;
   float umax = -INFINITY;
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
   if (!skip) {
     const int S = a.s, SP4 = a.sp4;
+    constexpr int U = BC_IU;
+    // the first tile's loads do not depend on the prologue: put them in flight before it
+    long long t = (long long)blockIdx.x * 4 + wave;
+    bc_i4 x[U], y[U];
+    float4 rq01 = make_float4(0.f, -1.f, 0.f, -1.f), rq23 = rq01;
+    if (t < a.ptiles) {
+      const bc_i4* __restrict__ p0 = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p0 + (size_t)u * 64);
+      rq01 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane];
+      rq23 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane + 1];
+    }
     // ---- prologue: quantise the sweep vector(s) of this launch (every block does the same tiny job)
     double m0 = 0., m1 = 0.;
     for (int k = threadIdx.x; k < S; k += blockDim.x) {
@@ -153,21 +191,25 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
     __syncthreads();
     const double vn = (MODE == 0) ? 1. : *a.v_norm;
     const double rs = sqrt((double)S) * 0.5;
-    const double ev0 = rs * vstep0, ev1 = rs * vstep1;   // ||v^ - v|| bounds
+    // fp32 copies, each rounded UP where it enters a bound
+    const float fvn = __double2float_ru(vn), fev0 = __double2float_ru(rs * vstep0), fev1 = __double2float_ru(rs * vstep1);   // ||v||, ||v^ - v||
+    const float fvs0 = (float)vstep0, fvs1 = (float)vstep1, fpd = (float)a.post_div;
 
-    constexpr int U = BC_IU;
-    for (long long t = (long long)blockIdx.x * 4 + wave; t < a.ptiles; t += (long long)gridDim.x * 4) {
+    bool first = true;
+    for (; t < a.ptiles; t += (long long)gridDim.x * 4) {
       const bc_i4* __restrict__ p = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
       int acc[4][NV];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < NV; ++c) acc[j][c] = 0;
-      bc_i4 x[U], y[U];
+      if (!first) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
-      const float4 rq01 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane];
-      const float4 rq23 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane + 1];
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+        rq01 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane];
+        rq23 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane + 1];
+      }
+      first = false;
       for (int g0 = 0; g0 < SP4; g0 += U) {
         const bool more = g0 + U < SP4;
         if (more) {
@@ -187,31 +229,31 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
           for (int u = 0; u < U; ++u) x[u] = y[u];
         }
       }
-      // ---- per-row intervals (4 rows per lane)
+      // ---- per-row intervals (4 rows per lane), fp32 with explicit slack (bc_score_interval_f32)
       const float sc[4] = {rq01.x, rq01.z, rq23.x, rq23.z};
       const float dl[4] = {rq01.y, rq01.w, rq23.y, rq23.w};
-      double Ub[4], Lb[4];
-      double tl = -INFINITY;
-      float tmax = -INFINITY;
+      float Ub[4], Lb[4];
+      float tl = -INFINITY, tmax = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         Ub[j] = -INFINITY;
         Lb[j] = -INFINITY;
         if (!(dl[j] < 0.f)) {                           // live (a NaN delta counts as live and yields [-inf, inf])
-          const double scale = (double)sc[j], dr = (double)dl[j];
-          const double s0 = scale * vstep0 * (128. * (double)acc[j][0] + (double)acc[j][1]);
-          const double s1 = (MODE == 0) ? scale * vstep1 * (128. * (double)acc[j][2] + (double)acc[j][3]) : 0.;
-          double delta = fmax(dr * vn + (1. + dr) * ev0, (MODE == 0) ? dr * vn + (1. + dr) * ev1 : 0.) * (1. + 1e-9) + 1e-12;
-          if (vbad || dr != dr) delta = INFINITY;
-          if (delta == INFINITY) { Ub[j] = INFINITY; Lb[j] = -INFINITY; }
-          else bc_score_interval<MODE>(s0, s1, delta, a.post_div, Ub[j], Lb[j]);
-          tl = fmax(tl, Lb[j]);
-          tmax = fmaxf(tmax, __double2float_ru(Ub[j]));
+          const float dr = dl[j];
+          // u^.v^ : exact integers, scaled in fp32 (relative error < 3e-7, covered below)
+          const float s0 = sc[j] * fvs0 * (128.f * (float)acc[j][0] + (float)acc[j][1]);
+          const float s1 = (MODE == 0) ? sc[j] * fvs1 * (128.f * (float)acc[j][2] + (float)acc[j][3]) : 0.f;
+          float delta = fmaxf(dr * fvn + (1.f + dr) * fev0, (MODE == 0) ? dr * fvn + (1.f + dr) * fev1 : 0.f) * 1.00001f
+                        + 4e-7f * fmaxf(fabsf(s0), fabsf(s1)) + 1e-12f;
+          if (vbad || dr != dr) { Ub[j] = INFINITY; Lb[j] = -INFINITY; }
+          else bc_score_interval_f32<MODE>(s0, s1, delta, fpd, Ub[j], Lb[j]);
+          tl = fmaxf(tl, Lb[j]);
+          tmax = fmaxf(tmax, Ub[j]);
         }
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
-        tl = fmax(tl, __shfl_xor(tl, d, BC_WAVE));
+        tl = fmaxf(tl, __shfl_xor(tl, d, BC_WAVE));
         tmax = fmaxf(tmax, __shfl_xor(tmax, d, BC_WAVE));
       }
       // local candidates: rows whose upper bound reaches the tile's best lower bound (ballot compaction, <= 4 kept)
@@ -222,7 +264,7 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         const unsigned long long m = __ballot(c);
         if (c) {
           const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (slot < 4) a.tile_cand[t * 4 + slot] = make_float2(__double2float_ru(Ub[j]), (float)(4 * lane + j));
+          if (slot < 4) a.tile_cand[t * 4 + slot] = make_float2(Ub[j], (float)(4 * lane + j));
         }
         base += __popcll(m);
       }
@@ -230,14 +272,14 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         a.tile_u[t] = tmax;
         a.tile_ncand[t] = base;
       }
-      best_l = fmax(best_l, tl);
+      best_l = fmaxf(best_l, tl);
       umax = fmaxf(umax, tmax);
     }
   }
   if (lane == 0) { sl[wave] = best_l; su[wave] = umax; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.blk_l[blockIdx.x] = fmax(fmax(sl[0], sl[1]), fmax(sl[2], sl[3]));
+    a.blk_l[blockIdx.x] = (double)fmaxf(fmaxf(sl[0], sl[1]), fmaxf(sl[2], sl[3]));
     a.blk_u[blockIdx.x] = fmaxf(fmaxf(su[0], su[1]), fmaxf(su[2], su[3]));
   }
 }
