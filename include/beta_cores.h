@@ -159,9 +159,9 @@ int bc_phi_argmax(bc_phi* phi, int mode, const double* v, double post_div, int64
 int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int alg, double norm_sum,
                     int allow_zero_rows, bc_snnls** out);
 int bc_snnls_destroy(bc_snnls* h);
-/* *on = 0, or the storage precision (16 / 32) of the mirror of Phi this solver's sweeps stream through the
- * reduced-precision pre-filter (bc_prefilter.hip): fp16 for shards of >= 393216 rows by default;
- * BC_PREFILTER=0 / 16 / 32 in the environment forces it.  Selections and weights are identical either way
+/* *on = 0, or the storage precision (8 / 16 / 32 bits per element) of the mirror of Phi this solver's sweeps
+ * stream through the reduced-precision pre-filter (bc_prefilter.hip): int8 for shards of >= 393216 rows by
+ * default; BC_PREFILTER=0 / 8 / 16 / 32 in the environment forces it.  Selections and weights are identical either way
  * (candidates are rescored from the fp64 Phi with the arithmetic of the fp64 sweep). */
 int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
 /* Diagnostic: how many sweeps since creation overflowed the pre-filter's candidate list and were redone,
