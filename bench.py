@@ -255,6 +255,7 @@ def main():
             'posterior_gram': {'kernel_ms': k4_ms / max(k4_n, 1), 'wall_ms': 1e3 * t_post,
                                'tflops': 2.0 * n_local * (D + 1) * (D + 1) / max(k4_ms / max(k4_n, 1), 1e-9) / 1e9,
                                'note': 'K4 X^T W X on fp64 MFMA, all local rows, w = 1 (sampler set-up, untimed)'},
+            'prefilter': dict(zip(('sweeps', 'candidates_rescored', 'fp64_fallbacks'), alg.snnls._eng.prefilter_stats())),
             'solver_init_ms': 1e3 * t_init, 'setup_s': t_setup,
             'coreset': {'size': int(len(idcs)), 'error': err, 'failed_steps': int(st_tr.sum())},
         }

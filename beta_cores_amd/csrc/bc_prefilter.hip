@@ -52,7 +52,8 @@ struct bc_pref {
   double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
   float* blk_u = nullptr;     // [grid] block maxima of the upper bounds (lets the selection skip whole blocks of tiles)
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
-  int* ctrl = nullptr;        // [1] the last launch fell back to the fp64 sweep, [2] hand-shake timeout, [3] fallbacks so far
+  int* ctrl = nullptr;        // [1] the last launch fell back to the fp64 sweep, [2] hand-shake timeout, [3] fallbacks so far,
+                              // [4..5] sweeps so far (u64), [6..7] candidates rescored so far (u64)
   unsigned* sync = nullptr;   // in-launch hand-shake of k_rescore (verdict, arrivals)
   unsigned epoch = 0;         // launch sequence number of k_rescore
   int helpers_grid = 1;       // blocks of k_rescore: block 0 + fallback helpers
@@ -603,10 +604,14 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw
       for (int q = threadIdx.x; q < ntl; q += blockDim.x) {
         const long long t = tlist[q];
         const int n = a.tile_ncand[t];
+        float2 prs[4];                           // fetched together with the count: one round trip
+#pragma unroll
+        for (int i = 0; i < 4; ++i) prs[i] = a.tile_cand[t * 4 + i];
         if (n <= 4) {
-          for (int i = 0; i < n; ++i) {
-            const float2 pr = a.tile_cand[t * 4 + i];
-            if ((double)pr.x >= lmax) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float2 pr = prs[i];
+            if (i < n && (double)pr.x >= lmax) {
               const int slot = atomicAdd(&cnt, 1);
               const long long row = t * a.ptile + (int)pr.y;
               if (slot < a.cap) a.cand[slot] = row;
@@ -701,6 +706,11 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw
   if (threadIdx.x == 0) {
     a.ctrl[1] = overflow ? 1 : 0;              // observable: the last launch fell back
     if (overflow) a.ctrl[3] += 1;              // ... and how often since creation
+    if (!skip) {                               // diagnostics: sweeps and candidates rescored since creation
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(a.ctrl + 4);
+      st[0] += 1;
+      st[1] += overflow ? 0 : (unsigned long long)cnt;
+    }
     if (gridDim.x > 1) {
       __threadfence();
       __hip_atomic_store(sync, 4u * epoch + (overflow ? 1u : 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

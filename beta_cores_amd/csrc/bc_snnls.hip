@@ -944,6 +944,23 @@ extern "C" int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n) {
   return BC_OK;
 }
 
+extern "C" int bc_snnls_prefilter_stats(const bc_snnls* h, int64_t* sweeps, int64_t* candidates, int64_t* fallbacks) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  if (sweeps) *sweeps = 0;
+  if (candidates) *candidates = 0;
+  if (fallbacks) *fallbacks = 0;
+  if (!h->pref) return BC_OK;
+  int ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  BC_HIP(hipMemcpyAsync(ctrl, bc_pref_ctrl(h->pref), sizeof(ctrl), hipMemcpyDeviceToHost, h->ctx->stream));
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  unsigned long long st[2];
+  memcpy(st, ctrl + 4, sizeof(st));
+  if (sweeps) *sweeps = (int64_t)st[0];
+  if (candidates) *candidates = (int64_t)st[1];
+  if (fallbacks) *fallbacks = ctrl[3];
+  return BC_OK;
+}
+
 extern "C" int bc_snnls_set_tolerance(bc_snnls* h, double tol) {
   if (!h) return BC_INVALID_ARGUMENT;
   h->d.tol = tol;

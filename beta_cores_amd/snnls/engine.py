@@ -150,6 +150,12 @@ class HipEngine:
         N.call('bc_snnls_prefilter_fallbacks', self.h, C.byref(n))
         return int(n.value)
 
+    def prefilter_stats(self):
+        """(sweeps, candidates handed to the exact rescoring, fp64 fallbacks) since this solver was created."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        N.call('bc_snnls_prefilter_stats', self.h, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
     def trace(self):
         n = C.c_int64()
         N.call('bc_snnls_trace', self.h, 0, None, None, None, C.byref(n))

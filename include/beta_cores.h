@@ -167,6 +167,9 @@ int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
 /* Diagnostic: how many sweeps since creation overflowed the pre-filter's candidate list and were redone,
  * inside the same launch, by the full fp64 sweep. */
 int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n);
+/* Diagnostic: sweeps run through the pre-filter since creation, rows it handed to the exact fp64 rescoring in
+ * total (candidates / sweeps = how selective the reduced-precision bounds are on this data), and fallbacks. */
+int bc_snnls_prefilter_stats(const bc_snnls* h, int64_t* sweeps, int64_t* candidates, int64_t* fallbacks);
 /* bayesiancoresets/util/__init__.py:4-7 (TOL, set_tolerance); default 1e-12 */
 int bc_snnls_set_tolerance(bc_snnls* h, double tol);
 /* multi-rank: device buffers (world*(S+4) and (S+4) doubles) through which the
