@@ -111,7 +111,10 @@ struct bc_snnls {
 
 // xw = sum_j val[j] * cols[j], err = ||xw - b||, ||xw||^2 and the positive count.  The list is split over
 // G = blockDim/S thread groups (fixed split => deterministic), partial vectors are combined in group order.
-__device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
+// PF: the first 16 terms of every thread's share come from `c16` (cols prefetched at kernel start, slot u <->
+// list entry g + u*G) except the entry appended in this very step (`at_new`), whose column is P.xf.
+template <bool PF>
+__device__ void dev_xw_err_t(const SnnlsDev& P, SnnlsState& S, double* red, const double (&c16)[16], long long at_new) {
   __shared__ double part[BC_FIN_THREADS];
   __shared__ int npos_sh;
   const int s = P.s;
@@ -128,6 +131,18 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
       // load per term would cost a full memory latency each.  The k == 0 thread of each group also counts
       // the positive weights it walks over (every list slot belongs to exactly one group).
       long long j = g;
+      if (PF) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (j < nnz) {
+            const double vj = P.val[j];
+            const double cv = (j == at_new) ? P.xf[k] : c16[u];
+            acc = fma(vj, cv, acc);
+            np += (vj > 0.) ? 1 : 0;
+            j += G;
+          }
+        }
+      }
       for (; j + 15 * (long long)G < nnz; j += 16 * (long long)G) {
         double v8[16], c8[16];
 #pragma unroll
@@ -202,6 +217,11 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
     }
   }
   __syncthreads();
+}
+
+__device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
+  const double none[16] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+  dev_xw_err_t<false>(P, S, red, none, -1);
 }
 
 // vectors for the next sweep.  GIGA: giga.py:21-30 ; FW / OMP: residual b - A.w          (wave 0 + one barrier)
@@ -596,6 +616,133 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P0, int
     for (int k = threadIdx.x; k < s; k += blockDim.x) P0.xw[k] = P.xw[k];
   if (threadIdx.x == 0) {
     S.sel_valid = 0;      // the picked column lived in LDS: a later step-wise reweight must fetch it again
+    *P0.st = S;
+  }
+}
+
+// The same step with ONE round of global loads up front: state, S-vectors, all candidate records (with their
+// columns), the weight list (val, idx) and each thread's first 16 list columns are requested before anything is
+// consumed, then the step runs out of LDS / registers and the results are written back at the end.  The plain
+// kernel above pays a memory latency per phase (state -> records -> column -> list -> columns ...), ~7 dependent
+// round trips; both produce the same bits (same device functions, same orders).  Used when the list and the records
+// fit the LDS budget (nnz_hint + 1 <= BC_PF_MAXNNZ, world * rec_len <= BC_PF_MAXREC, S <= blockDim).
+#define BC_PF_MAXNNZ 1024
+#define BC_PF_MAXREC 2048
+template <int ALG>
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, int nnz_hint) {
+  extern __shared__ double pf_lds[];
+  __shared__ SnnlsState S;
+  __shared__ double red[64];
+  __shared__ int sh_fail;
+  const int s = P0.s;
+  const int nrec = P0.fuse_winner ? 0 : P0.world * P0.rec_len;
+  double* l_b = pf_lds;
+  double* l_bn = l_b + s;
+  double* l_xw = l_bn + s;
+  double* l_xf = l_xw + s;
+  double* l_xwp = l_xf + s;
+  double* l_rec = l_xwp + s;
+  double* l_val = l_rec + nrec;
+  long long* l_idx = reinterpret_cast<long long*>(l_val + (nnz_hint + 1));
+  // ---- one round of loads
+  if (threadIdx.x == 0) S = *P0.st;
+  for (int k = threadIdx.x; k < s; k += blockDim.x) {
+    l_b[k] = P0.b[k];
+    l_bn[k] = P0.bn[k];
+    l_xw[k] = P0.xw[k];
+  }
+  for (int i = threadIdx.x; i < nrec; i += blockDim.x) l_rec[i] = P0.cand_all[i];
+  for (int j = threadIdx.x; j < nnz_hint; j += blockDim.x) {
+    l_val[j] = P0.val[j];
+    l_idx[j] = P0.idx[j];
+  }
+  const int G = blockDim.x / s;
+  const int g = threadIdx.x / s, kk = threadIdx.x - g * s;
+  double c16[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    c16[u] = 0.;
+    if (g < G && nnz_hint > 0) {
+      long long j = g + (long long)u * G;
+      j = j < nnz_hint ? j : nnz_hint - 1;          // clamped: always a valid slot, unused when past the list
+      c16[u] = P0.cols[(size_t)j * s + kk];
+    }
+  }
+  __syncthreads();
+  SnnlsDev P = P0;
+  P.b = l_b;
+  P.bn = l_bn;
+  P.xw = l_xw;
+  P.xf = l_xf;
+  P.xw_prev = l_xwp;
+  P.val = l_val;
+  P.idx = l_idx;
+  if (nrec) P.cand_all = l_rec;
+  if (S.reached_limit) return;                       // snnls.py:32-34 / :73-74
+  if (S.nnz > nnz_hint) {                            // the host's bound on the list length was wrong: refuse
+    if (threadIdx.x == 0) { S.overflow = 1; *P0.st = S; }
+    return;
+  }
+  const bool guard = S.npos > 0;                     // snnls.py:44-45
+  int fail = S.select_fail;                          // _select raised
+  long long f = -1;
+  bool wrote = false;
+  const long long nnz0 = S.nnz, npos0 = S.npos;
+  const double err0 = S.err_cur, xwsq0 = S.xw_sq;
+  if (!fail) {
+    if (P.fuse_winner) dev_pick_blocks(P, S);
+    else dev_pick<ALG>(P, S, red);
+    if (!S.sel_valid) fail = 1;
+    f = S.sel_f;
+  }
+  if (!fail) {
+    double alpha = 0., beta = 0.;
+    fail = dev_step_sizes<ALG>(P, S, red, alpha, beta);
+    if (!fail) {
+      for (int k = threadIdx.x; k < s; k += blockDim.x) P.xw_prev[k] = P.xw[k];
+      dev_apply(P, S, alpha, beta);                  // on the LDS copy of (val, idx); a new column goes to global cols
+      const long long at_new = (S.nnz == nnz0 + 1) ? nnz0 : -1;
+      dev_xw_err_t<true>(P, S, red, c16, at_new);
+      wrote = true;
+      if (guard) {
+        if (S.err_cur > err0) {                      // snnls.py:58-61: nothing was written back yet, just drop it
+          for (int k = threadIdx.x; k < s; k += blockDim.x) P.xw[k] = P.xw_prev[k];
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            S.nnz = nnz0;
+            S.npos = npos0;
+            S.err_cur = err0;
+            S.xw_sq = xwsq0;
+          }
+          fail = 1;
+          wrote = false;
+        } else if (threadIdx.x == 0) {
+          S.retried = 0;                             // snnls.py:62
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (fail) {                                      // snnls.py:63-72
+      if (S.retried) S.reached_limit = 1;
+      else S.retried = 1;
+    }
+    sh_fail = fail;
+  }
+  __syncthreads();
+  dev_trace(P, S, f, sh_fail);
+  __syncthreads();
+  dev_prep<ALG>(P, S, red);
+  // ---- write back
+  for (int k = threadIdx.x; k < s; k += blockDim.x) P0.xw[k] = P.xw[k];
+  if (wrote) {
+    const long long nnz = S.nnz;
+    for (long long j = threadIdx.x; j < nnz; j += blockDim.x) P0.val[j] = l_val[j];
+    if (nnz == nnz0 + 1 && threadIdx.x == 0) P0.idx[nnz0] = l_idx[nnz0];
+  }
+  if (threadIdx.x == 0) {
+    S.sel_valid = 0;
     *P0.st = S;
   }
 }
@@ -1056,6 +1203,20 @@ extern "C" int bc_snnls_step_finish(bc_snnls* h) {
   d.blk_val = h->phi->blk_val;
   d.blk_idx = h->phi->blk_idx;
   d.nblk = h->phi->sweep_blocks;
+  static const int no_pf = getenv("BC_FINISH_NOPF") ? atoi(getenv("BC_FINISH_NOPF")) : 0;
+  const long long nrec = d.fuse_winner ? 0 : (long long)d.world * d.rec_len;
+  if (!no_pf && d.s <= BC_FIN_THREADS && h->nnz_upper + 1 <= BC_PF_MAXNNZ && nrec <= BC_PF_MAXREC && h->nnz_upper + 1 <= d.cap) {
+    const int hint = (int)h->nnz_upper;
+    const size_t lds = ((size_t)5 * d.s + nrec + 2 * (size_t)(hint + 1)) * sizeof(double);
+    if (h->alg == BC_ALG_GIGA)
+      hipLaunchKernelGGL(k_step_finish_pf<BC_ALG_GIGA>, dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint);
+    else
+      hipLaunchKernelGGL(k_step_finish_pf<BC_ALG_FW>, dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint);
+    BC_HIP(hipGetLastError());
+    h->nnz_upper += 1;
+    h->iter_upper += 1;
+    return BC_OK;
+  }
   const int lds_vecs = d.s <= 1024 ? 1 : 0;
   const size_t lds = lds_vecs ? (size_t)5 * d.s * sizeof(double) : 0;
   if (h->alg == BC_ALG_GIGA)
