@@ -21,18 +21,23 @@ from . import _native as N
 from .device import DeviceData, _ptr, default_context
 
 try:
-    from threadpoolctl import threadpool_limits as _limits
+    from threadpoolctl import ThreadpoolController as _Controller
 except Exception:                                     # pragma: no cover
-    _limits = None
+    _Controller = None
+_controller = None
 
 
 def _small_lapack(d):
     """The D x D Cholesky / triangular solve of a coreset posterior is microseconds of work; on a
     many-core host a multi-threaded BLAS spends milliseconds synchronising its pool on it (measured:
-    4.9 ms per solve_triangular at D = 64 with 128 threads).  Same routines, one thread."""
-    if _limits is None or d > 512:
+    4.9 ms per solve_triangular at D = 64 with 128 threads).  Same routines, one thread.  The controller is
+    created once: discovering the loaded BLAS libraries costs ~0.9 ms, more than the solve it guards."""
+    global _controller
+    if _Controller is None or d > 512:
         return contextlib.nullcontext()
-    return _limits(limits=1, user_api='blas')
+    if _controller is None:
+        _controller = _Controller()
+    return _controller.limit(limits=1, user_api='blas')
 
 
 _slots = {}
