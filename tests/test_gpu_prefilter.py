@@ -173,6 +173,33 @@ def test_many_samples(bc, s, prec):
     same(run(bc, bc.snnls.GIGA, phi, 40, prec), run(bc, bc.snnls.GIGA, phi, 40, 0))
 
 
+@pytest.mark.parametrize('noise,ncopies', [(1e-4, 1500), (1e-9, 300), (3e-3, 3000)])
+def test_clusters_of_near_duplicates(bc, prec, noise, ncopies):
+    """Hundreds to thousands of rows within the reduced-precision window of the best one: the candidate list is
+    long (per-thread exact rescoring instead of the wave-per-candidate path), tiles hold more than four local
+    candidates (the int8 mirror then hands over whole tiles), yet nothing overflows into the fp64 fallback for the
+    smaller clusters -- and the selections must still be those of the fp64 sweep."""
+    rng = np.random.RandomState(21)
+    n, s = 40000, 40
+    phi = correlated(rng, n, s)
+    src = phi[123].copy()
+    where = rng.choice(n, ncopies, replace=False)
+    phi[where] = src * (1. + noise * rng.randn(ncopies, s))
+    for cls in (bc.snnls.GIGA, bc.snnls.FrankWolfe):
+        same(run(bc, cls, phi, 30, prec), run(bc, cls, phi, 30, 0))
+
+
+def test_prefilter_statistics(bc, prec):
+    rng = np.random.RandomState(22)
+    phi = correlated(rng, 60000, 50)
+    with prefilter(prec):
+        sv = bc.snnls.GIGA(phi.T, phi.sum(axis=0))
+    sv.build(25)
+    sweeps, cands, falls = sv._eng.prefilter_stats()
+    assert sweeps >= 25 and falls == 0
+    assert sweeps <= cands <= 64 * sweeps          # at least the winner each time, and a selective filter
+
+
 def test_million_rows_identical(bc):
     import torch
     g = torch.Generator(device='cuda'); g.manual_seed(11)
