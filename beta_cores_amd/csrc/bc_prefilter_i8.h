@@ -22,7 +22,9 @@
 #pragma once
 
 #define BC_ITILE 256
+#ifndef BC_IU
 #define BC_IU 5          // k-groups per batch (5 KiB in flight per wave and buffer)
+#endif
 #define BC_IMAXG 320     // k-groups the digit table holds: S <= 1280
 typedef int bc_i4 __attribute__((ext_vector_type(4)));
 

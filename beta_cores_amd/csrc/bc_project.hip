@@ -241,7 +241,9 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     }
     return;
   }
-  double* colpart = Tl;   // [waves][NT*16]
+  // column partials reuse the staging LDS (all of it: Zl and Tl are dead after the loop)
+  constexpr bool LDSCP = (JT == 2) && (NTHR / 64) * NR * 17 <= 128 * LDZ + NR * LDT;
+  double* colpart = LDSCP ? lds : Tl;   // LDSCP: [waves][NR][17], else [waves][NR]
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) {
     const long long gr = r0 + row_base + jt;
@@ -323,12 +325,18 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         if (s < S) tbase[(size_t)s * BC_TILE] = acc[0][st][reg];
         cp = acc[0][st][reg];
       }
-      // per-tile column partial (K2): sum over this wave's rows
-      cp += __shfl_xor(cp, 1, BC_WAVE);
-      cp += __shfl_xor(cp, 2, BC_WAVE);
-      cp += __shfl_xor(cp, 4, BC_WAVE);
-      cp += __shfl_xor(cp, 8, BC_WAVE);
-      if (j == 0) colpart[w * NR + s] = cp;
+      // per-tile column partial (K2): sum over the tile's rows.  JT == 2 kernels park each lane's pair sum in LDS
+      // ([wave][sample][16 row pairs], rows padded to 17) and let one thread per sample add them up in a fixed
+      // order -- a 4-step fp64 shuffle reduction per value cost ~8 % of the kernel (0.25 ms per 4M rows).
+      if (LDSCP) {
+        colpart[(w * NR + s) * 17 + j] = cp;
+      } else {
+        cp += __shfl_xor(cp, 1, BC_WAVE);
+        cp += __shfl_xor(cp, 2, BC_WAVE);
+        cp += __shfl_xor(cp, 4, BC_WAVE);
+        cp += __shfl_xor(cp, 8, BC_WAVE);
+        if (j == 0) colpart[w * NR + s] = cp;
+      }
     }
   }
   if (TL > 0) {
@@ -340,18 +348,32 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       if (s_tail < S) tbase[(size_t)s_tail * BC_TILE] = tv[0];
       cp = tv[0];
     }
-    cp += __shfl_xor(cp, 1, BC_WAVE);
-    cp += __shfl_xor(cp, 2, BC_WAVE);
-    cp += __shfl_xor(cp, 4, BC_WAVE);
-    cp += __shfl_xor(cp, 8, BC_WAVE);
-    if (j == 0) colpart[w * NR + s_tail] = cp;
+    if (LDSCP) {
+      colpart[(w * NR + s_tail) * 17 + j] = cp;
+    } else {
+      cp += __shfl_xor(cp, 1, BC_WAVE);
+      cp += __shfl_xor(cp, 2, BC_WAVE);
+      cp += __shfl_xor(cp, 4, BC_WAVE);
+      cp += __shfl_xor(cp, 8, BC_WAVE);
+      if (j == 0) colpart[w * NR + s_tail] = cp;
+    }
   }
   __syncthreads();
   constexpr int NW = NTHR / 64;
   for (int s = tid; s < S; s += NTHR) {
-    double t = colpart[s];
+    double t = 0.;
+    if (LDSCP) {
 #pragma unroll
-    for (int ww = 1; ww < NW; ++ww) t += colpart[ww * NR + s];
+      for (int ww = 0; ww < NW; ++ww) {
+        const double* row = colpart + (ww * NR + s) * 17;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) t += row[jj];
+      }
+    } else {
+      t = colpart[s];
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) t += colpart[ww * NR + s];
+    }
     a.tile_part[(size_t)tile * S + s] = t;
   }
 }
