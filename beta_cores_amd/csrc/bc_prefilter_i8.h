@@ -197,26 +197,29 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
     const float fvn = __double2float_ru(vn), fev0 = __double2float_ru(rs * vstep0), fev1 = __double2float_ru(rs * vstep1);   // ||v||, ||v^ - v||
     const float fvs0 = (float)vstep0, fvs1 = (float)vstep1, fpd = (float)a.post_div;
 
-    bool first = true;
-    for (; t < a.ptiles; t += (long long)gridDim.x * 4) {
+    // Continuous pipeline: while the last batch of a tile is consumed and its rows are evaluated, the first batch
+    // (and the row constants) of the wave's NEXT tile are already in flight.
+    const long long tstride = (long long)gridDim.x * 4;
+    for (; t < a.ptiles; t += tstride) {
       const bc_i4* __restrict__ p = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
       int acc[4][NV];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < NV; ++c) acc[j][c] = 0;
-      if (!first) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
-        rq01 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane];
-        rq23 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane + 1];
-      }
-      first = false;
+      const float4 cq01 = rq01, cq23 = rq23;          // this tile's (scale, delta)
       for (int g0 = 0; g0 < SP4; g0 += U) {
         const bool more = g0 + U < SP4;
         if (more) {
 #pragma unroll
           for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p + (size_t)(g0 + U + u) * 64);
+        } else if (t + tstride < a.ptiles) {
+          const long long tn = t + tstride;
+          const bc_i4* __restrict__ pn = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)tn * SP4 * BC_ITILE) + lane;
+#pragma unroll
+          for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(pn + (size_t)u * 64);
+          rq01 = reinterpret_cast<const float4*>(a.rowq + tn * BC_ITILE)[2 * lane];
+          rq23 = reinterpret_cast<const float4*>(a.rowq + tn * BC_ITILE)[2 * lane + 1];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -226,14 +229,12 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
 #pragma unroll
             for (int c = 0; c < NV; ++c) acc[j][c] = __builtin_amdgcn_sdot4(x[u][j], dg[c], acc[j][c], false);
         }
-        if (more) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) x[u] = y[u];
-        }
+        for (int u = 0; u < U; ++u) x[u] = y[u];        // (after the last batch: the next tile's first batch, if any)
       }
       // ---- per-row intervals (4 rows per lane), fp32 with explicit slack (bc_score_interval_f32)
-      const float sc[4] = {rq01.x, rq01.z, rq23.x, rq23.z};
-      const float dl[4] = {rq01.y, rq01.w, rq23.y, rq23.w};
+      const float sc[4] = {cq01.x, cq01.z, cq23.x, cq23.z};
+      const float dl[4] = {cq01.y, cq01.w, cq23.y, cq23.w};
       float Ub[4], Lb[4];
       float tl = -INFINITY, tmax = -INFINITY;
 #pragma unroll
