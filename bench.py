@@ -199,8 +199,8 @@ def main():
         # 10) and one live-mask byte per 8 rows; it writes only per-tile / per-block bounds.  fp32: 4 B/element + the
         # norms, and one fp32 upper bound written per row.  Candidates are rescored in fp64 either way.
         if pref == 8:
-            # int8 mirror: one byte per element (k-groups of 4 padded to a multiple of 5) + (scale, delta) per row
-            k3_bytes = 4.0 * n_local * (-(-(-(-S // 4)) // 5) * 5) + 8.0 * n_local
+            # int8 mirror: one byte per element (k-groups of 4 padded to a multiple of 5) + (scale, delta) halfs per row
+            k3_bytes = 4.0 * n_local * (-(-(-(-S // 4)) // 5) * 5) + 4.0 * n_local
         elif pref == 16:
             k3_bytes = 2.0 * n_local * (-(-S // 10) * 10) + n_local / 8.0
         else:

@@ -32,6 +32,7 @@
 #include <cstring>
 
 #define BC_PTILE 256   // rows per u32 tile: one sample of a tile = 1 KiB = 64 lanes x float4
+typedef _Float16 bc_hq2 __attribute__((ext_vector_type(2)));   // int8 mirror: (scale, delta) of a row (bc_prefilter_i8.h)
 
 struct bc_pref {
   bc_ctx* ctx = nullptr;
@@ -40,7 +41,7 @@ struct bc_pref {
   _Float16* u16 = nullptr;    // fp16: [ptiles][SP][512]
   unsigned char* live = nullptr;   // fp16: [ptiles][64] live-row mask
   int* u8 = nullptr;          // int8: [ptiles][sp4][256] dwords (bc_prefilter_i8.h)
-  float2* rowq = nullptr;     // int8: (scale, delta) per row
+  bc_hq2* rowq = nullptr;     // int8: (scale, delta) per row, two halfs
   float2* tile_cand = nullptr;   // int8: [ptiles][4]
   int* tile_ncand = nullptr;     // int8: [ptiles]
   int sp4 = 0;                // int8: k-groups stored per tile
@@ -828,7 +829,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const size_t o_u = take(p->prec == 8 ? (size_t)p->ptiles * p->sp4 * BC_ITILE * sizeof(int)
                                        : (size_t)p->ptiles * p->sp * p->ptile * (p->prec == 16 ? sizeof(_Float16) : sizeof(float)));
   const size_t o_ub = take(p->prec != 32 ? 0 : (size_t)p->ptiles * p->ptile * sizeof(float));
-  const size_t o_rq = take(p->prec == 8 ? (size_t)p->ptiles * BC_ITILE * sizeof(float2) : 0);
+  const size_t o_rq = take(p->prec == 8 ? (size_t)p->ptiles * BC_ITILE * sizeof(bc_hq2) : 0);
   const size_t o_tc = take(p->prec == 8 ? (size_t)p->ptiles * 4 * sizeof(float2) : 0);
   const size_t o_tn = take(p->prec == 8 ? (size_t)p->ptiles * sizeof(int) : 0);
   const size_t o_lv = take(p->prec == 16 ? (size_t)p->ptiles * 64 : 0);
@@ -846,7 +847,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->ub = p->prec != 32 ? nullptr : (float*)(base + o_ub);
   if (p->prec == 8) {
     p->u8 = (int*)(base + o_u);
-    p->rowq = (float2*)(base + o_rq);
+    p->rowq = (bc_hq2*)(base + o_rq);
     p->tile_cand = (float2*)(base + o_tc);
     p->tile_ncand = (int*)(base + o_tn);
   }

@@ -1,7 +1,8 @@
 // K3 pre-filter, int8 mirror (BC_PREFILTER=8): one byte per element.
 //
 //   q[i, k] = rint( u[i, k] / scale_i ),  scale_i = max_k |u[i, k]| / 127,   u = Phi[i, :] / ||Phi[i, :]||
-//   rowq[i] = (scale_i, delta_i)   with delta_i >= || q[i, :] * scale_i - u[i, :] ||_2   measured at build time
+//   rowq[i] = (scale_i, delta_i) as two halfs, delta_i >= || q[i, :] * scale_i - u[i, :] ||_2 measured at build time
+//             (scale_i is rounded UP to a half first and the row is quantised with that value, so it is exact)
 //
 // The sweep vectors are quantised per launch to 14 bits + sign, v^_k = (128 d0_k + d1_k) * vstep with int8
 // digits d0 in [-127, 127], d1 in [-64, 64] and vstep = max|v| / 16256, so that
@@ -27,10 +28,11 @@
 #endif
 #define BC_IMAXG 320     // k-groups the digit table holds: S <= 1280
 typedef int bc_i4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bc_hq8 __attribute__((ext_vector_type(8)));   // ... of a lane's four rows
 
 struct I8Args {
   const int* u8;            // [ptiles][sp4][256]
-  const float2* rowq;       // [ptiles*256] (scale, delta); delta < 0: dead row (padding or zero norm)
+  const bc_hq2* rowq;       // [ptiles*256] (scale, delta) halfs; delta < 0: dead row (padding or zero norm), NaN: uncertain row
   const double* v;
   const int* skip_flag;
   const double* v_norm;     // dot mode: ||v|| from the solver state
@@ -73,7 +75,7 @@ __device__ __forceinline__ void bc_score_interval_f32(float s0, float s1, float 
 // one block per 256-row tile, thread = row
 __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ tiles, const double* __restrict__ norms,
                                                  long long n_rows, int S, int SP4, int* __restrict__ u8,
-                                                 float2* __restrict__ rowq) {
+                                                 bc_hq2* __restrict__ rowq) {
   const long long t = blockIdx.x;
   const long long r = t * BC_ITILE + threadIdx.x;
   const bool live = r < n_rows && norms[r < n_rows ? r : 0] != 0.;
@@ -88,7 +90,14 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
       mx = fmax(mx, fabs(u));
     }
   const bool ok = live && !has_nan && mx > 0.;
-  const double scale = ok ? mx / 127. : 0.;
+  // the scale is a half, rounded UP (so |q| <= 127 still holds); the row is quantised with exactly that value
+  _Float16 hs = (_Float16)0.f;
+  if (ok) {
+    hs = (_Float16)(float)(mx / 127.);
+    if ((double)(float)hs < mx / 127.) hs = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, hs) + 1));   // next half up (positive)
+    if ((float)hs < 6.2e-5f) hs = (_Float16)6.2e-5f;     // keep it a normal half (rows with tiny maxima do not exist for unit rows)
+  }
+  const double scale = (double)(float)hs;
   double err2 = 0.;
   int* q = u8 + (size_t)t * SP4 * BC_ITILE + threadIdx.x;
   for (int g = 0; g < SP4; ++g) {
@@ -108,16 +117,17 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
     }
     q[(size_t)g * BC_ITILE] = (int)w;
   }
-  float2 rq;
+  bc_hq2 rq;
   if (!live) {
-    rq = make_float2(0.f, -1.f);
+    rq = (bc_hq2){(_Float16)0.f, (_Float16)-1.f};
   } else if (!ok) {
-    rq = make_float2(0.f, NAN);      // NaN / inf in the row (or a unit row that underflowed): kept, with [-inf, inf]
+    rq = (bc_hq2){(_Float16)0.f, __builtin_bit_cast(_Float16, (unsigned short)0x7e00)};   // NaN: kept, with [-inf, inf]
   } else {
-    // rounded up, with room for the fp64 evaluation above and the float conversion of scale
-    const double sc_f = (double)(float)scale;
-    const double extra = fabs(sc_f - scale) * 127. * sqrt((double)S);   // the kernel multiplies by the float scale
-    rq = make_float2((float)scale, __double2float_ru((sqrt(err2) + extra) * (1. + 1e-6) + 1e-12));
+    // delta as a half rounded up (with room for the fp64 evaluation above)
+    const double dd = sqrt(err2) * (1. + 1e-6) + 1e-12;
+    _Float16 hd = (_Float16)(float)dd;
+    if ((double)(float)hd < dd) hd = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, hd) + 1));
+    rq = (bc_hq2){hs, hd};
   }
   rowq[r - 0] = rq;
 }
@@ -139,13 +149,12 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
     // the first tile's loads do not depend on the prologue: put them in flight before it
     long long t = (long long)blockIdx.x * 4 + wave;
     bc_i4 x[U], y[U];
-    float4 rq01 = make_float4(0.f, -1.f, 0.f, -1.f), rq23 = rq01;
+    bc_hq8 rq = {(_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f};
     if (t < a.ptiles) {
       const bc_i4* __restrict__ p0 = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
 #pragma unroll
       for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p0 + (size_t)u * 64);
-      rq01 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane];
-      rq23 = reinterpret_cast<const float4*>(a.rowq + t * BC_ITILE)[2 * lane + 1];
+      rq = reinterpret_cast<const bc_hq8*>(a.rowq + t * BC_ITILE)[lane];
     }
     // ---- prologue: quantise the sweep vector(s) of this launch (every block does the same tiny job)
     double m0 = 0., m1 = 0.;
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < NV; ++c) acc[j][c] = 0;
-      const float4 cq01 = rq01, cq23 = rq23;          // this tile's (scale, delta)
+      const bc_hq8 cq = rq;                            // this tile's (scale, delta) x 4 rows
       for (int g0 = 0; g0 < SP4; g0 += U) {
         const bool more = g0 + U < SP4;
         if (more) {
@@ -218,8 +227,7 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
           const bc_i4* __restrict__ pn = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)tn * SP4 * BC_ITILE) + lane;
 #pragma unroll
           for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(pn + (size_t)u * 64);
-          rq01 = reinterpret_cast<const float4*>(a.rowq + tn * BC_ITILE)[2 * lane];
-          rq23 = reinterpret_cast<const float4*>(a.rowq + tn * BC_ITILE)[2 * lane + 1];
+          rq = reinterpret_cast<const bc_hq8*>(a.rowq + tn * BC_ITILE)[lane];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         for (int u = 0; u < U; ++u) x[u] = y[u];        // (after the last batch: the next tile's first batch, if any)
       }
       // ---- per-row intervals (4 rows per lane), fp32 with explicit slack (bc_score_interval_f32)
-      const float sc[4] = {cq01.x, cq01.z, cq23.x, cq23.z};
-      const float dl[4] = {cq01.y, cq01.w, cq23.y, cq23.w};
+      const float sc[4] = {(float)cq[0], (float)cq[2], (float)cq[4], (float)cq[6]};
+      const float dl[4] = {(float)cq[1], (float)cq[3], (float)cq[5], (float)cq[7]};
       float Ub[4], Lb[4];
       float tl = -INFINITY, tmax = -INFINITY;
 #pragma unroll
