@@ -200,6 +200,43 @@ def test_prefilter_statistics(bc, prec):
     assert sweeps <= cands <= 64 * sweeps          # at least the winner each time, and a selective filter
 
 
+def _fuzz_problem(rng, n, s, kind):
+    if kind == 0:
+        phi = rng.randn(n, s)
+    elif kind == 1:
+        r = max(1, s // 6)
+        phi = rng.randn(n, r).dot(rng.randn(r, s)) + 0.2 * rng.randn(n, s)
+    elif kind == 2:                                                  # sparse rows
+        phi = rng.randn(n, s) * (rng.rand(n, s) < 0.15)
+        phi[np.abs(phi).sum(axis=1) == 0, 0] = 1.0
+    elif kind == 3:                                                  # row scales over 12 decades
+        phi = rng.randn(n, s) * 10.0 ** rng.uniform(-6, 6, size=(n, 1))
+    elif kind == 4:                                                  # 50 copies of each prototype, perturbed at 1e-6
+        base = rng.randn(max(1, n // 50), s)
+        phi = base[rng.randint(base.shape[0], size=n)] * (1 + 1e-6 * rng.randn(n, s))
+    else:                                                            # element scales over 5 decades
+        phi = rng.randn(n, s) * 10.0 ** rng.uniform(-5, 0, size=(n, s))
+    return phi - phi.mean(axis=1)[:, None] if s > 1 else phi
+
+
+def test_random_problems_all_mirrors(bc):
+    """A fixed-seed slice of the fuzz run recorded in profiles/r01_notes.md (5986 random problems x 3 mirrors, no
+    mismatch): sizes 1..200k, S 1..130, six data families, GIGA and Frank-Wolfe."""
+    rng = np.random.RandomState(77)
+    done = 0
+    while done < 40:
+        n = int(10 ** rng.uniform(0, 5.0)); s = rng.randint(1, 131); kind = rng.randint(6)
+        phi = _fuzz_problem(rng, n, s, kind)
+        if not np.isfinite(phi).all() or (np.linalg.norm(phi, axis=1) == 0).any():
+            continue
+        cls = bc.snnls.GIGA if rng.rand() < 0.6 else bc.snnls.FrankWolfe
+        steps = min(n, rng.randint(1, 40))
+        ref = run(bc, cls, phi, steps, 0)
+        for prec in (8, 16, 32):
+            same(run(bc, cls, phi, steps, prec), ref)
+        done += 1
+
+
 def test_million_rows_identical(bc):
     import torch
     g = torch.Generator(device='cuda'); g.manual_seed(11)
