@@ -254,13 +254,23 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       else if (MODEL >= BC_MODEL_GAUSS_LL) ra = a.rowaux[gr];
     }
     double sum = 0., vmin = INFINITY, vmax = -INFINITY;
+    // TL > 0 kernels (96 < S <= 100): every sample of the NT tiles is a real one and every lane holds some, so the
+    // `s < S` predicates vanish and "all S values equal" is tracked with compares against the lane's first value
+    // (fmin / fmax cost three instructions each with their canonicalisation; a NaN makes the row non-constant,
+    // as in the reference, where a NaN row stays NaN).
+    double vref = 0.;
+    bool differs = false;
 #pragma unroll
     for (int st = 0; st < NT; ++st) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int s = 16 * st + g + 4 * reg;
         double v = 0.;
-        if (s < S && live) {
+        if (TL > 0) {
+          if (live) v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c);
+          if (st == 0 && reg == 0) vref = v;
+          differs |= (v != vref);
+        } else if (s < S && live) {
           v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c);
           vmin = fmin(vmin, v);
           vmax = fmax(vmax, v);
@@ -273,22 +283,34 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       double v = 0.;
       if (s_tail < S && live) {
         v = bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c);
-        vmin = fmin(vmin, v);
-        vmax = fmax(vmax, v);
+        differs |= (v != vref);
       }
       tv[jt] = v;
       sum += v;
     }
     sum += __shfl_xor(sum, 16, BC_WAVE);
     sum += __shfl_xor(sum, 32, BC_WAVE);
-    vmin = fmin(vmin, __shfl_xor(vmin, 16, BC_WAVE));
-    vmin = fmin(vmin, __shfl_xor(vmin, 32, BC_WAVE));
-    vmax = fmax(vmax, __shfl_xor(vmax, 16, BC_WAVE));
-    vmax = fmax(vmax, __shfl_xor(vmax, 32, BC_WAVE));
+    bool constant_row;
+    double cval;
+    if (TL > 0) {
+      int df = differs ? 1 : 0;
+      df |= (vref != __shfl_xor(vref, 16, BC_WAVE)) ? 1 : 0;
+      df |= __shfl_xor(df, 16, BC_WAVE);
+      df |= (vref != __shfl_xor(vref, 32, BC_WAVE)) ? 1 : 0;
+      df |= __shfl_xor(df, 32, BC_WAVE);
+      constant_row = df == 0;
+      cval = vref;
+    } else {
+      vmin = fmin(vmin, __shfl_xor(vmin, 16, BC_WAVE));
+      vmin = fmin(vmin, __shfl_xor(vmin, 32, BC_WAVE));
+      vmax = fmax(vmax, __shfl_xor(vmax, 16, BC_WAVE));
+      vmax = fmax(vmax, __shfl_xor(vmax, 32, BC_WAVE));
+      constant_row = vmin == vmax;
+      cval = vmax;
+    }
     // a row whose S values are all the same number centres to exactly 0 (the rounded mean of S equal
     // numbers need not equal them); such rows are the "all-zero rows" dropped at hilbert.py:16
-    const bool constant_row = vmin == vmax;
-    const double mean = constant_row ? vmax : sum / (double)S;           // lls.mean(axis=1)
+    const double mean = constant_row ? cval : sum / (double)S;           // lls.mean(axis=1)
     double sq = 0.;
 #pragma unroll
     for (int st = 0; st < NT; ++st) {
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       for (int reg = 0; reg < 4; ++reg) {
         const int s = 16 * st + g + 4 * reg;
         double v = acc[jt][st][reg];
-        v = (s < S && live) ? v - mean : 0.;
+        v = ((TL > 0 || s < S) && live) ? v - mean : 0.;
         acc[jt][st][reg] = v;
         sq = fma(v, v, sq);
       }
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       const int s = 16 * st + g + 4 * reg;
       double cp;
       if (JT == 2) {
-        if (s < S) bc_store2(tbase + (size_t)s * BC_TILE, acc[0][st][reg], acc[JT - 1][st][reg]);
+        if (TL > 0 || s < S) bc_store2(tbase + (size_t)s * BC_TILE, acc[0][st][reg], acc[JT - 1][st][reg]);
         cp = acc[0][st][reg] + acc[JT - 1][st][reg];
       } else {
         if (s < S) tbase[(size_t)s * BC_TILE] = acc[0][st][reg];
