@@ -45,6 +45,7 @@ _SIGNATURES = {
     'bc_phi_norms': [vp, vp],
     'bc_phi_norm_stats': [vp, c_i64p, c_dp],
     'bc_phi_to_host': [vp, vp],
+    'bc_phi_group_sum': [vp, vp, vp, C.c_int64, vpp],
     'bc_phi_gather_rows': [vp, vp, C.c_int64, vp],
     'bc_phi_matvec': [vp, vp, vp],
     'bc_phi_destroy': [vp],

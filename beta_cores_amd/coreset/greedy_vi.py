@@ -61,7 +61,7 @@ class _GreedyVICoreset(Coreset):
         elif n_subsample is None and self.groups:
             group_idcs = list(range(len(self.groups)))
             sub_idcs = _flatten([self.groups[i] for i in group_idcs])
-            vecs = np.array([np.sum(np.asarray(self._proj(self.data[self.groups[i], :], beta)), axis=0) for i in group_idcs])
+            vecs = self._group_vecs(group_idcs, beta)
             sum_scaling = 1.
         elif n_subsample and (self.groups is None or not select):
             sub_idcs = np.random.randint(self.data.shape[0], size=n_subsample)
@@ -70,13 +70,24 @@ class _GreedyVICoreset(Coreset):
         else:
             group_idcs = np.random.randint(len(self.groups), size=n_subsample)
             sub_idcs = _flatten([self.groups[i] for i in group_idcs])
-            vecs = np.array([np.sum(np.asarray(self._proj(self.data[self.groups[i], :], beta)), axis=0) for i in group_idcs])
+            vecs = self._group_vecs(group_idcs, beta)
             sum_scaling = len(self.groups) / n_subsample
         if self.pts.size > 0:
             corevecs = np.asarray(self._proj(p, beta))
         else:
             corevecs = np.zeros((0, vecs.shape[1]))
         return self._on_device(vecs), sum_scaling, sub_idcs, group_idcs, corevecs
+
+    def _group_vecs(self, group_idcs, beta):
+        """One vector per group: the sum of its rows' projections (bcores.py:46-50, 56-61).  A device projector
+        projects all rows once (K1) and the groups are summed on the device (bc_phi_group_sum) -- the same rows,
+        the same order of additions; a black-box projector is called group by group like in the reference."""
+        from .projector import _DeviceProjectorBase
+        if isinstance(self.ll_projector, _DeviceProjectorBase):
+            full = self._proj(self.data, beta)
+            if isinstance(full, DevicePhi):
+                return full.group_sum([self.groups[i] for i in group_idcs])
+        return np.array([np.sum(np.asarray(self._proj(self.data[self.groups[i], :], beta)), axis=0) for i in group_idcs])
 
     def _on_device(self, vecs):
         """Black-box projectors hand back a host array; its N-row reductions still run on the GPU."""

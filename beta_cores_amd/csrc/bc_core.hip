@@ -570,6 +570,69 @@ extern "C" int bc_phi_from_host(bc_ctx* ctx, const double* src, int64_t n_rows, 
   return BC_OK;
 }
 
+// Segmented row sums (grouped selection, bcores.py:46-50,56-61 / sparsevi.py:44-48,54-59):
+//   dst[g, :] = sum_{j in [offsets[g], offsets[g+1])} Phi[members[j], :]
+// accumulated sequentially in member order, which is what `vecs[idcs].sum(axis=0)` does in NumPy (a reduction over
+// the outer axis adds row after row).  One block per group, thread = sample; the reads of a member row are 1 KiB
+// apart per sample (tile layout) but groups are usually runs of neighbouring rows, which share cache lines.
+__global__ __launch_bounds__(128) void k_group_sum(const double* __restrict__ tiles, int s, const long long* __restrict__ members,
+                                                  const long long* __restrict__ offsets, double* __restrict__ dst) {
+  const long long g = blockIdx.x;
+  const long long j0 = offsets[g], j1 = offsets[g + 1];
+  for (int k = threadIdx.x; k < s; k += blockDim.x) {
+    double acc = 0.0;
+    for (long long j = j0; j < j1; ++j) acc += tiles[bc_tile_off(members[j], k, s)];
+    dst[(size_t)g * s + k] = acc;
+  }
+}
+
+extern "C" int bc_phi_group_sum(bc_phi* p, const int64_t* members, const int64_t* offsets, int64_t n_groups, bc_phi** out) {
+  if (!p || !out || n_groups < 0 || (n_groups > 0 && (!offsets || (offsets[n_groups] > 0 && !members)))) {
+    bc_set_error("bc_phi_group_sum: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  const int64_t total = n_groups > 0 ? offsets[n_groups] : 0;
+  for (int64_t g = 0; g < n_groups; ++g)
+    if (offsets[g] < 0 || offsets[g + 1] < offsets[g]) { bc_set_error("bc_phi_group_sum: offsets must be non-decreasing from >= 0"); return BC_INVALID_ARGUMENT; }
+  for (int64_t j = 0; j < total; ++j)
+    if (members[j] < 0 || members[j] >= p->n_rows) {
+      bc_set_error("bc_phi_group_sum: member %lld out of range [0,%lld)", (long long)members[j], (long long)p->n_rows);
+      return BC_INVALID_ARGUMENT;
+    }
+  bc_ctx* ctx = p->ctx;
+  BC_HIP(hipSetDevice(ctx->device));
+  bc_phi* q = nullptr;
+  int rc = bc_phi_alloc(ctx, n_groups, p->s, 0, &q);
+  if (rc) return rc;
+  if (n_groups > 0) {
+    long long *dmem = nullptr, *doff = nullptr;
+    double* stage = nullptr;
+    hipError_t e = hipMalloc((void**)&doff, (size_t)(n_groups + 1) * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&dmem, (size_t)(total > 0 ? total : 1) * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&stage, (size_t)n_groups * p->s * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(doff, offsets, (size_t)(n_groups + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && total > 0) e = hipMemcpyAsync(dmem, members, (size_t)total * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_group_sum, dim3((unsigned)n_groups), dim3(128), 0, ctx->stream, p->tiles, p->s, dmem, doff, stage);
+      const size_t lds = (size_t)32 * (BC_TILE + 1) * sizeof(double);
+      hipLaunchKernelGGL(k_layout_from_rowmajor, dim3((unsigned)q->ntiles), dim3(256), lds, ctx->stream, stage,
+                         (long long)n_groups, p->s, q->tiles, q->norms, q->tile_part);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (doff) (void)hipFree(doff);
+    if (dmem) (void)hipFree(dmem);
+    if (stage) (void)hipFree(stage);
+    if (e != hipSuccess) { bc_phi_destroy(q); return bc_hip_fail(e, "bc_phi_group_sum", __FILE__, __LINE__); }
+  } else {
+    BC_HIP(hipMemsetAsync(q->norms, 0, BC_TILE * sizeof(double), ctx->stream));
+  }
+  rc = bc_phi_finish_stats(q);
+  if (rc) { bc_phi_destroy(q); return rc; }
+  *out = q;
+  return BC_OK;
+}
+
 extern "C" int bc_phi_shape(const bc_phi* p, int64_t* n_rows, int32_t* s, int64_t* row_offset) {
   if (!p) { bc_set_error("bc_phi_shape: NULL phi"); return BC_INVALID_ARGUMENT; }
   if (n_rows) *n_rows = p->n_rows;

@@ -233,6 +233,20 @@ class DevicePhi:
         N.call('bc_phi_gather_rows', self.h, _ptr(idx), int(idx.shape[0]), _ptr(out))
         return out
 
+    def group_sum(self, groups):
+        """DevicePhi whose row g is the sum of this matrix's rows groups[g] (local indices), accumulated in the
+        order given -- `np.array([vecs[g].sum(axis=0) for g in groups])` without leaving the device
+        (grouped selection, bcores.py:46-50, 56-61)."""
+        sizes = [len(g) for g in groups]
+        offsets = np.zeros(len(groups) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=offsets[1:])
+        members = (np.concatenate([np.asarray(g, dtype=np.int64).ravel() for g in groups]) if offsets[-1] > 0
+                   else np.zeros(0, dtype=np.int64))
+        members = np.ascontiguousarray(members, dtype=np.int64)
+        h = C.c_void_p()
+        N.call('bc_phi_group_sum', self.h, _ptr(members) if members.size else None, _ptr(offsets), len(groups), C.byref(h))
+        return DevicePhi(h, self.ctx)
+
     def matvec(self, v):
         v = _as_f64(v, 'v')
         out = np.empty(self.shape[0])

@@ -134,6 +134,13 @@ int bc_phi_norms(bc_phi* phi, double* out_n);
 /* number of all-zero rows (dropped at hilbert.py:16 / bcores.py:67) and sum of norms (frankwolfe.py:21,24) */
 int bc_phi_norm_stats(bc_phi* phi, int64_t* zero_rows, double* norm_sum);
 int bc_phi_to_host(bc_phi* phi, double* out_rowmajor);
+/* Grouped (batch) selection, bcores.py:46-50,56-61 / sparsevi.py:44-48,54-59: the reference projects each
+ * group's rows and sums them, `vecs = [proj(data[groups[i]]).sum(axis=0) for i in ...]`.  Here the data are
+ * projected once (K1) and the groups are summed on the device: *out gets n_groups rows,
+ * row g = sum over j in [offsets[g], offsets[g+1]) of Phi[members[j], :], accumulated in member order (NumPy's
+ * order for an axis-0 sum).  members are LOCAL row numbers of `p`; a group may be empty (zero row). */
+int bc_phi_group_sum(bc_phi* p, const int64_t* members, const int64_t* offsets, int64_t n_groups, bc_phi** out);
+
 /* rows by LOCAL index -> m x S row-major (A[:, f] at giga.py:45, frankwolfe.py:27) */
 int bc_phi_gather_rows(bc_phi* phi, const int64_t* local_idx, int64_t m, double* out);
 /* out[j] = sum_i weights[i] * Phi[i, :]  is not needed by the reference; what it

@@ -271,3 +271,23 @@ def test_vector_fma_variant_matches(bc):
     env = dict(os.environ, BC_K1_VALU='1')
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_group_sum_matches_numpy_bits(bc):
+    """bc_phi_group_sum: per-group sums of Phi rows, accumulated in member order -- bit-identical to
+    np.array([phi[g].sum(axis=0) for g in groups]) (bcores.py:46-50), for contiguous, scattered, repeated-member,
+    single-row and empty groups; the result is a regular DevicePhi (norms, column sums, argmax work on it)."""
+    rng = np.random.RandomState(5)
+    n, s = 3001, 37
+    phi = rng.randn(n, s) * 10.0 ** rng.uniform(-3, 3, size=(n, 1))
+    dev = bc.DevicePhi.from_host(phi)
+    groups = [list(range(0, 130)), list(range(130, 131)), [], list(rng.choice(n, 400, replace=False)),
+              [5, 5, 5, 2999, 3000], list(range(2000, 3001))]
+    got = dev.group_sum(groups)
+    want = np.array([phi[g].sum(axis=0) if len(g) else np.zeros(s) for g in groups])
+    assert got.shape == (len(groups), s)
+    assert np.array_equal(np.asarray(got), want)
+    np.testing.assert_allclose(got.norms(), np.linalg.norm(want, axis=1), rtol=1e-14)
+    np.testing.assert_allclose(got.colsum(), want.sum(axis=0), rtol=1e-12, atol=1e-9)
+    with pytest.raises(ValueError):
+        dev.group_sum([[0, n]])
