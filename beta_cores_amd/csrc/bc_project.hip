@@ -67,9 +67,22 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
       return (m < 100.) ? -log1p(exp(m)) : -m;
     }
     case BC_MODEL_LOGISTIC_BETA: {        // -( (b+1)/b*(1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) )
+      // model_lr.py:81-86 evaluates two exp and three pow per element; here the powers go through
+      //   L1 = log(1+e^m),  L2 = log(1+e^-m) = L1 - m   (each taken from the side that cannot overflow)
+      //   (1+e^m)^a = exp(a L1),  (1+e^-m)^a = exp(a L2)
+      // i.e. one log1p and four exp (the kernel was transcendental-bound: 4x the linear model's time).  Same
+      // saturation as the reference's IEEE overflow semantics (m -> +inf: +1, m -> -inf: -1/b); where the reference
+      // flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the 1e-11 of the parity tolerance.
       const double m = -p;
-      const double em = exp(m), enm = exp(-m);
-      return -((c[0] * pow(1. + em, c[1])) - (pow(1. + em, c[2]) + pow(1. + enm, c[2])));
+      double L1, L2;
+      if (m <= 0.) {
+        L1 = log1p(exp(m));
+        L2 = L1 - m;
+      } else {
+        L2 = log1p(exp(-m));
+        L1 = L2 + m;
+      }
+      return -((c[0] * exp(c[1] * L1)) - (exp(c[2] * L1) + exp(c[2] * L2)));
     }
     case BC_MODEL_GAUSS_LL: {             // cc - 1/2*(xSx + tSt - 2*xSt)
       const double q = (ra + sa) - 2. * p;
