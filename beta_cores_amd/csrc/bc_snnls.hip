@@ -1062,7 +1062,7 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   // BC_PREFILTER = 0 (off) / 1 (on, default precision) / 8 / 16 / 32 (on, that storage precision)
   const char* env = getenv("BC_PREFILTER");
   const int req = env ? atoi(env) : -1;
-  const bool want = env ? req != 0 : phi->n_rows >= 393216;   // measured break-even ~262k rows at S = 100
+  const bool want = env ? req != 0 : phi->n_rows >= 163840;   // measured break-even ~131k rows at S = 100 (int8 mirror, profiles/r01_notes.md)
   if (want && phi->n_rows > 0) {
     rc = bc_pref_create(phi, (req == 8 || req == 16 || req == 32) ? req : BC_PREF_DEFAULT_PREC, &h->pref);
     if (rc) { bc_snnls_destroy(h); return rc; }

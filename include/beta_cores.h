@@ -167,7 +167,7 @@ int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int alg, double n
                     int allow_zero_rows, bc_snnls** out);
 int bc_snnls_destroy(bc_snnls* h);
 /* *on = 0, or the storage precision (8 / 16 / 32 bits per element) of the mirror of Phi this solver's sweeps
- * stream through the reduced-precision pre-filter (bc_prefilter.hip): int8 for shards of >= 393216 rows by
+ * stream through the reduced-precision pre-filter (bc_prefilter.hip): int8 for shards of >= 163840 rows by
  * default; BC_PREFILTER=0 / 8 / 16 / 32 in the environment forces it.  Selections and weights are identical either way
  * (candidates are rescored from the fp64 Phi with the arithmetic of the fp64 sweep). */
 int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
