@@ -1,0 +1,49 @@
+"""bench.py keeps its contract: one JSON line with the driver's keys, the roofline and cpu_baseline objects,
+and a CPU-parity verdict -- on a small workload so that it runs in seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '12', '--warmup', '3',
+           '--rows', '300000', '--dim', '24', '--samples', '40', '--cpu-sample', '30000', '--cpu-iters', '6'] + list(extra)
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, 'bench must print exactly one line: %r' % lines
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = run_bench()
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 12 and d['warmup'] == 3 and d['higher_is_better'] is True
+    assert d['vs_baseline'] is None and d['scaling'] == 'strong' and 'workload' in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'hbm' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['parity_on_sample'].startswith('ok')
+    assert abs(d['value'] - 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['config']['sweep'].startswith('int8') and d['prefilter']['fp64_fallbacks'] == 0
+
+
+def test_bench_sweep_modes_agree():
+    a = run_bench('--no-cpu', env={'BC_PREFILTER': '0'})
+    b = run_bench('--no-cpu', env={'BC_PREFILTER': '8'})
+    assert a['coreset'] == b['coreset']            # same size, same error, same number of failed steps
+    assert a['config']['sweep'] == 'fp64' and b['config']['sweep'].startswith('int8')
