@@ -83,6 +83,7 @@ class BetaBlackBoxProjector(Projector):
 
 
 _SMALL_ROWS = 4096     # below this an input is treated as transient (coreset points, sub-samples)
+_BIG_ROWS = 65536      # Phi buffers above this are not hoarded: at most one free buffer per S is kept
 
 
 def _pool_shutdown(state):
@@ -95,9 +96,11 @@ def _pool_shutdown(state):
 
 
 class _PhiPool:
-    """Phi buffers for small projections, recycled instead of hipMalloc'ed / hipFree'd per call.
+    """Phi buffers recycled instead of hipMalloc'ed / hipFree'd per projection.
     A handle is lent to exactly one DevicePhi wrapper; when that wrapper is garbage collected the
-    handle comes back (so two live results never alias).  Handles still on loan when the pool dies
+    handle comes back -- so two live results never alias: a solver that still holds the Phi of an
+    earlier project() keeps its buffer, and the next project() gets another one (the reference
+    returns a fresh array per call, projector.py:24).  Handles still on loan when the pool dies
     stay valid and are destroyed by their wrapper."""
 
     def __init__(self, ctx):
@@ -107,11 +110,16 @@ class _PhiPool:
 
     def acquire(self, n_rows, s):
         lst = self.state['free'].setdefault(s, [])
+        best = None
         for i, (cap, h) in enumerate(lst):
-            if cap >= n_rows:
-                lst.pop(i)
-                return cap, h
-        cap = max(256, 1 << int(np.ceil(np.log2(max(n_rows, 1)))))
+            if cap >= n_rows and (best is None or cap < lst[best][0]):
+                best = i
+        if best is not None and (n_rows < _BIG_ROWS or lst[best][0] <= 2 * n_rows):
+            return lst.pop(best)
+        if n_rows < _BIG_ROWS:
+            cap = max(256, 1 << int(np.ceil(np.log2(max(n_rows, 1)))))
+        else:
+            cap = ((n_rows + N.TILE_ROWS - 1) // N.TILE_ROWS) * N.TILE_ROWS      # large shards: no power-of-two slack
         h = C.c_void_p()
         N.call('bc_phi_create', self.ctx.h, int(cap), int(s), C.byref(h))
         return cap, h
@@ -120,11 +128,61 @@ class _PhiPool:
         state = self.state
 
         def release(handle):
-            if state['alive']:
-                state['free'].setdefault(s, []).append((cap, handle))
-            else:
+            if not state['alive']:
                 N.load().bc_phi_destroy(handle)
+                return
+            lst = state['free'].setdefault(s, [])
+            if cap >= _BIG_ROWS and any(c >= _BIG_ROWS for c, _ in lst):
+                N.load().bc_phi_destroy(handle)      # one spare large buffer per S is enough for a gradient loop
+                return
+            lst.append((cap, handle))
         return release
+
+    def clear(self):
+        destroy = N.load().bc_phi_destroy
+        for lst in self.state['free'].values():
+            for _, h in lst:
+                destroy(h)
+        self.state['free'].clear()
+
+
+# ---- host arrays pinned on the device.  While an ndarray is pinned its device copy is what gets projected, so an
+# in-place edit of the array would go unseen; the array is therefore made read-only for as long as any pin holds it
+# (NumPy then raises on assignment instead of the device silently serving stale rows).
+_pin_guard = {}      # id(ndarray) -> [count, original writeable flag, weakref]
+
+
+def _guard_acquire(arr):
+    key = id(arr)
+    ent = _pin_guard.get(key)
+    if ent is not None and ent[2]() is arr:
+        ent[0] += 1
+        return
+    was = bool(arr.flags.writeable)
+    try:
+        arr.flags.writeable = False
+    except ValueError:
+        pass
+    try:
+        ref = weakref.ref(arr, lambda _, k=key: _pin_guard.pop(k, None))
+    except TypeError:
+        ref = lambda: arr
+    _pin_guard[key] = [1, was, ref]
+
+
+def _guard_release(key):
+    ent = _pin_guard.get(key)
+    if ent is None:
+        return
+    ent[0] -= 1
+    if ent[0] <= 0:
+        arr = ent[2]()
+        if arr is not None and ent[1]:
+            try:
+                arr.flags.writeable = True
+            except ValueError:
+                pass
+        _pin_guard.pop(key, None)
 
 
 class _DeviceProjectorBase(Projector):
@@ -133,8 +191,7 @@ class _DeviceProjectorBase(Projector):
         self.sampler = sampler
         self.model = model
         self.ctx = ctx or default_context()
-        self._data_cache = {}      # id(ndarray) -> (weakref, DeviceData)       large, repeatedly projected arrays
-        self._phi_cache = {}       # (id(DeviceData), model_id, S) -> DevicePhi  whose buffers get reused
+        self._pins = {}            # id(ndarray) -> (weakref, DeviceData): arrays the caller pinned (see pin())
         self._slots = {}           # dz -> DeviceData slot for small transient inputs
         self._pool = _PhiPool(self.ctx)
         self.update(np.array([]), np.array([]))
@@ -142,38 +199,60 @@ class _DeviceProjectorBase(Projector):
     def update(self, wts, pts):
         self.samples = self.sampler(self.projection_dimension, wts, pts)
 
-    # -- data residency: a large array projected repeatedly is uploaded once; small ones go through a slot
+    # -- data residency.  Default: like projector.py:24, every project() reads the LIVE host array (it is uploaded
+    # for that call).  A large array projected over and over (BetaCoreset's full-data gradient loop) can be pinned:
+    # uploaded once, served from HBM afterwards, read-only on the host until unpinned.
+    def pin(self, pts):
+        """Keep a device copy of `pts` for later project() calls; returns the DeviceData.  `pts` becomes read-only
+        (ndarray.flags.writeable = False) until unpin(pts) / forget(), or until the projector dies."""
+        if isinstance(pts, DeviceData):
+            return pts
+        key = id(pts)
+        hit = self._pins.get(key)
+        if hit is not None and hit[0]() is pts:
+            return hit[1]
+        arr = np.atleast_2d(pts)
+        dd = DeviceData(arr, ctx=self.ctx)
+        _guard_acquire(pts)
+        fin = weakref.finalize(self, _guard_release, key)      # a dying projector lets go of its pins
+        try:
+            ref = weakref.ref(pts, lambda _, k=key, pins=self._pins: pins.pop(k, None))
+        except TypeError:
+            ref = lambda: pts
+        self._pins[key] = (ref, dd, fin)
+        return dd
+
+    def unpin(self, pts):
+        hit = self._pins.pop(id(pts), None)
+        if hit is not None:
+            hit[2].detach()
+            _guard_release(id(pts))
+
+    def forget(self, pts=None):
+        """Drop the pinned device copy of `pts` (or of everything) and the spare Phi buffers."""
+        if pts is not None:
+            self.unpin(pts)
+            return
+        for key in list(self._pins):
+            hit = self._pins.pop(key)
+            hit[2].detach()
+            _guard_release(key)
+        self._pool.clear()
+
     def device_data(self, pts):
+        """(DeviceData, transient): transient inputs live in a re-used upload slot that the next call overwrites."""
         if isinstance(pts, DeviceData):
             return pts, False
+        hit = self._pins.get(id(pts))
+        if hit is not None and hit[0]() is pts:
+            return hit[1], False
         pts = np.atleast_2d(pts)
         if pts.shape[0] < _SMALL_ROWS:
             slot = self._slots.get(pts.shape[1])
             if slot is None:
                 slot = self._slots[pts.shape[1]] = DeviceData.slot(pts.shape[1], cap_rows=256, ctx=self.ctx)
             return slot.update(pts), True
-        key = id(pts)
-        hit = self._data_cache.get(key)
-        if hit is not None and hit[0]() is pts:
-            return hit[1], False
-        dd = DeviceData(pts, ctx=self.ctx)
-        try:
-            self._data_cache[key] = (weakref.ref(pts, lambda _, k=key: self._data_cache.pop(k, None)), dd)
-        except TypeError:
-            pass
-        return dd, False
-
-    def forget(self, pts=None):
-        """Drop the cached device copy of `pts` (or of everything).  Arrays of >= 4096 rows are uploaded
-        once per projector and assumed unchanged afterwards; call this after editing one in place."""
-        if pts is None:
-            self._data_cache.clear()
-            self._phi_cache.clear()
-            return
-        hit = self._data_cache.pop(id(pts), None)
-        if hit is not None:
-            for key in [k for k in self._phi_cache if k[0] == id(hit[1])]:
-                del self._phi_cache[key]
+        return DeviceData(pts, ctx=self.ctx), False            # live array, uploaded for this call
 
     def _run(self, pts, model_id, params):
         dd, transient = self.device_data(pts)
@@ -183,23 +262,14 @@ class _DeviceProjectorBase(Projector):
                              % (dd.shape[1], self.model.data_width(theta.shape[1]), theta.shape[1]))
         params = np.ascontiguousarray(params, dtype=np.float64)
         S = int(theta.shape[0])
-        if transient:
-            cap, h = self._pool.acquire(dd.shape[0], S)
+        cap, h = self._pool.acquire(dd.shape[0], S)
+        try:
             N.call('bc_project', self.ctx.h, dd.h, int(model_id), _ptr(theta), S, _ptr(params), int(params.shape[0]),
-                   0, C.byref(h))
-            return DevicePhi(h, self.ctx, release=self._pool.releaser(cap, S))
-        key = (id(dd), model_id, S)
-        prev = self._phi_cache.get(key)
-        h = C.c_void_p(prev.h.value) if prev is not None else C.c_void_p()
-        N.call('bc_project', self.ctx.h, dd.h, int(model_id), _ptr(theta), S, _ptr(params), int(params.shape[0]),
-               int(dd.row_offset), C.byref(h))
-        if prev is not None:
-            prev.refresh()
-            return prev
-        phi = DevicePhi(h, self.ctx)
-        phi._data = dd
-        self._phi_cache[key] = phi
-        return phi
+                   0 if transient else int(dd.row_offset), C.byref(h))
+        except Exception:
+            self._pool.releaser(cap, S)(h)
+            raise
+        return DevicePhi(h, self.ctx, release=self._pool.releaser(cap, S))
 
 
 class DeviceProjector(_DeviceProjectorBase):

@@ -321,9 +321,11 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       constant_row = vmin == vmax;
       cval = vmax;
     }
-    // a row whose S values are all the same number centres to exactly 0 (the rounded mean of S equal
-    // numbers need not equal them); such rows are the "all-zero rows" dropped at hilbert.py:16
-    const double mean = constant_row ? cval : sum / (double)S;           // lls.mean(axis=1)
+    // a row whose S values are all the same number c (a data row with all-zero features): the reference subtracts
+    // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny constant
+    // residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The tree-order sum
+    // above would round differently and flip that zero / non-zero status, so such rows use NumPy's order.
+    const double mean = (constant_row ? bc_np_sum_const_256(cval, S) : sum) / (double)S;   // lls.mean(axis=1)
     double sq = 0.;
 #pragma unroll
     for (int st = 0; st < NT; ++st) {
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
 }
 
 // S > 256, second stage: centre the rows of one tile (subtract the mean over all s_total samples; constant
-// rows become exactly 0), write them back, emit the row norms and the tile's column partial sums.
+// rows get NumPy's rounded mean, see bc_np_sum_const_*), write them back, emit the row norms and the tile's column partial sums.
 __global__ __launch_bounds__(256) void k_center_tiles(double* __restrict__ tiles, double* __restrict__ norms,
                                                      double* __restrict__ tile_part, long long n_rows, int S) {
   __shared__ double lds[32 * (BC_TILE + 1)];
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void k_center_tiles(double* __restrict__ tiles
   __syncthreads();
   const double tot = psum[r] + psum[128 + r];
   const double mn = fmin(pmin[r], pmin[128 + r]), mx = fmax(pmax[r], pmax[128 + r]);
-  const double mean = (mn == mx) ? mx : tot / (double)S;
+  const double mean = ((mn == mx) ? bc_np_sum_const_any(mx, S) : tot) / (double)S;   // constant row: NumPy's rounding of the mean
   __syncthreads();
   double sq = 0.;
   for (int s0 = 0; s0 < S; s0 += 32) {
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_project_v(ProjArgs a) {
     const double tot = ((rs0[r] + rs0[256 + r]) + rs0[512 + r]) + rs0[768 + r];
     const double mn = fmin(fmin(rs1[r], rs1[256 + r]), fmin(rs1[512 + r], rs1[768 + r]));
     const double mx = fmax(fmax(rs2[r], rs2[256 + r]), fmax(rs2[512 + r], rs2[768 + r]));
-    mean[rr] = (mn == mx) ? mx : tot / (double)S;      // constant row -> exactly 0 after centring (hilbert.py:16)
+    mean[rr] = ((mn == mx) ? bc_np_sum_const_256(mx, S) : tot) / (double)S;      // constant row: NumPy's rounding of the mean
   }
   __syncthreads();
 #pragma unroll

@@ -11,6 +11,7 @@ import weakref
 import numpy as np
 
 from .. import _native as N
+from .. import util
 from ..device import DevicePhi, _PhiT, _ptr, default_context
 
 ALG_IDS = {'giga': N.ALG_GIGA, 'fw': N.ALG_FW, 'omp': N.ALG_OMP}
@@ -50,7 +51,8 @@ class HipEngine:
                C.byref(h))
         self.h = h
         self._fin = weakref.finalize(self, N.load().bc_snnls_destroy, h)
-        N.call('bc_snnls_set_tolerance', h, float(tol))
+        self._tol = None
+        self.set_tolerance(tol)
         on = C.c_int()
         N.call('bc_snnls_prefilter_active', h, C.byref(on))
         self.prefilter = int(on.value)           # 0, or the storage precision (16 / 32) of the mirror of Phi the sweeps
@@ -71,8 +73,20 @@ class HipEngine:
                 self._xchg = comm.make_exchange(n.value, self.ctx)
                 N.call('bc_snnls_bind_exchange', h, self.world, C.c_void_p(self._xchg.send_ptr), C.c_void_p(self._xchg.all_ptr))
 
+    def set_tolerance(self, tol):
+        tol = float(tol)
+        if tol != self._tol:
+            N.call('bc_snnls_set_tolerance', self.h, tol)
+            self._tol = tol
+
+    def _live_tol(self):
+        """The reference reads util.TOL at every use (giga.py:28, snnls.py:92), so util.set_tolerance() after a
+        solver was built changes its numeric-limit checks; the device copy follows (one scalar, sent when it changed)."""
+        self.set_tolerance(util.TOL)
+
     # ---- fused loop (snnls.py:31-79 on the device)
     def build_fused(self, itrs):
+        self._live_tol()
         lim = C.c_int()
         if not self.exchange:
             N.call('bc_snnls_build', self.h, int(itrs), C.byref(lim))
@@ -87,6 +101,7 @@ class HipEngine:
 
     # ---- step-wise protocol
     def select(self):
+        self._live_tol()
         f = C.c_int64()
         if not self.exchange:
             N.call('bc_snnls_select', self.h, C.byref(f))
@@ -97,6 +112,7 @@ class HipEngine:
         return f.value
 
     def reweight(self, f):
+        self._live_tol()
         N.call('bc_snnls_reweight', self.h, int(f))
 
     def error(self):

@@ -24,15 +24,12 @@ def gaussian_KL(mu0, Sig0, mu1, Sig1inv):
     return 0.5 * (t1 + t2 + t3 - mu0.shape[0])
 
 
-def main():
-    nm = sys.argv[1] if len(sys.argv) > 1 else 'BCORES'
-    tr = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    M = int(os.environ.get('M', 40))
-    N = int(os.environ.get('N', 5000))
-    d = int(os.environ.get('D', 50))
+def run(nm='BCORES', tr=1, N=5000, d=50, M=40, opt_itrs=200, n_subsample_opt=200, n_subsample_select=1000, proj_dim=200,
+        pihat_noise=0.75, i0=0.1, verbose=True):
+    """One trial of the experiment.  Statement order follows the reference script (main.py:15-108), so with the same
+    seed the global NumPy RNG stream -- data, the four projectors' constructor draws, the noise of the 'realistic'
+    tangent space -- is the script's.  Returns dict(w, p, idcs (per m = 0..M), rkl, fkl, Xc)."""
     np.random.seed(tr)
-    opt_itrs, n_subsample_opt, n_subsample_select, proj_dim, pihat_noise, i0 = 200, 200, 1000, 200, 0.75, 0.1
-
     mu0, Sig0 = np.zeros(d), np.eye(d)
     Sig = 500 * np.eye(d)
     th = np.zeros(d)
@@ -46,7 +43,10 @@ def main():
                          np.random.multivariate_normal(th, 10 * Sig, int(N / 10.))))
 
     model = bc.likelihoods.GaussianLocation(Siginv, logdetSig)
+    # every projector draws its first Theta when constructed (projector.py:18,46): all four are built, in the
+    # script's order, whichever algorithm runs
     sampler_optimal = lambda n, w, pts: mup + np.random.randn(n, mup.shape[0]).dot(LSigp.T)
+    prj_optimal = bc.DeviceProjector(sampler_optimal, proj_dim, model)
     U = np.random.rand()
     muhat = U * mup + (1. - U) * mu0
     Sighat = U * Sigp + (1. - U) * Sig0
@@ -54,6 +54,7 @@ def main():
     Sighat *= np.exp(-2 * pihat_noise * np.fabs(np.random.randn()))
     LSighat = np.linalg.cholesky(Sighat)
     sampler_realistic = lambda n, w, pts: mup + np.random.randn(n, mup.shape[0]).dot(LSighat.T)
+    prj_realistic = bc.DeviceProjector(sampler_realistic, proj_dim, model)
 
     def sampler_w(sz, wts, pts):
         if pts.shape[0] == 0:
@@ -61,34 +62,47 @@ def main():
         muw, LSigw, _ = bc.gaussian_weighted_post(mu0, Sig0inv, Siginv, pts, wts)
         return muw + np.random.randn(sz, muw.shape[0]).dot(LSigw.T)
 
+    prj_w = bc.DeviceProjector(sampler_w, proj_dim, model)
+    prj_bw = bc.DeviceBetaProjector(sampler_w, proj_dim, model)
+
     sched = lambda i: i0 / (1. + i)
     if nm == 'BCORES':
-        alg = bc.BetaCoreset(Xc, bc.DeviceBetaProjector(sampler_w, proj_dim, model), opt_itrs=opt_itrs,
-                             n_subsample_opt=n_subsample_opt, n_subsample_select=n_subsample_select, step_sched=sched,
-                             beta=.1, learn_beta=False)
+        alg = bc.BetaCoreset(Xc, prj_bw, opt_itrs=opt_itrs, n_subsample_opt=n_subsample_opt,
+                             n_subsample_select=n_subsample_select, step_sched=sched, beta=.1, learn_beta=False)
     elif nm == 'SVI':
-        alg = bc.SparseVICoreset(Xc, bc.DeviceProjector(sampler_w, proj_dim, model), opt_itrs=opt_itrs,
-                                 n_subsample_opt=n_subsample_opt, n_subsample_select=n_subsample_select, step_sched=sched)
+        alg = bc.SparseVICoreset(Xc, prj_w, opt_itrs=opt_itrs, n_subsample_opt=n_subsample_opt,
+                                 n_subsample_select=n_subsample_select, step_sched=sched)
     elif nm == 'GIGAO':
-        alg = bc.HilbertCoreset(Xc, bc.DeviceProjector(sampler_optimal, proj_dim, model))
+        alg = bc.HilbertCoreset(Xc, prj_optimal)
     elif nm == 'GIGAR':
-        alg = bc.HilbertCoreset(Xc, bc.DeviceProjector(sampler_realistic, proj_dim, model))
+        alg = bc.HilbertCoreset(Xc, prj_realistic)
     else:
         raise SystemExit('alg must be one of BCORES, SVI, GIGAO, GIGAR')
 
-    print('%4s %12s %12s' % ('m', 'reverse KL', 'forward KL'))
+    w, p, idl = [np.array([0.])], [np.zeros((1, Xc.shape[1]))], [np.zeros(0, dtype=np.int64)]
     for m in range(1, M + 1):
         alg.build(1, m)
         got = alg.get()
-        wts, pts = got[0], got[1]
-        if wts.shape[0] == 0:
-            wts, pts = np.array([0.]), np.zeros((1, Xc.shape[1]))
-        muw, LSigw, LSigwInv = bc.gaussian_weighted_post(mu0, Sig0inv, Siginv, pts, wts)
+        w.append(got[0].copy())
+        p.append(got[1].copy())
+        idl.append(got[2].copy())
+    rkl, fkl = np.zeros(M + 1), np.zeros(M + 1)
+    if verbose:
+        print('%4s %12s %12s' % ('m', 'reverse KL', 'forward KL'))
+    for m in range(M + 1):
+        muw, LSigw, LSigwInv = bc.gaussian_weighted_post(mu0, Sig0inv, Siginv, p[m], w[m])
         Sigw = LSigw.dot(LSigw.T)
-        rkl = gaussian_KL(muw, Sigw, mup, SigpInv)
-        fkl = gaussian_KL(mup, Sigp, muw, LSigwInv.dot(LSigwInv.T))
-        if m in (1, 2, 5, 10, 20, M) or m % 50 == 0:
-            print('%4d %12.4f %12.4f' % (m, rkl, fkl))
+        rkl[m] = gaussian_KL(muw, Sigw, mup, SigpInv)
+        fkl[m] = gaussian_KL(mup, Sigp, muw, LSigwInv.dot(LSigwInv.T))
+        if verbose and (m in (1, 2, 5, 10, 20, M) or m % 50 == 0):
+            print('%4d %12.4f %12.4f' % (m, rkl[m], fkl[m]))
+    return dict(w=w, p=p, idcs=idl, rkl=rkl, fkl=fkl, Xc=Xc)
+
+
+def main():
+    nm = sys.argv[1] if len(sys.argv) > 1 else 'BCORES'
+    tr = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    run(nm, tr, N=int(os.environ.get('N', 5000)), d=int(os.environ.get('D', 50)), M=int(os.environ.get('M', 40)))
 
 
 if __name__ == '__main__':

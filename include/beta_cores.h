@@ -19,9 +19,13 @@
  *     memory is owned by the handles; handles are not thread-safe.
  *   - all arithmetic is IEEE double (the reference computes in float64);
  *     indices are int64 GLOBAL row numbers (row_offset + local row).
- *   - one context == one GPU == one process (ranks are separate processes;
- *     the per-step candidate exchange is done by the host with
- *     torch.distributed/RCCL on the buffers bound with bc_snnls_bind_exchange).
+ *   - one context == one GPU == one process (ranks are separate processes).
+ *     The per-step candidate exchange is issued by THIS library: ncclAllGather
+ *     (RCCL) on the context's stream, from inside bc_snnls_build /
+ *     bc_snnls_select, once a communicator is bound with bc_snnls_bind_comm
+ *     (bc_comm_* below).  bc_snnls_bind_exchange is the second transport: the
+ *     host moves the records between step_local / step_finish (gloo CPU tests,
+ *     several ranks sharing one GPU).
  *
  * Phi layout in HBM ("row tiles"): rows are grouped in tiles of 128; inside a
  * tile the element (row r, sample s) lives at  tile*S*128 + s*128 + (r%128),

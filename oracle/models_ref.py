@@ -125,3 +125,11 @@ def linreg_xtwx(z, w):
     X^T diag(w) X  and  X^T (w*y).  Kernel K4's outputs."""
     X, Y = _split_xy(z)
     return (w[:, np.newaxis] * X).T.dot(X), (w[:, np.newaxis] * Y[:, np.newaxis] * X).sum(axis=0)
+
+
+def gaussian_KL(mu0, Sig0, mu1, Sig1inv):
+    """gaussian.py:22-26: KL( N(mu0, Sig0) || N(mu1, Sig1) )."""
+    t1 = np.dot(Sig1inv, Sig0).trace()
+    t2 = np.dot((mu1 - mu0), np.dot(Sig1inv, mu1 - mu0))
+    t3 = -np.linalg.slogdet(Sig1inv)[1] - np.linalg.slogdet(Sig0)[1]
+    return 0.5 * (t1 + t2 + t3 - mu0.shape[0])

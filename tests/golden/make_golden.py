@@ -442,7 +442,323 @@ def f7_nn_opt():
     save('f7_nn_opt', **out)
 
 
+# ---------------------------------------------------------------- F10: sampling "solvers"
+def f10_sampling():
+    """ImportanceSampling / UniformSampling (snnls/sampling.py:6-37), draws from the GLOBAL NumPy RNG."""
+    rng = np.random.RandomState(10)
+    N, D, S, steps = 300, 6, 40, 30
+    Z, th, _ = linreg_problem(rng, N, D, S)
+    prj = R.projector.BlackBoxProjector(lambda n, w, p: th, S, lambda z, t: R.linreg.gaussian_loglikelihood(z, t, 1.0))
+    phi = prj.project(Z)
+    out = dict(Z=Z, th=th, phi=phi)
+    for nm, cls in (('imp', R.snnls.ImportanceSampling), ('unif', R.snnls.UniformSampling)):
+        np.random.seed(100)
+        sel, err, lim, W = run_solver_stepwise(cls, phi, steps)
+        out[nm + '_sel'], out[nm + '_err'], out[nm + '_lim'], out[nm + '_W'] = sel, err, lim, W
+        out[nm + '_rng_after'] = np.array(np.random.rand())
+        # the same through HilbertCoreset(snnls=...), one build(steps) call
+        np.random.seed(101)
+        h = R.hilbert.HilbertCoreset(Z, prj, snnls=cls, wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+        h.build(steps, steps)
+        wts, pts, idcs = h.get()
+        out[nm + '_h_wts'], out[nm + '_h_idcs'], out[nm + '_h_err'] = wts, idcs, np.array(h.error())
+    save('f10_sampling', **out)
+
+
+# ---------------------------------------------------------------- F11: grouped AND sub-sampled tangent space
+def f11_grouped_subsampled():
+    """bcores.py:56-61 / sparsevi.py:54-59: `groups` together with n_subsample_select (random groups in the
+    selection step) and n_subsample_opt (random rows in the gradient steps, bcores.py:51-55).  The sampler is
+    deterministic (fixed E); the sub-sampling draws come from the global RNG and their order is pinned."""
+    rng = np.random.RandomState(11)
+    N, D, S = 240, 5, 24
+    Z, _, E = linreg_problem(rng, N, D, S)
+    perm = rng.permutation(N)
+    groups = [sorted(perm[i:i + 12].tolist()) for i in range(0, N, 12)]     # 20 groups of 12 rows
+    out = dict(Z=Z, E=E, groups=np.array(groups))
+    opt_itrs, builds = 6, 5
+
+    def sampler(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts = np.zeros(1)
+            pts = np.zeros((1, Z.shape[1]))
+        mu, L, _ = R.linreg.weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+
+    fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    bl = lambda z, t, b: R.neurlinr.neurlinr_beta_likelihood(z, t, b, 1.0)
+    ll = lambda z, t: R.linreg.gaussian_loglikelihood(z, t, 1.0)
+    for nm in ('bcores', 'svi'):
+        np.random.seed(110)
+        if nm == 'bcores':
+            alg = R.bcores.BetaCoreset(Z, R.projector.BetaBlackBoxProjector(sampler, S, bl, ll, None), opt_itrs=opt_itrs,
+                                       n_subsample_select=8, n_subsample_opt=50, step_sched=lambda i: 0.1 / (1. + i),
+                                       beta=0.1, learn_beta=False, groups=groups, **fresh())
+        else:
+            alg = R.sparsevi.SparseVICoreset(Z, R.projector.BlackBoxProjector(sampler, S, ll), opt_itrs=opt_itrs,
+                                             n_subsample_select=8, n_subsample_opt=50, step_sched=lambda i: 0.1 / (1. + i),
+                                             groups=groups, **fresh())
+        for m in range(builds):
+            quiet(alg.build, 1, 12 * (m + 1))
+            out['%s_allw_%d' % (nm, m)] = alg.wts.copy()
+            out['%s_allidcs_%d' % (nm, m)] = alg.idcs.copy()
+            out['%s_groups_%d' % (nm, m)] = np.array([int(g) for g in alg.selected_groups])
+        out['%s_rng_after' % nm] = np.array(np.random.rand())
+    out['opt_itrs'] = np.array(opt_itrs)
+    save('f11_grouped_subsampled', **out)
+
+
+# ---------------------------------------------------------------- F12: constant rows (all-zero features)
+def f12_constant_rows():
+    """Data rows with all-zero features project to S equal numbers c; `lls -= lls.mean(axis=1)` (projector.py:26)
+    leaves c - mean, which NumPy's pairwise mean makes non-zero for most (c, S) with S not a power of two.  Such
+    rows keep a positive norm, survive hilbert.py:16 and no index shift happens; rows whose residue IS exactly zero
+    are dropped and shift every later index (hilbert.py:16 vs :32).  S = 100 and S = 200, linreg (x_i = 0, assorted y)
+    and logistic (z_i = 0: every value is -log 2)."""
+    rng = np.random.RandomState(12)
+    out = {}
+    N, D, steps = 600, 8, 30
+    zero_at = np.array([0, 3, 4, 17, 100, 101, 257, 300, 311, 389, 450, 512, 555, 580, 599])
+    for S in (100, 200):
+        Z, th, _ = linreg_problem(rng, N, D, S)
+        Z[zero_at, :D] = 0.
+        Z[zero_at[:4], D] = [0., 1., -2., 0.5]                       # exactly representable y among the rest
+        prj = R.projector.BlackBoxProjector(lambda n, w, p: th, S, lambda z, t: R.linreg.gaussian_loglikelihood(z, t, 1.0))
+        phi = prj.project(Z)
+        tag = 'lin_S%d_' % S
+        out[tag + 'Z'], out[tag + 'th'], out[tag + 'phi_const'] = Z, th, phi[zero_at]      # the constant rows of Phi
+        out[tag + 'kept'] = np.sqrt((phi ** 2).sum(axis=1)) > 0.         # hilbert.py:16
+        for an, cls in (('giga', R.snnls.GIGA), ('fw', R.snnls.FrankWolfe)):
+            res = hilbert_run(Z, prj, steps, cls)
+            for k in ('sel', 'err', 'wts', 'idcs'):
+                out['%s%s_%s' % (tag, an, k)] = res[k]
+        # logistic
+        Dl = 16
+        X = rng.randn(N, Dl)
+        thstar = np.ones(Dl) / np.sqrt(Dl)
+        yl = np.where(rng.rand(N) <= 1. / (1. + np.exp(-X.dot(thstar))), 1., -1.)
+        Zl = yl[:, None] * X
+        Zl[zero_at] = 0.
+        thl = thstar + 0.1 * rng.randn(S, Dl)
+        prjl = R.projector.BlackBoxProjector(lambda n, w, p: thl, S, R.lr.log_likelihood)
+        phil = prjl.project(Zl)
+        tag = 'log_S%d_' % S
+        out[tag + 'Z'], out[tag + 'th'], out[tag + 'phi_const'] = Zl, thl, phil[zero_at]
+        out[tag + 'kept'] = np.sqrt((phil ** 2).sum(axis=1)) > 0.
+        res = hilbert_run(Zl, prjl, steps)
+        for k in ('sel', 'err', 'wts', 'idcs'):
+            out['%sgiga_%s' % (tag, k)] = res[k]
+    out['zero_at'] = zero_at
+    save('f12_constant_rows', **out)
+
+
+# ---------------------------------------------------------------- F13: greedy VI with all-zero projection rows
+def f13_greedy_vi_zero_rows():
+    """BetaCoreset / SparseVI never drop all-zero rows of the tangent space: the filter at bcores.py:67-68 needs
+    select=True with groups=None, and the ungrouped _select calls _get_projection with select=False (bcores.py:76).
+    A zero row's correlation is 0/0 = NaN; np.argmax returns the first NaN, `corrs.max() > x` is False.  S = 16
+    makes the constant rows exactly zero (the mean of 16 equal doubles is exact); S = 100 keeps them as tiny
+    residue rows.  Both recorded."""
+    rng = np.random.RandomState(13)
+    N, D = 300, 5
+    out = {}
+    for S in (16, 100):
+        Z, _, E = linreg_problem(rng, N, D, S)
+        zero_at = np.array([7, 40, 41, 200])
+        Z[zero_at, :D] = 0.
+        out['S%d_Z' % S], out['S%d_E' % S] = Z, E
+
+        def sampler(sz, wts, pts, Z=Z, E=E):
+            if pts.shape[0] == 0:
+                wts = np.zeros(1)
+                pts = np.zeros((1, Z.shape[1]))
+            mu, L, _ = R.linreg.weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+            return mu + E.dot(L.T)
+
+        fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+        bl = lambda z, t, b: R.neurlinr.neurlinr_beta_likelihood(z, t, b, 1.0)
+        ll = lambda z, t: R.linreg.gaussian_loglikelihood(z, t, 1.0)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            for nm in ('bcores', 'svi'):
+                if nm == 'bcores':
+                    alg = R.bcores.BetaCoreset(Z, R.projector.BetaBlackBoxProjector(sampler, S, bl, ll, None), opt_itrs=5,
+                                               step_sched=lambda i: 0.1 / (1. + i), beta=0.1, learn_beta=False, **fresh())
+                else:
+                    alg = R.sparsevi.SparseVICoreset(Z, R.projector.BlackBoxProjector(sampler, S, ll), opt_itrs=5,
+                                                     step_sched=lambda i: 0.1 / (1. + i), **fresh())
+                for m in range(4):
+                    quiet(alg.build, 1, m + 1)
+                    out['S%d_%s_allw_%d' % (S, nm, m)] = alg.wts.copy()
+                    out['S%d_%s_allidcs_%d' % (S, nm, m)] = alg.idcs.copy()
+    out['zero_at'] = zero_at
+    save('f13_greedy_vi_zero_rows', **out)
+
+
+# ---------------------------------------------------------------- F14: the zellner_gaussian driver, shrunk
+def f14_zellner_gaussian_driver():
+    """examples/zellner_gaussian/main.py:33-167 at N = 400, d = 6, M = 8, proj_dim = 40: the data recipe, the four
+    projector constructors (each draws its first Theta from the global RNG when constructed, projector.py:18,46), the
+    BCORES / SVI / GIGAO / GIGAR objects, the build(1, m) loop and the KL metrics -- statement order as in the script,
+    so the global RNG stream is the script's.  BPSVI / RAND construct without touching the RNG and are left out."""
+    G = R.gaussian
+    out = {}
+    M, opt_itrs, n_subsample_opt, n_subsample_select, proj_dim, pihat_noise, i0 = 8, 30, 50, 150, 40, 0.75, 0.1
+    N, d = 400, 6
+    for nm in ('BCORES', 'SVI', 'GIGAO', 'GIGAR'):
+        tr = 3
+        np.random.seed(tr)
+        mu0, Sig0 = np.zeros(d), np.eye(d)
+        Sig = 500 * np.eye(d)
+        th = np.zeros(d)
+        Sig0inv, Siginv = np.linalg.inv(Sig0), np.linalg.inv(Sig)
+        logdetSig = np.linalg.slogdet(Sig)[1]
+        X = np.random.multivariate_normal(th, Sig, N)
+        mup, LSigp, LSigpInv = G.weighted_post(mu0, Sig0inv, Siginv, X, np.ones(X.shape[0]))
+        Sigp = LSigp.dot(LSigp.T)
+        SigpInv = LSigpInv.dot(LSigpInv.T)
+        Xc = np.concatenate((X, np.random.multivariate_normal(th + 200, 0.5 * Sig, int(N / 50.)),
+                             np.random.multivariate_normal(th + 150, 0.1 * Sig, int(N / 50.)),
+                             np.random.multivariate_normal(th, 10 * Sig, int(N / 10.))))
+        log_likelihood = lambda x, t: quiet(G.gaussian_loglikelihood, x, t, Siginv, logdetSig)
+        beta_likelihood = lambda x, t, beta: G.gaussian_beta_likelihood(x, t, beta, Siginv, logdetSig)
+        grad_beta = lambda x, t, beta: G.gaussian_beta_gradient(x, t, beta, Siginv, logdetSig)
+        sampler_optimal = lambda n, w, pts: mup + np.random.randn(n, mup.shape[0]).dot(LSigp.T)
+        prj_optimal = R.projector.BlackBoxProjector(sampler_optimal, proj_dim, log_likelihood, None)
+        U = np.random.rand()
+        muhat = U * mup + (1. - U) * mu0
+        Sighat = U * Sigp + (1. - U) * Sig0
+        muhat += pihat_noise * np.sqrt((muhat ** 2).sum()) * np.random.randn(muhat.shape[0])
+        Sighat *= np.exp(-2 * pihat_noise * np.fabs(np.random.randn()))
+        LSighat = np.linalg.cholesky(Sighat)
+        sampler_realistic = lambda n, w, pts: mup + np.random.randn(n, mup.shape[0]).dot(LSighat.T)
+        prj_realistic = R.projector.BlackBoxProjector(sampler_realistic, proj_dim, log_likelihood, None)
+
+        def sampler_w(sz, wts, pts):
+            if pts.shape[0] == 0:
+                wts = np.zeros(1)
+                pts = np.zeros((1, Xc.shape[1]))
+            muw, LSigw, _ = G.weighted_post(mu0, Sig0inv, Siginv, pts, wts)
+            return muw + np.random.randn(sz, muw.shape[0]).dot(LSigw.T)
+
+        prj_w = R.projector.BlackBoxProjector(sampler_w, proj_dim, log_likelihood, None)
+        prj_bw = R.projector.BetaBlackBoxProjector(sampler_w, proj_dim, beta_likelihood, log_likelihood, grad_beta)
+        fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+        sched = lambda i: i0 / (1. + i)
+        if nm == 'SVI':
+            alg = R.sparsevi.SparseVICoreset(Xc, prj_w, opt_itrs=opt_itrs, n_subsample_opt=n_subsample_opt,
+                                             n_subsample_select=n_subsample_select, step_sched=sched, **fresh())
+        elif nm == 'BCORES':
+            alg = R.bcores.BetaCoreset(Xc, prj_bw, opt_itrs=opt_itrs, n_subsample_opt=n_subsample_opt,
+                                       n_subsample_select=n_subsample_select, step_sched=sched, beta=.1, learn_beta=False,
+                                       **fresh())
+        elif nm == 'GIGAO':
+            alg = R.hilbert.HilbertCoreset(Xc, prj_optimal, **fresh())
+        else:
+            alg = R.hilbert.HilbertCoreset(Xc, prj_realistic, **fresh())
+        w = [np.array([0.])]
+        p = [np.zeros((1, Xc.shape[1]))]
+        idl = [np.zeros(0, dtype=np.int64)]
+        for m in range(1, M + 1):
+            quiet(alg.build, 1, m)
+            got = quiet(alg.get)
+            w.append(got[0].copy())
+            p.append(got[1].copy())
+            idl.append(got[2].copy())
+        rklw, fklw = np.zeros(M + 1), np.zeros(M + 1)
+        for m in range(M + 1):
+            muw, LSigw, LSigwInv = G.weighted_post(mu0, Sig0inv, Siginv, p[m], w[m])
+            Sigw = LSigw.dot(LSigw.T)
+            rklw[m] = G.gaussian_KL(muw, Sigw, mup, SigpInv)
+            fklw[m] = G.gaussian_KL(mup, Sigp, muw, LSigwInv.dot(LSigwInv.T))
+        out[nm + '_rkl'], out[nm + '_fkl'] = rklw, fklw
+        for m in range(M + 1):
+            out['%s_w_%d' % (nm, m)] = w[m]
+            out['%s_idcs_%d' % (nm, m)] = idl[m]
+        out[nm + '_rng_after'] = np.array(np.random.rand())
+        if nm == 'GIGAO':
+            out['Xc'] = Xc
+    out['params'] = np.array([N, d, M, opt_itrs, n_subsample_opt, n_subsample_select, proj_dim, 3])
+    save('f14_zellner_gaussian_driver', **out)
+
+
+# ---------------------------------------------------------------- F15: learn_beta=True
+def _get_projection_ii(self, n_subsample, w, p, beta):
+    """NOT reference code: the method bcores.py:131 calls does not exist anywhere in the reference tree, so
+    learn_beta=True cannot run as shipped.  This is the sibling of _get_projection (bcores.py:37-72) its call
+    site implies: same tangent space, plus the beta-gradient of the CORESET rows from
+    project_f(..., grad=True) (projector.py:56-61; `betagrads.dot(resid)` at bcores.py:134 must be M-long).
+    It is attached to the reference class for this fixture only."""
+    got = self._get_projection(n_subsample, w, p, beta)
+    vecs, sum_scaling, sub_idcs, corevecs = got
+    if self.pts.size > 0:
+        corevecs, betagrads = self.ll_projector.project_f(self.pts, beta, grad=True)
+    else:
+        betagrads = np.zeros((0, vecs.shape[1]))
+    return vecs, sum_scaling, sub_idcs, corevecs, betagrads
+
+
+def f15_learn_beta():
+    """BetaCoreset(learn_beta=True), bcores.py:127-140, Gaussian location model (the one model for which the
+    reference ships a beta-gradient, gaussian.py:46-62), full-data tangent space, deterministic sampler."""
+    rng = np.random.RandomState(15)
+    N, d, S = 300, 5, 32
+    Sig = 500. * np.eye(d)
+    Siginv = np.linalg.inv(Sig)
+    logdet = np.linalg.slogdet(Sig)[1]
+    X = rng.multivariate_normal(np.zeros(d), Sig, N)
+    # outliers near enough that exp(-beta q / 2) does not underflow into constant rows (F13 covers those)
+    Xc = np.concatenate((X, rng.multivariate_normal(np.zeros(d) + 40, 0.5 * Sig, N // 50),
+                         rng.multivariate_normal(np.zeros(d), 4 * Sig, N // 10)))
+    E = rng.randn(S, d)
+    mu0, Sig0inv = np.zeros(d), np.eye(d)
+
+    def sampler(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts = np.zeros(1)
+            pts = np.zeros((1, Xc.shape[1]))
+        muw, LSigw, _ = R.gaussian.weighted_post(mu0, Sig0inv, Siginv, pts, wts)
+        return muw + E.dot(LSigw.T)
+
+    ll = lambda x, t: quiet(R.gaussian.gaussian_loglikelihood, x, t, Siginv, logdet)
+    bl = lambda x, t, beta: R.gaussian.gaussian_beta_likelihood(x, t, beta, Siginv, logdet)
+    bg = lambda x, t, beta: R.gaussian.gaussian_beta_gradient(x, t, beta, Siginv, logdet)
+    out = dict(X=Xc, E=E, Siginv=Siginv, logdet=np.array(logdet))
+    R.bcores.BetaCoreset._get_projection_ii = _get_projection_ii
+    # A second quirk limits what the reference can run even then: `self.wts = xf[:-1]` (bcores.py:139) is a VIEW, and
+    # the next _select that appends a point dies in `self.wts.resize` ("does not own its data", bcores.py:85).  So the
+    # path is pinned by (a) one build from scratch and (b) a pre-initialised 6-point coreset: one build (select appends
+    # the 7th point to owned arrays, then the beta-learning optimisation) followed by two more _optimize() calls.
+    init_idcs = np.sort(rng.choice(Xc.shape[0], 6, replace=False)).astype(np.int64)
+    out['init_idcs'] = init_idcs
+    try:
+        for tag, nsub in (('full', None), ('sub', 80)):
+            np.random.seed(150)
+            prj = R.projector.BetaBlackBoxProjector(sampler, S, bl, ll, bg)
+            mk = lambda **kw: R.bcores.BetaCoreset(Xc, prj, opt_itrs=8, n_subsample_opt=nsub, n_subsample_select=nsub,
+                                                   step_sched=lambda i: 0.1 / (1. + i), beta=.3, learn_beta=True, **kw)
+            alg = mk(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+            quiet(alg.build, 1, 1)
+            out[tag + '_one_allw'], out[tag + '_one_allidcs'], out[tag + '_one_beta'] = alg.wts.copy(), alg.idcs.copy(), np.array(alg.beta)
+            alg = mk(wts=np.full(6, Xc.shape[0] / 6.), idcs=init_idcs.copy(), pts=Xc[init_idcs].copy())
+            quiet(alg.build, 1, 7)
+            for m in range(3):
+                if m > 0:
+                    quiet(alg._optimize)
+                out['%s_init_allw_%d' % (tag, m)] = alg.wts.copy()
+                out['%s_init_allidcs_%d' % (tag, m)] = alg.idcs.copy()
+                out['%s_init_beta_%d' % (tag, m)] = np.array(alg.beta)
+            out['%s_rng_after' % tag] = np.array(np.random.rand())
+    finally:
+        del R.bcores.BetaCoreset._get_projection_ii
+    save('f15_learn_beta', **out)
+
+
 if __name__ == '__main__':
+    only = set(sys.argv[1:])
+    if only:
+        for fn in sorted(only):
+            globals()[fn]()
+        sys.exit(0)
     f1_snnls()
     f2_formulas()
     f3_hilbert_linreg()
@@ -452,3 +768,9 @@ if __name__ == '__main__':
     f7_nn_opt()
     f8_grouped_vi()
     f9_subsampled_gaussian()
+    f10_sampling()
+    f11_grouped_subsampled()
+    f12_constant_rows()
+    f13_greedy_vi_zero_rows()
+    f14_zellner_gaussian_driver()
+    f15_learn_beta()

@@ -228,9 +228,11 @@ def test_blackbox_projector_still_works(bc):
 
 
 def test_zero_rows_follow_reference_index_quirk(bc):
-    """hilbert.py:16 drops all-zero rows and then indexes the filtered matrix (hilbert.py:32)."""
+    """hilbert.py:16 drops all-zero rows and then indexes the filtered matrix (hilbert.py:32).  S = 16 makes every
+    constant row exactly zero (the pairwise mean of 16 equal doubles is exact); test_f12_* covers S = 100 / 200, where
+    most constant rows keep a rounding residue and are NOT dropped."""
     rng = np.random.RandomState(9)
-    n, d, s = 600, 5, 16                                           # S = 16: the mean of 16 equal doubles is exact
+    n, d, s = 600, 5, 16
     Z = rng.randn(n, d + 1)
     th = np.tile(rng.randn(1, d), (s, 1))
     th[:, 0] += rng.randn(s) * 0.3                                 # only x_0 distinguishes the samples
@@ -245,6 +247,88 @@ def test_zero_rows_follow_reference_index_quirk(bc):
     np.testing.assert_array_equal(idcs, ref.idcs)
     np.testing.assert_allclose(wts, ref.wts, rtol=1e-5)
     assert np.array_equal(pts, Z[idcs])
+
+
+@pytest.mark.parametrize('S', [100, 200])
+@pytest.mark.parametrize('kind', ['lin', 'log'])
+def test_f12_constant_rows_follow_numpy_mean(bc, S, kind):
+    """Rows with all-zero features project to S equal numbers c.  The reference subtracts NumPy's pairwise mean, so the
+    row becomes the constant c - mean (non-zero for ~3/4 of the rows at S = 100) and STAYS in the matrix; only rows whose
+    residue is exactly 0 are dropped and shift later indices (hilbert.py:16,32).  Device Phi of those rows must carry the
+    reference's bits, the kept / dropped split, the selections and the returned idcs must be the reference's."""
+    g = load_golden('f12_constant_rows')
+    za = g['zero_at']
+    tag = '%s_S%d_' % (kind, S)
+    Z, th = g[tag + 'Z'], g[tag + 'th']
+    model = bc.likelihoods.LinearRegression(1.0) if kind == 'lin' else bc.likelihoods.LogisticRegression()
+    prj = bc.DeviceProjector(fixed(th), S, model)
+    phi = prj.project(Z)
+    host = np.asarray(phi)
+    assert np.array_equal(host[za], g[tag + 'phi_const'])              # bit-exact: c - np.mean(S copies of c)
+    kept = phi.norms() > 0.
+    assert np.array_equal(kept, g[tag + 'kept'])
+    assert phi.norm_stats()[0] == int((~g[tag + 'kept']).sum())
+    for an, cls in (('giga', bc.snnls.GIGA), ('fw', bc.snnls.FrankWolfe)):
+        if tag + an + '_sel' not in g.files:
+            continue
+        steps = g[tag + an + '_sel'].shape[0]
+        h = bc.HilbertCoreset(Z, prj, snnls=cls)
+        h.build(steps, steps)
+        wts, pts, idcs = h.get()
+        np.testing.assert_array_equal(idcs, g[tag + an + '_idcs'])
+        np.testing.assert_allclose(wts, g[tag + an + '_wts'], rtol=1e-5)
+        assert np.array_equal(pts, Z[idcs])
+        # the trace holds row numbers of the un-filtered matrix; the reference's are those of the filtered one
+        sel = h.snnls._eng.trace()[0]
+        shift = np.cumsum(~g[tag + 'kept'])
+        np.testing.assert_array_equal(sel - shift[sel], g[tag + an + '_sel'])
+
+
+def const_row_ok(dev_row, c, S):
+    """A constant row on the device: all S entries equal, and equal to c' - np.mean(S copies of c') for a c' within
+    2 ulp of the reference's c (the ROCm libm and glibc may round exp / log1p differently)."""
+    if not np.all(dev_row == dev_row[0]):
+        return False
+    cands = [c]
+    for _ in range(2):
+        cands = [np.nextafter(cands[0], -np.inf)] + cands + [np.nextafter(cands[-1], np.inf)]
+    return any(dev_row[0] == cc - np.full(S, cc).mean() for cc in cands)
+
+
+def test_constant_rows_wide_projection_and_other_models(bc):
+    """The same rule through the S > 256 path (centring pass k_center_tiles) and for the beta / Gaussian models,
+    against NumPy's own mean (the oracle projection)."""
+    rng = np.random.RandomState(12)
+    n, d = 300, 6
+    za = np.array([0, 5, 128, 129, 299])
+    for S in (97, 112, 130, 256, 300, 515):
+        Z = rng.randn(n, d + 1)
+        Z[za, :d] = 0.
+        th = rng.randn(S, d) * 0.4
+        prj = bc.DeviceBetaProjector(fixed(th), S, bc.likelihoods.LinearRegression(1.7))
+        raw = M.linreg_loglik(Z, th, 1.7)                          # no transcendental: c is reproduced bit for bit
+        ref = raw - raw.mean(axis=1)[:, None]
+        got = prj.project(Z)
+        assert np.array_equal(np.asarray(got)[za], ref[za]), S
+        assert np.array_equal(got.norms() > 0, np.sqrt((ref ** 2).sum(axis=1)) > 0), S
+        rawb = M.linreg_beta_lik(Z, th, 0.2, 1.7)                   # one exp: the device's c may sit an ulp or two away
+        hostb = np.asarray(prj.project_f(Z, 0.2))
+        for r in za:
+            assert const_row_ok(hostb[r], rawb[r, 0], S), (S, r)
+    # Gaussian location: x = 0 rows are not constant (theta^T Siginv theta varies) -- but far outliers under the
+    # beta-likelihood are: exp(-beta q / 2) underflows and every sample gives -(1+beta)^(-d/2-1)
+    Sig = 500. * np.eye(d)
+    Si, ld = np.linalg.inv(Sig), np.linalg.slogdet(Sig)[1]
+    X = rng.multivariate_normal(np.zeros(d), Sig, n)
+    X[za] += 4000.
+    for S in (40, 100):
+        thg = rng.randn(S, d) * 3.
+        prj = bc.DeviceBetaProjector(fixed(thg), S, bc.likelihoods.GaussianLocation(Si, ld))
+        raw = M.gauss_beta_lik(X, thg, 0.3, Si, ld)
+        assert np.all(raw[za] == raw[za][:, :1])
+        host = np.asarray(prj.project_f(X, 0.3))
+        for r in za:
+            assert const_row_ok(host[r], raw[r, 0], S), (S, r)
 
 
 def test_vector_fma_variant_matches(bc):

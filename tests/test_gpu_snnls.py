@@ -301,3 +301,41 @@ def test_pure_c_consumer_runs(tmp_path, bc):
     out = subprocess.run([exe, 'run'], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'coreset of' in out.stdout
+
+
+# ------------------------------------------------------------------ F10: sampling "solvers" against the reference
+@pytest.mark.parametrize('nm', ['imp', 'unif'])
+def test_f10_sampling_solvers_golden(bc, nm):
+    """ImportanceSampling / UniformSampling (snnls/sampling.py:6-37): draws from the global NumPy RNG with
+    probabilities proportional to the device row norms; sequence, weights, error() and the RNG position after 30
+    draws equal the reference's -- directly and through HilbertCoreset(snnls=...) on a device projection."""
+    g = load_golden('f10_sampling')
+    phi, Z, th = g['phi'], g['Z'], g['th']
+    cls = bc.snnls.ImportanceSampling if nm == 'imp' else bc.snnls.UniformSampling
+    steps = g[nm + '_sel'].shape[0]
+    np.random.seed(100)
+    s = cls(phi.T, phi.sum(axis=0))
+    picks = []
+    orig = s._select
+
+    def logged():
+        f = orig()
+        picks.append(int(f))
+        return f
+    s._select = logged
+    for m in range(steps):
+        s.build(1)
+        assert picks[-1] == g[nm + '_sel'][m]
+        np.testing.assert_allclose(s.weights(), g[nm + '_W'][m], rtol=WTOL, atol=0)
+        np.testing.assert_allclose(s.error(), g[nm + '_err'][m], rtol=1e-9)
+        assert bool(s.reached_numeric_limit) == bool(g[nm + '_lim'][m])
+    assert np.random.rand() == float(g[nm + '_rng_after'])
+    np.random.seed(101)
+    prj = bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0))
+    h = bc.HilbertCoreset(Z, prj, snnls=cls)
+    h.build(steps, steps)
+    wts, pts, idcs = h.get()
+    np.testing.assert_array_equal(idcs, g[nm + '_h_idcs'])
+    np.testing.assert_allclose(wts, g[nm + '_h_wts'], rtol=WTOL)
+    np.testing.assert_allclose(h.error(), float(g[nm + '_h_err']), rtol=1e-9)
+    assert np.array_equal(pts, Z[idcs])

@@ -184,3 +184,256 @@ def test_f7_nn_opt():
     grd = lambda x: Q.dot(x) - c
     assert np.array_equal(C.nn_opt(x0, grd, opt_itrs=50, step_sched=lambda i: 0.5 / (1. + i)), g['nn'])
     assert np.array_equal(C.partial_nn_opt(x0, grd, np.arange(0, 12, 2), opt_itrs=50, step_sched=lambda i: 0.5 / (1. + i)), g['pnn'])
+
+
+# ------------------------------------------------------------------ F9-F15 (round 2)
+def _gauss_sampler(mu0, Sig0inv, Siginv, dz, S, E=None):
+    """sampler_w of zellner_gaussian/main.py:90-95; E = None draws from the global RNG."""
+    def sampler(wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, dz))
+        muw, LSigw, _ = M.gauss_weighted_post(mu0, Sig0inv, Siginv, pts, wts)
+        e = np.random.randn(S, muw.shape[0]) if E is None else E
+        return muw + e.dot(LSigw.T)
+    return sampler
+
+
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+def test_f9_subsampled_gaussian(nm):
+    g = load_golden('f9_subsampled_gaussian')
+    X, Si, ld = g['X'], g['Siginv'], float(g['logdet'])
+    d, S = X.shape[1], 40
+    np.random.seed(90)
+    sampler = _gauss_sampler(np.zeros(d), np.eye(d), Si, d, S)
+    sampler(np.array([]), np.array([]))                 # the projector constructor draws once (projector.py:18,46)
+    if nm == 'bcores':
+        proj = lambda p, th: C.project_f(lambda x, t, b: M.gauss_beta_lik(x, t, b, Si, ld), p, th, .1)
+    else:
+        proj = lambda p, th: C.project(lambda x, t: M.gauss_loglik(x, t, Si, ld), p, th)
+    alg = C.RefGreedyVI(X, proj, sampler, 8, lambda i: 0.1 / (1. + i), n_subsample_select=150, n_subsample_opt=60)
+    for m in range(6):
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-10, atol=1e-14)
+    assert np.random.rand() == float(g['%s_rng_after' % nm])
+
+
+@pytest.mark.parametrize('nm', ['imp', 'unif'])
+def test_f10_sampling_solvers(nm):
+    g = load_golden('f10_sampling')
+    phi = g['phi']
+    cls = O.RefImportanceSampling if nm == 'imp' else O.RefUniformSampling
+    np.random.seed(100)
+    steps = g[nm + '_sel'].shape[0]
+    sel, err, lim, W = stepwise(cls(phi.T, phi.sum(axis=0)), steps)
+    np.testing.assert_array_equal(sel, g[nm + '_sel'])
+    np.testing.assert_array_equal(lim, g[nm + '_lim'])
+    np.testing.assert_allclose(W, g[nm + '_W'], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(err, g[nm + '_err'], rtol=1e-10)
+    assert np.random.rand() == float(g[nm + '_rng_after'])
+    np.random.seed(101)
+    h = C.RefHilbert(g['Z'], lambda z, t: M.linreg_loglik(z, t, 1.0), g['th'], cls)
+    h.build(steps, steps)
+    np.testing.assert_array_equal(h.idcs, g[nm + '_h_idcs'])
+    np.testing.assert_allclose(h.wts, g[nm + '_h_wts'], rtol=1e-13)
+    np.testing.assert_allclose(h.error(), float(g[nm + '_h_err']), rtol=1e-10)
+
+
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+def test_f11_grouped_subsampled(nm):
+    g = load_golden('f11_grouped_subsampled')
+    Z, E = g['Z'], g['E']
+    groups = [list(r) for r in g['groups']]
+    D = Z.shape[1] - 1
+
+    def sampler(wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+        mu, L, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+    if nm == 'bcores':
+        proj = lambda pts, th: C.project_f(lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0), pts, th, 0.1)
+    else:
+        proj = lambda pts, th: C.project(lambda z, t: M.linreg_loglik(z, t, 1.0), pts, th)
+    np.random.seed(110)
+    alg = C.RefGreedyVI(Z, proj, sampler, int(g['opt_itrs']), lambda i: 0.1 / (1. + i), groups=groups,
+                        n_subsample_select=8, n_subsample_opt=50, size_check_always=(nm == 'svi'))
+    for m in range(5):
+        alg.build(1, 12 * (m + 1))
+        np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+        np.testing.assert_array_equal(alg.selected_groups, g['%s_groups_%d' % (nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-10, atol=1e-14)
+    assert np.random.rand() == float(g['%s_rng_after' % nm])
+
+
+def np_mean_of_constant(c, n):
+    """NumPy's pairwise sum of n copies of c, divided by n -- the model the K1 kernel implements for constant
+    rows (csrc/bc_internal.h: bc_np_sum_const_*)."""
+    def leaf(n):
+        if n < 8:
+            r = 0.
+            for _ in range(n):
+                r = r + c
+            return r
+        r = c
+        for _ in range(1, n // 8):
+            r = r + c
+        res = ((r + r) + (r + r)) + ((r + r) + (r + r))
+        for _ in range(n - (n // 8) * 8):
+            res = res + c
+        return res
+
+    def rec(n):
+        if n <= 128:
+            return leaf(n)
+        n2 = n // 2
+        n2 -= n2 % 8
+        return rec(n2) + rec(n - n2)
+    return rec(n) / n
+
+
+def test_constant_row_mean_model_matches_numpy():
+    rng = np.random.RandomState(0)
+    for S in list(range(1, 300)) + [500, 1000, 1024, 4097]:
+        cs = np.concatenate((rng.randn(40) * 10. ** rng.uniform(-3, 3, 40), [-np.log(2.), 0., 1., -0.5 * np.log(2 * np.pi)]))
+        a = np.repeat(cs[:, None], S, axis=1)
+        want = a.mean(axis=1)
+        got = np.array([np_mean_of_constant(float(c), S) for c in cs])
+        assert np.array_equal(want, got), S
+
+
+@pytest.mark.parametrize('S', [100, 200])
+def test_f12_constant_rows(S):
+    g = load_golden('f12_constant_rows')
+    za = g['zero_at']
+    for tag, ll, algs in (('lin_S%d_' % S, lambda z, t: M.linreg_loglik(z, t, 1.0), ('giga', 'fw')),
+                          ('log_S%d_' % S, M.logistic_loglik, ('giga',))):
+        Z, th = g[tag + 'Z'], g[tag + 'th']
+        phi = C.project(ll, Z, th)
+        assert np.array_equal(phi[za], g[tag + 'phi_const'])
+        kept = np.sqrt((phi ** 2).sum(axis=1)) > 0.
+        assert np.array_equal(kept, g[tag + 'kept'])
+        # every constant row: c - mean(c x S) with the pairwise-sum model
+        raw = ll(Z[za], th)
+        for r in range(len(za)):
+            assert np.all(raw[r] == raw[r, 0])
+            assert phi[za[r], 0] == raw[r, 0] - np_mean_of_constant(float(raw[r, 0]), S)
+        for an in algs:
+            steps = g['%s%s_sel' % (tag, an)].shape[0]
+            h, sel, err = _hilbert(Z, ll, th, steps, ALGS[an])
+            np.testing.assert_array_equal(sel, g['%s%s_sel' % (tag, an)])
+            np.testing.assert_array_equal(h.idcs, g['%s%s_idcs' % (tag, an)])
+            np.testing.assert_allclose(h.wts, g['%s%s_wts' % (tag, an)], rtol=1e-12)
+
+
+@pytest.mark.parametrize('S', [16, 100])
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+def test_f13_greedy_vi_zero_rows(S, nm):
+    g = load_golden('f13_greedy_vi_zero_rows')
+    Z, E = g['S%d_Z' % S], g['S%d_E' % S]
+    D = Z.shape[1] - 1
+
+    def sampler(wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+        mu, L, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+    if nm == 'bcores':
+        proj = lambda pts, th: C.project_f(lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0), pts, th, 0.1)
+    else:
+        proj = lambda pts, th: C.project(lambda z, t: M.linreg_loglik(z, t, 1.0), pts, th)
+    alg = C.RefGreedyVI(Z, proj, sampler, 5, lambda i: 0.1 / (1. + i))
+    for m in range(4):
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, g['S%d_%s_allidcs_%d' % (S, nm, m)])
+        np.testing.assert_array_equal(alg.wts, g['S%d_%s_allw_%d' % (S, nm, m)])
+
+
+def run_zellner_gaussian_oracle(nm, params):
+    """examples/zellner_gaussian/main.py:33-167 on the oracle classes (statement order = RNG order)."""
+    N, d, M_, opt_itrs, n_sub_opt, n_sub_sel, proj_dim, tr = [int(v) for v in params]
+    pihat_noise, i0 = 0.75, 0.1
+    np.random.seed(tr)
+    mu0, Sig0 = np.zeros(d), np.eye(d)
+    Sig = 500 * np.eye(d)
+    th = np.zeros(d)
+    Sig0inv, Siginv = np.linalg.inv(Sig0), np.linalg.inv(Sig)
+    logdetSig = np.linalg.slogdet(Sig)[1]
+    X = np.random.multivariate_normal(th, Sig, N)
+    mup, LSigp, LSigpInv = M.gauss_weighted_post(mu0, Sig0inv, Siginv, X, np.ones(X.shape[0]))
+    Sigp, SigpInv = LSigp.dot(LSigp.T), LSigpInv.dot(LSigpInv.T)
+    Xc = np.concatenate((X, np.random.multivariate_normal(th + 200, 0.5 * Sig, int(N / 50.)),
+                         np.random.multivariate_normal(th + 150, 0.1 * Sig, int(N / 50.)),
+                         np.random.multivariate_normal(th, 10 * Sig, int(N / 10.))))
+    th_opt = mup + np.random.randn(proj_dim, d).dot(LSigp.T)                       # prj_optimal's constructor draw
+    U = np.random.rand()
+    muhat = U * mup + (1. - U) * mu0
+    Sighat = U * Sigp + (1. - U) * Sig0
+    muhat += pihat_noise * np.sqrt((muhat ** 2).sum()) * np.random.randn(muhat.shape[0])
+    Sighat *= np.exp(-2 * pihat_noise * np.fabs(np.random.randn()))
+    LSighat = np.linalg.cholesky(Sighat)
+    th_real = mup + np.random.randn(proj_dim, d).dot(LSighat.T)                    # prj_realistic's
+    sampler_w = _gauss_sampler(mu0, Sig0inv, Siginv, d, proj_dim)
+    sampler_w(np.array([]), np.array([]))                                         # prj_w's
+    sampler_w(np.array([]), np.array([]))                                         # prj_bw's
+    ll = lambda x, t: M.gauss_loglik(x, t, Siginv, logdetSig)
+    sched = lambda i: i0 / (1. + i)
+    if nm == 'BCORES':
+        proj = lambda p, t: C.project_f(lambda x, tt, b: M.gauss_beta_lik(x, tt, b, Siginv, logdetSig), p, t, .1)
+        alg = C.RefGreedyVI(Xc, proj, sampler_w, opt_itrs, sched, n_subsample_select=n_sub_sel, n_subsample_opt=n_sub_opt)
+    elif nm == 'SVI':
+        alg = C.RefGreedyVI(Xc, lambda p, t: C.project(ll, p, t), sampler_w, opt_itrs, sched,
+                            n_subsample_select=n_sub_sel, n_subsample_opt=n_sub_opt, size_check_always=True)
+    else:
+        alg = C.RefHilbert(Xc, ll, th_opt if nm == 'GIGAO' else th_real)
+    w, p, idl = [np.array([0.])], [np.zeros((1, d))], [np.zeros(0, dtype=np.int64)]
+    for m in range(1, M_ + 1):
+        alg.build(1, m)
+        got = alg.get()
+        w.append(got[0].copy()); p.append(got[1].copy()); idl.append(got[2].copy())
+    rkl, fkl = np.zeros(M_ + 1), np.zeros(M_ + 1)
+    for m in range(M_ + 1):
+        muw, LSigw, LSigwInv = M.gauss_weighted_post(mu0, Sig0inv, Siginv, p[m], w[m])
+        rkl[m] = M.gaussian_KL(muw, LSigw.dot(LSigw.T), mup, SigpInv)
+        fkl[m] = M.gaussian_KL(mup, Sigp, muw, LSigwInv.dot(LSigwInv.T))
+    return w, idl, rkl, fkl, np.random.rand()
+
+
+@pytest.mark.parametrize('nm', ['BCORES', 'SVI', 'GIGAO', 'GIGAR'])
+def test_f14_zellner_gaussian_driver(nm):
+    g = load_golden('f14_zellner_gaussian_driver')
+    w, idl, rkl, fkl, rng_after = run_zellner_gaussian_oracle(nm, g['params'])
+    for m in range(len(w)):
+        np.testing.assert_array_equal(idl[m], g['%s_idcs_%d' % (nm, m)])
+        np.testing.assert_allclose(w[m], g['%s_w_%d' % (nm, m)], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(rkl, g[nm + '_rkl'], rtol=1e-8)
+    np.testing.assert_allclose(fkl, g[nm + '_fkl'], rtol=1e-8)
+    assert rng_after == float(g[nm + '_rng_after'])
+
+
+@pytest.mark.parametrize('tag,nsub', [('full', None), ('sub', 80)])
+def test_f15_learn_beta(tag, nsub):
+    g = load_golden('f15_learn_beta')
+    X, E, Si, ld = g['X'], g['E'], g['Siginv'], float(g['logdet'])
+    d, S = X.shape[1], E.shape[0]
+    sampler = _gauss_sampler(np.zeros(d), np.eye(d), Si, d, S, E=E)
+    proj = lambda p, th, b: C.project_f(lambda x, t, bb: M.gauss_beta_lik(x, t, bb, Si, ld), p, th, b)
+    bgrad = lambda p, th, b: C.project_f(lambda x, t, bb: M.gauss_beta_grad(x, t, bb, Si, ld), p, th, b)
+    mk = lambda **kw: C.RefGreedyVI(X, proj, sampler, 8, lambda i: 0.1 / (1. + i), n_subsample_select=nsub,
+                                    n_subsample_opt=nsub, beta=.3, learn_beta=True, beta_grad=bgrad, **kw)
+    np.random.seed(150)
+    alg = mk()
+    alg.build(1, 1)
+    np.testing.assert_array_equal(alg.idcs, g[tag + '_one_allidcs'])
+    np.testing.assert_allclose(alg.wts, g[tag + '_one_allw'], rtol=1e-10)
+    np.testing.assert_allclose(alg.beta, float(g[tag + '_one_beta']), rtol=1e-10)
+    ii = g['init_idcs']
+    alg = mk(wts=np.full(6, X.shape[0] / 6.), idcs=ii, pts=X[ii])
+    alg.build(1, 7)
+    for m in range(3):
+        if m > 0:
+            alg.optimize()
+        np.testing.assert_array_equal(alg.idcs, g['%s_init_allidcs_%d' % (tag, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_init_allw_%d' % (tag, m)], rtol=1e-10)
+        np.testing.assert_allclose(alg.beta, float(g['%s_init_beta_%d' % (tag, m)]), rtol=1e-10)
+    assert np.random.rand() == float(g['%s_rng_after' % tag])
