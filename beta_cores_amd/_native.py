@@ -10,7 +10,7 @@ import os
 from .util.errors import NumericalPrecisionError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbeta_cores.so')
+LIB_PATH = os.environ.get('BETA_CORES_LIB') or os.path.join(_HERE, 'libbeta_cores.so')   # override: A/B builds side by side
 
 BC_OK, BC_NUMERICAL_PRECISION, BC_INVALID_ARGUMENT = 0, 1, 2
 ALG_GIGA, ALG_FW, ALG_OMP = 0, 1, 2

@@ -106,14 +106,12 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
 // NT = number of 16-sample accumulator tiles, KC = D-chunk staged per LDS pass,
 // JT = 16-row sub-tiles per wave (2 -> 4 waves per 128-row tile, 1 -> 8 waves; the latter keeps
 // the accumulators of a 200+-sample projection within the register file).
-// TL = 0 or 4 "tail" samples beyond the NT tiles (S <= 16*NT + TL), contracted on the vector pipe from the
-// B-operand registers the MFMAs already hold: lane (g, row) accumulates sum_{d = g mod 4} x[row][d]*theta[16*NT+t][d]
-// for t = 0..3 and two shuffles across the four g-lanes of a row finish the dot products.  S = 100 (every
-// BASELINE config) thus runs 6 MFMA tiles + 4 tail samples instead of 7 tiles with 12 padded samples: the tail's
-// 8 v_fma_f64 per k-step hide behind 12 MFMAs, and the matrix pipe does 6/7 of the work.
+// TL = 0 or 4 "tail" samples beyond the NT tiles (S <= 16*NT + TL): one sample QUAD contracted with
+// v_mfma_f64_4x4x4_4b_f64 (see the loop).  S = 100 (every BASELINE config) thus runs 6 tiles + 1 quad = exactly
+// 100 samples instead of 7 tiles with 12 padded ones.
 template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0>
 __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2) void k_project(ProjArgs a) {
-  static_assert(TL == 0 || (TL == 4 && !RAW), "tail: exactly one extra sample per g-lane");
+  static_assert(TL == 0 || (TL == 4 && !RAW), "tail: exactly one extra sample quad");
   constexpr int NTHR = 128 / (16 * JT) * 64;
   constexpr int NR = NT * 16 + TL;                // rows of (padded) Theta this kernel contracts with
   constexpr int LDZ = KC + 1;    // odd stride: rows (2j, 2j+1) of a lane pair hit distinct banks
@@ -137,11 +135,9 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
     for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
-  double tl[JT][TL > 0 ? TL : 1];
+  double tv[JT];
 #pragma unroll
-  for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-    for (int t = 0; t < (TL > 0 ? TL : 1); ++t) tl[jt][t] = 0.;
+  for (int jt = 0; jt < JT; ++jt) tv[jt] = 0.;
 
   // Staging through buffer loads: a wave-uniform descriptor per operand (SGPRs), ONE 32-bit
   // per-thread byte offset shared by all passes, and a scalar offset per pass -- no 64-bit
@@ -182,12 +178,25 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
 
   const int nchunks = a.dk / KC;
   load_chunk(0);
+  // per-row extra (y / x^T Siginv x): requested now, consumed in the epilogue (a dependent load there cost its
+  // full memory latency per tile)
+  double ra_pf[JT];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+    const long long gr = r0 + row_base + jt;
+    ra_pf[jt] = 0.;
+    if (gr < a.n_rows) {
+      if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra_pf[jt] = a.z[(size_t)gr * a.dz + a.d];
+      else if (MODEL >= BC_MODEL_GAUSS_LL) ra_pf[jt] = a.rowaux[gr];
+    }
+  }
   for (int c = 0; c < nchunks; ++c) {
     store_chunk();
     __syncthreads();
     if (c + 1 < nchunks) load_chunk((c + 1) * KC);
     const double* zrow0 = Zl + row_base * LDZ + g;
     const double* trow = Tl + j * LDT + g;
+    const double* tquad = Tl + (NT * 16 + (j & 3)) * LDT + g;
 #pragma unroll 2
     for (int kk = 0; kk < KC / 4; ++kk) {
       double bz[JT];
@@ -200,31 +209,18 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         for (int jt = 0; jt < JT; ++jt) acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bz[jt], acc[jt][st], 0, 0, 0);
       }
       if (TL > 0) {
-        const double* ttail = Tl + (NT * 16) * LDT + g;
+        // the 25th sample quad (S in 97..100) on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per
+        // instruction; lane (g, q = 4*blk + t) supplies A_blk[t][g], B_blk[g][t] and receives D_blk[g][t]
+        // (tools/mfma_f64_4x4x4_layout.hip).  With the same Theta quad in all four blocks and the sub-tile's 16
+        // rows spread over (blk, t), the lane receives, for ITS row, sample 16*NT + g: the accumulator layout of
+        // the 16x16x4 tiles, from the B operand they already hold.  (Round 1 contracted these four samples on the
+        // vector pipe: 8 v_fma_f64 + 4 operand reads per k-step and 8 shuffles per tile instead of 2 + 1 + 0.)
+        const double at = tquad[kk * 4];
 #pragma unroll
-        for (int t = 0; t < TL; ++t) {
-          const double at = ttail[t * LDT + kk * 4];
-#pragma unroll
-          for (int jt = 0; jt < JT; ++jt) tl[jt][t] = fma(at, bz[jt], tl[jt][t]);
-        }
+        for (int jt = 0; jt < JT; ++jt) tv[jt] = __builtin_amdgcn_mfma_f64_4x4x4f64(at, bz[jt], tv[jt], 0, 0, 0);
       }
     }
     __syncthreads();
-  }
-  // tail samples: combine the four d-residue classes of a row, lane g keeps sample 16*NT + g
-  double tv[JT];
-#pragma unroll
-  for (int jt = 0; jt < JT; ++jt) {
-    tv[jt] = 0.;
-    if (TL > 0) {
-#pragma unroll
-      for (int t = 0; t < TL; ++t) {
-        double x = tl[jt][t];
-        x += __shfl_xor(x, 16, BC_WAVE);
-        x += __shfl_xor(x, 32, BC_WAVE);
-        if (t == g) tv[jt] = x;
-      }
-    }
   }
   const int s_tail = NT * 16 + g;
 
@@ -236,11 +232,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     for (int jt = 0; jt < JT; ++jt) {
       const long long gr = r0 + row_base + jt;
       const bool live = gr < a.n_rows;
-      double ra = 0.;
-      if (live) {
-        if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra = a.z[(size_t)gr * a.dz + a.d];
-        else if (MODEL >= BC_MODEL_GAUSS_LL) ra = a.rowaux[gr];
-      }
+      const double ra = ra_pf[jt];
 #pragma unroll
       for (int st = 0; st < NT; ++st)
 #pragma unroll
@@ -261,11 +253,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   for (int jt = 0; jt < JT; ++jt) {
     const long long gr = r0 + row_base + jt;
     const bool live = gr < a.n_rows;
-    double ra = 0.;
-    if (live) {
-      if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra = a.z[(size_t)gr * a.dz + a.d];
-      else if (MODEL >= BC_MODEL_GAUSS_LL) ra = a.rowaux[gr];
-    }
+    const double ra = ra_pf[jt];
     double sum = 0., vmin = INFINITY, vmax = -INFINITY;
     // TL > 0 kernels (96 < S <= 100): every sample of the NT tiles is a real one and every lane holds some, so the
     // `s < S` predicates vanish and "all S values equal" is tracked with compares against the lane's first value
@@ -767,7 +755,7 @@ template <int MODEL>
 static int launch_project_nt(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int ntsel) {
   switch (ntsel) {
     case 4: return launch_project<MODEL, 4, 32, 2>(ctx, a, ntiles);
-    case 6: return launch_project<MODEL, 6, 32, 2, false, 4>(ctx, a, ntiles);      // 96 < S <= 100: 6 tiles + 4 tail samples
+    case 6: return launch_project<MODEL, 6, 32, 2, false, 4>(ctx, a, ntiles);      // 96 < S <= 100: 6 tiles + 1 sample quad
     case 7: {
       static const int jt1 = getenv("BC_K1_JT1") ? atoi(getenv("BC_K1_JT1")) : 0;
       if (jt1) return launch_project<MODEL, 7, 32, 1>(ctx, a, ntiles);
