@@ -149,8 +149,10 @@ def main():
     ctx.kernel_time_reset()
     barrier()
     t0 = time.perf_counter()
+    phi = None
     for i in range(args.proj_reps):
         ta = time.perf_counter()
+        phi = None                         # hand the previous result's buffers back first: every rep writes the same Phi
         phi = prj.project(data)
         if os.environ.get('BC_BENCH_VERBOSE'):
             sys.stderr.write('project rep %d: %.3f ms (host call incl. sync)\n' % (i, 1e3 * (time.perf_counter() - ta)))

@@ -12,7 +12,7 @@ from .util.errors import NumericalPrecisionError
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BETA_CORES_LIB') or os.path.join(_HERE, 'libbeta_cores.so')   # override: A/B builds side by side
 
-BC_OK, BC_NUMERICAL_PRECISION, BC_INVALID_ARGUMENT = 0, 1, 2
+BC_OK, BC_NUMERICAL_PRECISION, BC_INVALID_ARGUMENT, BC_RETRY_EXACT = 0, 1, 2, 3
 ALG_GIGA, ALG_FW, ALG_OMP = 0, 1, 2
 TILE_ROWS = 128
 
@@ -68,11 +68,13 @@ _SIGNATURES = {
     'bc_snnls_record_doubles': [vp, c_i32p],
     'bc_snnls_build_begin': [vp, C.c_int],
     'bc_snnls_step_local': [vp],
+    'bc_snnls_step_local_exact': [vp],
     'bc_snnls_step_finish': [vp],
-    'bc_snnls_build_end': [vp, c_ip, c_ip],
+    'bc_snnls_build_end': [vp, c_ip, c_ip, c_ip],
     'bc_snnls_build': [vp, C.c_int, c_ip],
     'bc_snnls_select': [vp, c_i64p],
     'bc_snnls_select_local': [vp],
+    'bc_snnls_select_local_exact': [vp],
     'bc_snnls_select_pick': [vp, c_i64p],
     'bc_snnls_reweight': [vp, C.c_int64],
     'bc_snnls_error': [vp, c_dp],

@@ -118,17 +118,33 @@ __device__ __forceinline__ void bc_wave_argmax(double& v, long long& i) {
   }
 }
 
-__device__ __forceinline__ double bc_wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, BC_WAVE);
-  return v;
+// Wave-wide sum of a double, the total in EVERY lane (all 64 lanes must be active).  Inside a 16-lane row the
+// partners come through DPP row rotations (v_mov_b32_dpp: a few cycles each) -- a rotation butterfly, so all lanes of
+// a row hold bit-identical sums -- and the four row sums are combined from SGPRs (v_readlane) in a fixed order.  The
+// __shfl_down tree this replaces moved each step through ds_bpermute: ~1.5k cycles per reduction, and the
+// single-block step kernels do a dozen of them back to back (8 of the 20 us of a greedy step's tail).
+template <int CTRL>
+__device__ __forceinline__ double bc_dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
 
-// wave-wide sum, result in every lane (fixed shuffle tree: deterministic)
-__device__ __forceinline__ double bc_wave_sum_all(double v) {
-  v = bc_wave_sum(v);
-  return __shfl(v, 0, BC_WAVE);
+__device__ __forceinline__ double bc_readlane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
 }
+
+__device__ __forceinline__ double bc_wave_sum_all(double v) {
+  v += bc_dpp_mov<0x128>(v);   // row_ror:8
+  v += bc_dpp_mov<0x124>(v);   // row_ror:4
+  v += bc_dpp_mov<0x122>(v);   // row_ror:2
+  v += bc_dpp_mov<0x121>(v);   // row_ror:1
+  return (bc_readlane(v, 0) + bc_readlane(v, 16)) + (bc_readlane(v, 32) + bc_readlane(v, 48));
+}
+
+__device__ __forceinline__ double bc_wave_sum(double v) { return bc_wave_sum_all(v); }
 
 // block-wide sum, result broadcast to every thread; red must hold >= 17 doubles
 __device__ __forceinline__ double bc_block_sum(double v, double* red) {

@@ -18,16 +18,15 @@
 //                         through their maximum U.  The candidates' scores are recomputed from the fp64 Phi
 //                         with the same arithmetic (same fma chain, same epilogue) as k_sweep, the argmax is
 //                         taken with NumPy's tie rule, and the candidate record is emitted.
-//   If the candidate list overflows, the same launch falls back to the full fp64 sweep: k_rescore runs with one
-//   block per CU; block 0 does the work above while the others wait for its verdict (they exit at once in the
-//   common case) and, on overflow, all of them sweep the fp64 Phi and block 0 merges their winners.
+//   If the candidate lists overflow, no record is produced; the step is marked and the host re-runs it with the
+//   exact fp64 sweep, stream-ordered (bc_rescore_dev.h, bc_snnls.hip: pf_overflow).
 //
 // Algorithmic traffic per row: fp16 2*S + 8 (norm) + 4 (U written) bytes; fp32 4*S + 12.
 //
 // The fp16 kernel accumulates in fp32 (v_cvt_f32_f16 + v_pk_fma_f32: both dot products of a row in one packed
 // FMA) and double-buffers its loads in registers; its planes are padded with zeros to a multiple of BC_HU and
 // the sweep vectors carry a zero tail (BC_V_PAD, bc_snnls.hip), so there is no remainder loop.
-#include "bc_sweep_dev.h"
+#include "bc_rescore_dev.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -53,11 +52,8 @@ struct bc_pref {
   double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
   float* blk_u = nullptr;     // [grid] block maxima of the upper bounds (lets the selection skip whole blocks of tiles)
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
-  int* ctrl = nullptr;        // [1] the last launch fell back to the fp64 sweep, [2] hand-shake timeout, [3] fallbacks so far,
+  int* ctrl = nullptr;        // [1] the last rescoring overflowed, [3] overflows so far,
                               // [4..5] sweeps so far (u64), [6..7] candidates rescored so far (u64)
-  unsigned* sync = nullptr;   // in-launch hand-shake of k_rescore (verdict, arrivals)
-  unsigned epoch = 0;         // launch sequence number of k_rescore
-  int helpers_grid = 1;       // blocks of k_rescore: block 0 + fallback helpers
   int cap = 4096;
   long long ptiles = 0;
   int grid = 1;
@@ -85,33 +81,8 @@ struct PrefArgs {
 
 typedef float bc_f4 __attribute__((ext_vector_type(4)));
 
-// bound of |fp64-kernel dot - fp32-input dot| for unit ||v||: 2^-24 (input rounding, Cauchy-Schwarz with
-// ||u_i|| <= 1 + 2^-24) plus the two fma chains' rounding (S * 2^-53 each), with margin.
-#define BC_PREF_DELTA 6.2e-8
-
-template <int MODE>
-__device__ __forceinline__ void bc_score_interval(double s0, double s1, double delta, double post_div, double& U, double& L) {
-  if (MODE == 0) {
-    const double a = fabs(s1) + delta;
-    const double c = 1. - a * a;
-    if (!(s0 == s0) || !(s1 == s1) || !(c > 1e-6)) {   // NaN, or too close to the validity boundary of giga.py:33
-      U = INFINITY;
-      L = -INFINITY;
-      return;
-    }
-    const double f = s0 / sqrt(1. - s1 * s1);
-    const double rc = 1. / sqrt(c);
-    const double e = delta * (rc + (fabs(s0) + delta) * a * rc * rc * rc) * 1.001 + 1e-13 * (1. + fabs(f));
-    U = f + e;
-    L = f - e;
-  } else {
-    if (!(s0 == s0)) { U = INFINITY; L = -INFINITY; return; }
-    const double f = s0 / post_div;
-    const double e = (delta * 1.001 + 1e-13 * fabs(s0)) / fabs(post_div);
-    U = f + e;
-    L = f - e;
-  }
-}
+// BC_PREF_DELTA (bc_rescore_dev.h): bound of |fp64-kernel dot - fp32-input dot| for unit ||v||: 2^-24 (input rounding,
+// Cauchy-Schwarz with ||u_i|| <= 1 + 2^-24) plus the two fma chains' rounding (S * 2^-53 each), with margin.
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
@@ -204,7 +175,6 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
 #include "bc_prefilter_i8.h"
 
 // ---- fp16 variant.  Tile = 512 rows, [S][512] halfs: one sample of a tile = 1 KiB = 64 lanes x 8 halfs.
-#define BC_HTILE 512
 typedef _Float16 bc_h8 __attribute__((ext_vector_type(8)));
 
 // bound of |fp64-kernel dot - (fp16 rows, fp32 v, fp32 fma chain) dot| for unit ||v||, ||u|| = 1:
@@ -214,7 +184,6 @@ typedef _Float16 bc_h8 __attribute__((ext_vector_type(8)));
 // every term taken with margin.
 static double bc_pref_delta16(int S) { return 4.8845e-4 + 3.0e-8 * sqrt((double)S) + 6.1e-8 * (double)(S + 2); }
 
-#define BC_HU 10   // sample planes per batch; the stored plane count is padded to a multiple (zero planes)
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sweep_f16(PrefArgs a) {
@@ -325,461 +294,21 @@ __global__ __launch_bounds__(256) void k_build_u16(const double* __restrict__ ti
   }
 }
 
-struct RescoreArgs {
-  const double* tiles;
-  const double* norms;
-  const double* v;
-  const int* skip_flag;
-  const float* ub;
-  const float* tile_u;
-  const double* blk_l;
-  const float* blk_u;
-  const _Float16* u16;       // fp16 mode: the per-row bounds of candidate tiles are recomputed from the mirror
-  const unsigned char* live;
-  const double* v_norm;
-  double delta;
-  int sp;
-  const float2* tile_cand;   // int8 mode: the sweep left up to 4 (upper bound, row) pairs per tile
-  const int* tile_ncand;
-  long long* cand;
-  int* ctrl;
-  double* rec;
-  long long row_offset, ptiles;
-  double post_div;
-  int s, cap, nblk, ptile;
-  int tile_rounds;           // tiles per sweep wave = ceil(ptiles / (4 * nblk)): block b swept tiles 4b+w + 4*nblk*i
-};
-
-// same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
+// passes B + C as their own launch (one block): multi-rank steps (the record goes into the exchange) and the
+// step-wise protocol.  On overflow the record carries BC_REC_OVERFLOW in its `valid` slot: whoever consumes the
+// gathered records (finish / pick kernels, every rank alike) turns that into "redo this step with the exact sweep".
 template <int MODE>
-__device__ __forceinline__ double bc_exact_score(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
-                                                 int S, double nr, double post_div) {
-  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
-  double a0 = 0., a1 = 0.;
-  int k = 0;
-  for (; k + 32 <= S; k += 32) {     // 32 independent loads in flight: this kernel is pure latency
-    double x[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) x[u] = p[(size_t)(k + u) * BC_TILE];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      if (MODE == 0) {
-        a0 = fma(x[u], v[2 * (k + u)], a0);
-        a1 = fma(x[u], v[2 * (k + u) + 1], a1);
-      } else {
-        a0 = fma(x[u], v[k + u], a0);
-      }
-    }
-  }
-  for (; k < S; ++k) {
-    const double x = p[(size_t)k * BC_TILE];
-    if (MODE == 0) {
-      a0 = fma(x, v[2 * k], a0);
-      a1 = fma(x, v[2 * k + 1], a1);
-    } else {
-      a0 = fma(x, v[k], a0);
-    }
-  }
-  if (MODE == 0) {
-    const double s0 = a0 / nr, s1 = a1 / nr;
-    const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
-    const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
-    return s0 / den;
-  }
-  return a0 / nr / post_div;
-}
-
-// The same score, computed by a whole wave for ONE row: the lanes fetch the row (and the sweep vectors) with one
-// round of independent loads -- lane l holds elements l, l+64, ... -- and then every lane runs the identical
-// sequential fma chain on broadcast values (v_readlane), so the result has the bits of bc_exact_score / k_sweep.
-// With a handful of candidates this replaces ~4 dependent load batches per candidate by one.
-// The same score, computed by a whole wave for ONE row: the lanes fetch the row and the sweep vectors with one
-// round of independent loads -- lane l holds elements l, l+64, ... --, park them in a wave-private LDS strip
-// and every lane then runs the identical sequential fma chain on broadcast LDS reads, so the result has the
-// bits of bc_exact_score / k_sweep.  With a handful of candidates this replaces four dependent load batches and
-// a one-lane chain by one round trip and a pipelined chain.  (Wave-private strip: LDS serves a wave's requests in
-// order, the wavefront-scope fences only keep the compiler from reordering.)
-template <int MODE>
-__device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
-                                                      int S, double nr, double post_div, double* strip /* [3][256] */) {
-  const int lane = threadIdx.x & 63;
-  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
-  double* sx = strip;
-  double* sa = strip + 256;
-  double* sb = strip + 512;
-  double a0 = 0., a1 = 0.;
-  for (int base = 0; base < S; base += 256) {
-    double x[4], vx[4], vy[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = base + 64 * e + lane;
-      const bool in = k < S;
-      x[e] = in ? p[(size_t)k * BC_TILE] : 0.;
-      if (MODE == 0) {
-        vx[e] = in ? v[2 * k] : 0.;
-        vy[e] = in ? v[2 * k + 1] : 0.;
-      } else {
-        vx[e] = in ? v[k] : 0.;
-        vy[e] = 0.;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous block's reads come first
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sx[64 * e + lane] = x[e];
-      sa[64 * e + lane] = vx[e];
-      if (MODE == 0) sb[64 * e + lane] = vy[e];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int n = (S - base) < 256 ? (S - base) : 256;
-#pragma unroll 8
-    for (int kk = 0; kk < n; ++kk) {
-      const double xk = sx[kk];
-      a0 = fma(xk, sa[kk], a0);
-      if (MODE == 0) a1 = fma(xk, sb[kk], a1);
-    }
-  }
-  if (MODE == 0) {
-    const double s0 = a0 / nr, s1 = a1 / nr;
-    const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
-    const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
-    return s0 / den;
-  }
-  return a0 / nr / post_div;
-}
-
-// In-launch hand-shake between block 0 (selection + rescoring) and the helper blocks (fp64 fallback).
-//   sync[0]  verdict of launch `epoch`: 4*epoch + 1 = fall back, 4*epoch + 2 = done, nothing to do
-//   sync[1]  arrivals of the helper blocks after their share of the fallback sweep (reset by block 0)
-// Every wait is bounded, so the grid drains even if the protocol were broken (ctrl[2] records a timeout).
-#define BC_RS_SPIN_LIMIT (1 << 24)
-#define BC_RS_TILE_LIMIT16 64   // fp16 mode recomputes candidate tiles (~3 us each): past this the fp64 sweep is cheaper
-typedef _Float16 bc_h2 __attribute__((ext_vector_type(2)));
-// polling load: relaxed (an acquire per poll would invalidate caches 255 blocks x every poll and slow
-// block 0 down); the one acquire fence follows once the awaited value has been seen
-__device__ __forceinline__ unsigned bc_ld_poll(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// one plane of the fp32 chain for a thread's two rows (k_rescore's recomputation of a candidate tile)
-template <int MODE>
-__device__ __forceinline__ void bc_rs_accumulate(bc_h2 x, const double* __restrict__ v, int k, float (&a0)[2], float (&a1)[2]) {
-  if (MODE == 0) {
-    const float vx = (float)v[2 * k], vy = (float)v[2 * k + 1];
-    a0[0] = fmaf((float)x[0], vx, a0[0]);
-    a1[0] = fmaf((float)x[0], vy, a1[0]);
-    a0[1] = fmaf((float)x[1], vx, a0[1]);
-    a1[1] = fmaf((float)x[1], vy, a1[1]);
-  } else {
-    const float vx = (float)v[k];
-    a0[0] = fmaf((float)x[0], vx, a0[0]);
-    a0[1] = fmaf((float)x[1], vx, a0[1]);
-  }
-}
-
-// passes B + C: Lmax = max of the block lower bounds; candidates = rows whose upper bound reaches it (whole
-// tiles are skipped through their maximum); exact fp64 rescoring; record.  Grid = 1 + helpers.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, bc_sweep_args sw, double* __restrict__ blk_val,
-                                                long long* __restrict__ blk_idx, unsigned* __restrict__ sync,
-                                                unsigned epoch) {
-  __shared__ double sv[4];
-  __shared__ long long si[4];
-  __shared__ long long win;
-  __shared__ int cnt;
-  __shared__ int tcnt;
-  __shared__ int tlist[1024];
-  __shared__ unsigned verdict;
-  __shared__ int bcnt;
-  __shared__ int blist[64];                  // sweep blocks whose maximum upper bound reaches Lmax
-  __shared__ long long scand[32];            // the first candidates, kept on chip (the usual case has 1-3)
-  __shared__ double strips[4][3 * 256];      // bc_exact_score_wave: one strip per wave
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, long long n_rows) {
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
-
-  if (blockIdx.x != 0) {
-    // ---- helper block: wait for block 0's verdict
-    if (threadIdx.x == 0) {
-      unsigned v = 0;
-      for (int spin = 0; spin < BC_RS_SPIN_LIMIT; ++spin) {
-        v = bc_ld_poll(sync);
-        if ((v >> 2) == epoch) break;
-        __builtin_amdgcn_s_sleep(32);
-      }
-      verdict = ((v >> 2) == epoch) ? (v & 3u) : 2u;
-      if (verdict == 1u) __threadfence();
-    }
-    __syncthreads();
-    if (verdict != 1u) return;
-    double bv;
-    long long bi;
-    bc_sweep_block<MODE>(sw, blockIdx.x, gridDim.x, false, sv, si, bv, bi);
-    if (threadIdx.x == 0) {
-      blk_val[blockIdx.x] = bv;
-      blk_idx[blockIdx.x] = bi;
-      __threadfence();                         // release the candidate before arriving
-      atomicAdd(sync + 1, 1u);
-    }
-    return;
-  }
-
-  // ---- block 0
-  bool overflow = false;
-  if (!skip) {
-    double lmax = -INFINITY;
-    float bu[4];                               // this thread's share of the block upper bounds (nblk <= 1024)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = threadIdx.x + q * 256;
-      bu[q] = -INFINITY;
-      if (i < a.nblk) {
-        lmax = fmax(lmax, a.blk_l[i]);
-        bu[q] = a.blk_u[i];
-      }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
-    if (lane == 0) sv[wave] = lmax;
-    if (threadIdx.x == 0) { cnt = 0; tcnt = 0; bcnt = 0; }
-    __syncthreads();
-    lmax = fmax(fmax(sv[0], sv[1]), fmax(sv[2], sv[3]));
-    // phase B1: tiles whose maximum upper bound reaches Lmax -- first the sweep blocks whose maximum does
-    // (usually one or two), then only the tiles those blocks walked
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (bu[q] != -INFINITY && (double)bu[q] >= lmax) {
-        const int slot = atomicAdd(&bcnt, 1);
-        if (slot < 64) blist[slot] = threadIdx.x + q * 256;
-      }
-    __syncthreads();
-    const int nbl = bcnt;
-    if (nbl <= 64) {
-      const int per = 4 * a.tile_rounds, total = nbl * per;
-      for (int i0 = 0; i0 < total; i0 += 8 * blockDim.x) {
-        float tu[8];
-        long long tt[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = i0 + u * blockDim.x + threadIdx.x;
-          tt[u] = -1;
-          tu[u] = -INFINITY;
-          if (idx < total) {
-            const int b = blist[idx / per], q = idx % per;
-            const long long t = (long long)b * 4 + (q & 3) + (long long)(q >> 2) * 4 * a.nblk;
-            if (t < a.ptiles) { tt[u] = t; tu[u] = a.tile_u[t]; }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (tt[u] >= 0 && tu[u] != -INFINITY && (double)tu[u] >= lmax) {
-            const int slot = atomicAdd(&tcnt, 1);
-            if (slot < 1024) tlist[slot] = (int)tt[u];
-          }
-      }
-    } else {
-      // many blocks in play: scan all per-tile maxima, 16 independent loads at a time
-      for (long long t0 = 0; t0 < a.ptiles; t0 += 16LL * blockDim.x) {
-        float tu[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const long long t = t0 + (long long)u * blockDim.x + threadIdx.x;
-          tu[u] = t < a.ptiles ? a.tile_u[t] : -INFINITY;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (tu[u] != -INFINITY && (double)tu[u] >= lmax) {
-            const int slot = atomicAdd(&tcnt, 1);
-            if (slot < 1024) tlist[slot] = (int)(t0 + (long long)u * blockDim.x + threadIdx.x);
-          }
-      }
-    }
-    __syncthreads();
-    const int ntl = tcnt;
-    if (threadIdx.x == 0) bcnt = 0;            // reused by the int8 branch below
-    __syncthreads();
-    overflow = ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
-    if (!overflow && a.tile_cand) {
-      // phase B2 (int8 mirror): the pairs the sweep left for each such tile; a tile with more than four local
-      // candidates hands over all of its rows
-      for (int q = threadIdx.x; q < ntl; q += blockDim.x) {
-        const long long t = tlist[q];
-        const int n = a.tile_ncand[t];
-        float2 prs[4];                           // fetched together with the count: one round trip
-#pragma unroll
-        for (int i = 0; i < 4; ++i) prs[i] = a.tile_cand[t * 4 + i];
-        if (n <= 4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float2 pr = prs[i];
-            if (i < n && (double)pr.x >= lmax) {
-              const int slot = atomicAdd(&cnt, 1);
-              const long long row = t * a.ptile + (int)pr.y;
-              if (slot < a.cap) a.cand[slot] = row;
-              if (slot < 32) scand[slot] = row;
-            }
-          }
-        } else {
-          const int o = atomicAdd(&bcnt, 1);      // (bcnt is free again after phase B1)
-          if (o < 64) blist[o] = (int)t;
-        }
-      }
-      __syncthreads();
-      const int no = bcnt;
-      overflow = no > 64;
-      if (!overflow) {
-        for (int o = 0; o < no; ++o) {
-          const long long row = (long long)blist[o] * a.ptile + threadIdx.x;      // ptile == blockDim.x == 256
-          if (row < sw.n_rows && a.norms[row] != 0.) {
-            const int slot = atomicAdd(&cnt, 1);
-            if (slot < a.cap) a.cand[slot] = row;
-            if (slot < 32) scand[slot] = row;
-          }
-        }
-        __syncthreads();
-        overflow = cnt > a.cap;
-      }
-    } else if (!overflow && a.u16) {
-      // phase B2 (fp16 mirror): recompute the per-row intervals of each such tile from the mirror -- the sweep
-      // wrote none.  Thread = two adjacent rows of the tile (one 4-byte load per plane, 1 KiB per plane and
-      // block), up to 64 planes in flight; fp32 chain, same interval formula and delta as the sweep.
-      const double delta = (MODE == 0) ? a.delta : a.delta * (*a.v_norm);
-      for (int q = 0; q < ntl; ++q) {
-        const long long t = tlist[q];
-        const bc_h2* __restrict__ tp = reinterpret_cast<const bc_h2*>(a.u16 + (size_t)t * a.sp * BC_HTILE) + threadIdx.x;
-        float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
-        // sp is a multiple of BC_HU = 10: batches of 50 planes (all loads of a batch in flight), then of 10
-        int k0 = 0;
-        for (; k0 + 50 <= a.sp; k0 += 50) {
-          bc_h2 x[50];
-#pragma unroll
-          for (int u = 0; u < 50; ++u) x[u] = tp[(size_t)(k0 + u) * (BC_HTILE / 2)];
-#pragma unroll
-          for (int u = 0; u < 50; ++u) bc_rs_accumulate<MODE>(x[u], a.v, k0 + u, a0, a1);
-        }
-        for (; k0 < a.sp; k0 += BC_HU) {
-          bc_h2 x[BC_HU];
-#pragma unroll
-          for (int u = 0; u < BC_HU; ++u) x[u] = tp[(size_t)(k0 + u) * (BC_HTILE / 2)];
-#pragma unroll
-          for (int u = 0; u < BC_HU; ++u) bc_rs_accumulate<MODE>(x[u], a.v, k0 + u, a0, a1);
-        }
-        const unsigned lv = a.live[t * 64 + (threadIdx.x >> 2)];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int i = 2 * threadIdx.x + j;                    // row within the tile
-          if ((lv >> (i & 7)) & 1u) {
-            double Ub, Lb;
-            bc_score_interval<MODE>((double)a0[j], (double)a1[j], delta, a.post_div, Ub, Lb);
-            if (Ub >= lmax) {
-              const int slot = atomicAdd(&cnt, 1);
-              if (slot < a.cap) a.cand[slot] = t * BC_HTILE + i;
-              if (slot < 32) scand[slot] = t * BC_HTILE + i;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      overflow = cnt > a.cap;
-    } else if (!overflow) {
-      // phase B2 (fp32 mirror): one wave per such tile, all of the tile's stored upper bounds in flight at once
-      for (int q = wave; q < ntl; q += 4) {
-        const long long t = tlist[q];
-        float u8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int i = lane + 64 * e;
-          u8[e] = i < a.ptile ? a.ub[t * a.ptile + i] : -INFINITY;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (u8[e] != -INFINITY && (double)u8[e] >= lmax) {
-            const int slot = atomicAdd(&cnt, 1);
-            if (slot < a.cap) a.cand[slot] = t * a.ptile + lane + 64 * e;
-            if (slot < 32) scand[slot] = t * a.ptile + lane + 64 * e;
-          }
-      }
-      __syncthreads();
-      overflow = cnt > a.cap;
-    }
-  }
-  // verdict for the helpers (block-uniform: tcnt / cnt are shared)
-  if (threadIdx.x == 0) {
-    a.ctrl[1] = overflow ? 1 : 0;              // observable: the last launch fell back
-    if (overflow) a.ctrl[3] += 1;              // ... and how often since creation
-    if (!skip) {                               // diagnostics: sweeps and candidates rescored since creation
-      unsigned long long* st = reinterpret_cast<unsigned long long*>(a.ctrl + 4);
-      st[0] += 1;
-      st[1] += overflow ? 0 : (unsigned long long)cnt;
-    }
-    if (gridDim.x > 1) {
-      __threadfence();
-      __hip_atomic_store(sync, 4u * epoch + (overflow ? 1u : 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   if (skip) return;
-
-  if (overflow) {
-    // ---- full fp64 sweep by the whole grid, block 0 merges
-    double bv;
-    long long bi;
-    bc_sweep_block<MODE>(sw, 0, gridDim.x, false, sv, si, bv, bi);
+  if (bc_rescore_block<MODE>(a, n_rows, a.rec)) {
     if (threadIdx.x == 0) {
-      blk_val[0] = bv;
-      blk_idx[0] = bi;
-      int ok = 1;
-      if (gridDim.x > 1) {
-        ok = 0;
-        for (int spin = 0; spin < BC_RS_SPIN_LIMIT; ++spin) {
-          if (bc_ld_poll(sync + 1) == gridDim.x - 1) { ok = 1; break; }
-          __builtin_amdgcn_s_sleep(8);
-        }
-        sync[1] = 0;                            // ready for the next launch (stream-ordered)
-      }
-      if (!ok) a.ctrl[2] = 1;
-      __threadfence();
-    }
-    __syncthreads();
-    bc_emit_record(blk_val, blk_idx, (int)gridDim.x, a.tiles, a.norms, a.s, a.row_offset, false, a.rec, sv, si, &win);
-    return;
-  }
-
-  const int count = cnt;
-  double bv = -INFINITY;
-  long long bi = LLONG_MAX;
-  if (count <= 32) {
-    // the usual case, a handful of candidates: a wave per candidate
-    for (int j = wave; j < count; j += 4) {
-      const long long r = scand[j];
-      const double sc = bc_exact_score_wave<MODE>(a.tiles, a.v, r, a.s, a.norms[r], a.post_div, strips[wave]);
-      const long long gi = a.row_offset + r;
-      if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
-    }
-  } else {
-    for (int j = threadIdx.x; j < count; j += blockDim.x) {
-      const long long r = a.cand[j];
-      const double sc = bc_exact_score<MODE>(a.tiles, a.v, r, a.s, a.norms[r], a.post_div);
-      const long long gi = a.row_offset + r;
-      if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
+      a.rec[0] = -INFINITY;
+      reinterpret_cast<long long*>(a.rec)[1] = -1;
+      a.rec[2] = 0.0;
+      a.rec[3] = BC_REC_OVERFLOW;
     }
   }
-  bc_wave_argmax(bv, bi);
-  __syncthreads();
-  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
-    const bool valid = bi != LLONG_MAX;
-    a.rec[0] = bv;
-    reinterpret_cast<long long*>(a.rec)[1] = valid ? bi : -1;
-    a.rec[2] = valid ? a.norms[bi - a.row_offset] : 0.0;
-    a.rec[3] = valid ? 1.0 : 0.0;
-    win = valid ? bi - a.row_offset : -1;
-  }
-  __syncthreads();
-  const long long r = win;
-  for (int k = threadIdx.x; k < a.s; k += blockDim.x) a.rec[BC_REC_HDR + k] = (r >= 0) ? a.tiles[bc_tile_off(r, k, a.s)] : 0.0;
 }
 
 // u32 tile builder: one block per 256-row tile, thread = row
@@ -838,7 +367,6 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const size_t o_bu = take((size_t)p->grid * sizeof(float));
   const size_t o_c = take((size_t)p->cap * sizeof(long long));
   const size_t o_ctrl = take(256);
-  const size_t o_sync = take(256);
   hipError_t e = hipMalloc(&p->slab, off);
   if (e != hipSuccess) { delete p; return bc_hip_fail(e, "hipMalloc(prefilter)", __FILE__, __LINE__); }
   char* base = (char*)p->slab;
@@ -857,13 +385,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->blk_u = (float*)(base + o_bu);
   p->cand = (long long*)(base + o_c);
   p->ctrl = (int*)(base + o_ctrl);
-  p->sync = (unsigned*)(base + o_sync);
-  // helpers: one block per CU, all resident next to block 0; never more than the fp64 block-candidate arrays hold
-  p->helpers_grid = ctx->n_cu < phi->sweep_blocks ? ctx->n_cu : phi->sweep_blocks;
-  { const char* hg = getenv("BC_PREF_HELPERS"); if (hg && atoi(hg) >= 1 && atoi(hg) < p->helpers_grid) p->helpers_grid = atoi(hg); }
-  if ((long long)p->helpers_grid * 4 > phi->ntiles) p->helpers_grid = (int)((phi->ntiles + 3) / 4);
-  if (p->helpers_grid < 1) p->helpers_grid = 1;
-  e = hipMemsetAsync(p->ctrl, 0, 512, ctx->stream);
+  e = hipMemsetAsync(p->ctrl, 0, 256, ctx->stream);
   if (e == hipSuccess) {
     if (p->prec == 8)
       hipLaunchKernelGGL(k_build_i8, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
@@ -891,9 +413,9 @@ const int* bc_pref_ctrl(const bc_pref* p) { return p->ctrl; }
 void bc_pref_set_cap(bc_pref* p, int cap) { if (cap >= 1 && cap <= 4096) p->cap = cap; }
 int bc_pref_precision(const bc_pref* p) { return p->prec; }
 
-// passes A, B, C (and the in-launch fp64 fallback)
-int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
-                   const int* skip_flag, double* rec_dev) {
+// pass A: the reduced-precision sweep (bounds per tile / block); fills the argument block of passes B + C
+int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
+                         const int* skip_flag, double* rec_dev, RescoreArgs* r_out) {
   bc_ctx* ctx = p->ctx;
   bc_phi* phi = p->phi;
   PrefArgs a;
@@ -944,7 +466,7 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   BC_HIP(hipGetLastError());
   rc = bc_timer_end(ctx, 0);
   if (rc) return rc;
-  RescoreArgs r;
+  RescoreArgs& r = *r_out;
   r.tiles = phi->tiles;
   r.norms = phi->norms;
   r.v = v_dev;
@@ -971,21 +493,17 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   r.cap = p->cap;
   r.nblk = p->grid;
   r.ptile = p->ptile;
-  bc_sweep_args sw;
-  sw.tiles = phi->tiles;
-  sw.norms = phi->norms;
-  sw.v = v_dev;
-  sw.skip_flag = nullptr;
-  sw.n_rows = phi->n_rows;
-  sw.ntiles = phi->ntiles;
-  sw.row_offset = phi->row_offset;
-  sw.post_div = post_div;
-  sw.s = phi->s;
-  p->epoch = (p->epoch + 1) & 0x3fffffffu;
-  if (p->epoch == 0) p->epoch = 1;            // sync[0] starts at 0: epoch 0 would match before any verdict
-  const int g = p->helpers_grid;
-  if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(g), dim3(256), 0, ctx->stream, r, sw, phi->blk_val, phi->blk_idx, p->sync, p->epoch);
-  else hipLaunchKernelGGL(k_rescore<1>, dim3(g), dim3(256), 0, ctx->stream, r, sw, phi->blk_val, phi->blk_idx, p->sync, p->epoch);
+  return BC_OK;
+}
+
+// passes A, B, C: sweep, then the rescoring as its own one-block launch (record into rec_dev)
+int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
+                   const int* skip_flag, double* rec_dev) {
+  RescoreArgs r;
+  int rc = bc_pref_launch_sweep(p, mode, v_dev, v_norm_dev, post_div, skip_flag, rec_dev, &r);
+  if (rc) return rc;
+  if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
+  else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
   BC_HIP(hipGetLastError());
   return BC_OK;
 }

@@ -1,0 +1,452 @@
+// Rescoring stage of the pre-filtered K3 sweep (passes B + C of bc_prefilter.hip) as a block-level device function,
+// shared by the stand-alone k_rescore launch (bc_prefilter.hip: multi-rank steps, step-wise protocol) and by the
+// single-rank greedy loop's fused rescoring + finish kernel (bc_snnls.hip).
+//
+//   Lmax = max of the sweep's per-block lower bounds; every row whose upper bound reaches Lmax is a candidate --
+//   the true argmax is always among them -- found hierarchically (blocks -> tiles -> rows); the candidates are
+//   rescored from the fp64 Phi with the arithmetic of k_sweep (same fma chain, same epilogue), the argmax uses
+//   NumPy's tie rule on (score, global index), and the candidate record is written.
+//
+// If the candidate lists overflow (thousands of exact duplicates, say) NO record is produced and the function
+// returns 1: the caller marks the step as "redo with the exact sweep" and the HOST re-runs that one step through
+// the fp64 kernel, stream-ordered (bc_snnls.hip: pf_overflow).  Round 1 handled the overflow inside the launch with
+// helper blocks spinning on a flag; that needed all of them co-resident and could time out silently.
+#pragma once
+#include "bc_sweep_dev.h"
+
+#define BC_PREF_DELTA 6.2e-8
+#define BC_HTILE 512   // rows per fp16 tile
+#define BC_HU 10       // fp16 sample planes per batch; the stored plane count is padded to a multiple (zero planes)
+#define BC_RS_TILE_LIMIT16 64   // fp16 mode recomputes candidate tiles (~3 us each): past this the fp64 sweep is cheaper
+#define BC_REC_OVERFLOW (-1.0)  // rec[3] of a record that says "this rank's pre-filter overflowed: redo the step exactly"
+typedef _Float16 bc_h2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__device__ __forceinline__ void bc_score_interval(double s0, double s1, double delta, double post_div, double& U, double& L) {
+  if (MODE == 0) {
+    const double a = fabs(s1) + delta;
+    const double c = 1. - a * a;
+    if (!(s0 == s0) || !(s1 == s1) || !(c > 1e-6)) {   // NaN, or too close to the validity boundary of giga.py:33
+      U = INFINITY;
+      L = -INFINITY;
+      return;
+    }
+    const double f = s0 / sqrt(1. - s1 * s1);
+    const double rc = 1. / sqrt(c);
+    const double e = delta * (rc + (fabs(s0) + delta) * a * rc * rc * rc) * 1.001 + 1e-13 * (1. + fabs(f));
+    U = f + e;
+    L = f - e;
+  } else {
+    if (!(s0 == s0)) { U = INFINITY; L = -INFINITY; return; }
+    const double f = s0 / post_div;
+    const double e = (delta * 1.001 + 1e-13 * fabs(s0)) / fabs(post_div);
+    U = f + e;
+    L = f - e;
+  }
+}
+
+
+struct RescoreArgs {
+  const double* tiles;
+  const double* norms;
+  const double* v;
+  const int* skip_flag;
+  const float* ub;
+  const float* tile_u;
+  const double* blk_l;
+  const float* blk_u;
+  const _Float16* u16;       // fp16 mode: the per-row bounds of candidate tiles are recomputed from the mirror
+  const unsigned char* live;
+  const double* v_norm;
+  double delta;
+  int sp;
+  const float2* tile_cand;   // int8 mode: the sweep left up to 4 (upper bound, row) pairs per tile
+  const int* tile_ncand;
+  long long* cand;
+  int* ctrl;
+  double* rec;
+  long long row_offset, ptiles;
+  double post_div;
+  int s, cap, nblk, ptile;
+  int tile_rounds;           // tiles per sweep wave = ceil(ptiles / (4 * nblk)): block b swept tiles 4b+w + 4*nblk*i
+};
+
+// same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
+template <int MODE>
+__device__ __forceinline__ double bc_exact_score(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
+                                                 int S, double nr, double post_div) {
+  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+  double a0 = 0., a1 = 0.;
+  int k = 0;
+  for (; k + 32 <= S; k += 32) {     // 32 independent loads in flight: this kernel is pure latency
+    double x[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) x[u] = p[(size_t)(k + u) * BC_TILE];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      if (MODE == 0) {
+        a0 = fma(x[u], v[2 * (k + u)], a0);
+        a1 = fma(x[u], v[2 * (k + u) + 1], a1);
+      } else {
+        a0 = fma(x[u], v[k + u], a0);
+      }
+    }
+  }
+  for (; k < S; ++k) {
+    const double x = p[(size_t)k * BC_TILE];
+    if (MODE == 0) {
+      a0 = fma(x, v[2 * k], a0);
+      a1 = fma(x, v[2 * k + 1], a1);
+    } else {
+      a0 = fma(x, v[k], a0);
+    }
+  }
+  if (MODE == 0) {
+    const double s0 = a0 / nr, s1 = a1 / nr;
+    const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
+    const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
+    return s0 / den;
+  }
+  return a0 / nr / post_div;
+}
+
+// The same score, computed by a whole wave for ONE row: the lanes fetch the row (and the sweep vectors) with one
+// round of independent loads -- lane l holds elements l, l+64, ... -- and then every lane runs the identical
+// sequential fma chain on broadcast values (v_readlane), so the result has the bits of bc_exact_score / k_sweep.
+// With a handful of candidates this replaces ~4 dependent load batches per candidate by one.
+// The same score, computed by a whole wave for ONE row: the lanes fetch the row and the sweep vectors with one
+// round of independent loads -- lane l holds elements l, l+64, ... --, park them in a wave-private LDS strip
+// and every lane then runs the identical sequential fma chain on broadcast LDS reads, so the result has the
+// bits of bc_exact_score / k_sweep.  With a handful of candidates this replaces four dependent load batches and
+// a one-lane chain by one round trip and a pipelined chain.  (Wave-private strip: LDS serves a wave's requests in
+// order, the wavefront-scope fences only keep the compiler from reordering.)
+template <int MODE>
+__device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
+                                                      int S, double nr, double post_div, double* strip /* [3][256] */) {
+  const int lane = threadIdx.x & 63;
+  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+  double* sx = strip;
+  double* sa = strip + 256;
+  double* sb = strip + 512;
+  double a0 = 0., a1 = 0.;
+  for (int base = 0; base < S; base += 256) {
+    double x[4], vx[4], vy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = base + 64 * e + lane;
+      const bool in = k < S;
+      x[e] = in ? p[(size_t)k * BC_TILE] : 0.;
+      if (MODE == 0) {
+        vx[e] = in ? v[2 * k] : 0.;
+        vy[e] = in ? v[2 * k + 1] : 0.;
+      } else {
+        vx[e] = in ? v[k] : 0.;
+        vy[e] = 0.;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous block's reads come first
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sx[64 * e + lane] = x[e];
+      sa[64 * e + lane] = vx[e];
+      if (MODE == 0) sb[64 * e + lane] = vy[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = (S - base) < 256 ? (S - base) : 256;
+#pragma unroll 8
+    for (int kk = 0; kk < n; ++kk) {
+      const double xk = sx[kk];
+      a0 = fma(xk, sa[kk], a0);
+      if (MODE == 0) a1 = fma(xk, sb[kk], a1);
+    }
+  }
+  if (MODE == 0) {
+    const double s0 = a0 / nr, s1 = a1 / nr;
+    const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
+    const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
+    return s0 / den;
+  }
+  return a0 / nr / post_div;
+}
+
+// one plane of the fp32 chain for a thread's two rows (k_rescore's recomputation of a candidate tile)
+template <int MODE>
+__device__ __forceinline__ void bc_rs_accumulate(bc_h2 x, const double* __restrict__ v, int k, float (&a0)[2], float (&a1)[2]) {
+  if (MODE == 0) {
+    const float vx = (float)v[2 * k], vy = (float)v[2 * k + 1];
+    a0[0] = fmaf((float)x[0], vx, a0[0]);
+    a1[0] = fmaf((float)x[0], vy, a1[0]);
+    a0[1] = fmaf((float)x[1], vx, a0[1]);
+    a1[1] = fmaf((float)x[1], vy, a1[1]);
+  } else {
+    const float vx = (float)v[k];
+    a0[0] = fmaf((float)x[0], vx, a0[0]);
+    a0[1] = fmaf((float)x[1], vx, a0[1]);
+  }
+}
+
+
+// The block-level rescoring.  Any block size that is a multiple of 64 and >= 256; every thread of the block must
+// call it (it contains barriers).  `rec` may point to LDS or global memory.  Returns 1 on overflow (block-uniform).
+#ifndef FSTAMP
+#define FSTAMP(i) do { } while (0)
+#endif
+template <int MODE>
+__device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* __restrict__ rec) {
+  __shared__ double sv[16];
+  __shared__ long long si[16];
+  __shared__ long long win;
+  __shared__ int cnt, tcnt, bcnt;
+  __shared__ int tlist[1024];
+  __shared__ int blist[64];                  // sweep blocks whose maximum upper bound reaches Lmax
+  __shared__ long long scand[32];            // the first candidates, kept on chip (the usual case has 1-3)
+  __shared__ double strips[4][3 * 256];      // bc_exact_score_wave: one strip per scoring wave
+  __shared__ double bestrow[4][256];         // the row of each scoring wave's best candidate (S <= 256): the record's column
+  __shared__ double snorm[16];
+  __shared__ int swave;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  bool overflow = false;
+  double lmax = -INFINITY;
+  float bu[4];                               // this thread's share of the block upper bounds (nblk <= 1024)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = threadIdx.x + q * 256;
+    bu[q] = -INFINITY;
+    if (threadIdx.x < 256 && i < a.nblk) {
+      lmax = fmax(lmax, a.blk_l[i]);
+      bu[q] = a.blk_u[i];
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
+  if (lane == 0) sv[wave] = lmax;
+  if (threadIdx.x == 0) { cnt = 0; tcnt = 0; bcnt = 0; }
+  __syncthreads();
+  lmax = sv[0];
+  for (int w = 1; w < nw; ++w) lmax = fmax(lmax, sv[w]);
+  FSTAMP(10);
+  // phase B1: tiles whose maximum upper bound reaches Lmax -- first the sweep blocks whose maximum does
+  // (usually one or two), then only the tiles those blocks walked
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (bu[q] != -INFINITY && (double)bu[q] >= lmax) {
+      const int slot = atomicAdd(&bcnt, 1);
+      if (slot < 64) blist[slot] = threadIdx.x + q * 256;
+    }
+  __syncthreads();
+  const int nbl = bcnt;
+  if (nbl <= 64) {
+    const int per = 4 * a.tile_rounds, total = nbl * per;
+    for (int i0 = 0; i0 < total; i0 += 8 * blockDim.x) {
+      float tu[8];
+      long long tt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + u * blockDim.x + threadIdx.x;
+        tt[u] = -1;
+        tu[u] = -INFINITY;
+        if (idx < total) {
+          const int b = blist[idx / per], q = idx % per;
+          const long long t = (long long)b * 4 + (q & 3) + (long long)(q >> 2) * 4 * a.nblk;
+          if (t < a.ptiles) { tt[u] = t; tu[u] = a.tile_u[t]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (tt[u] >= 0 && tu[u] != -INFINITY && (double)tu[u] >= lmax) {
+          const int slot = atomicAdd(&tcnt, 1);
+          if (slot < 1024) tlist[slot] = (int)tt[u];
+        }
+    }
+  } else {
+    // many blocks in play: scan all per-tile maxima, 16 independent loads at a time
+    for (long long t0 = 0; t0 < a.ptiles; t0 += 16LL * blockDim.x) {
+      float tu[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const long long t = t0 + (long long)u * blockDim.x + threadIdx.x;
+        tu[u] = t < a.ptiles ? a.tile_u[t] : -INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (tu[u] != -INFINITY && (double)tu[u] >= lmax) {
+          const int slot = atomicAdd(&tcnt, 1);
+          if (slot < 1024) tlist[slot] = (int)(t0 + (long long)u * blockDim.x + threadIdx.x);
+        }
+    }
+  }
+  __syncthreads();
+  FSTAMP(11);
+  const int ntl = tcnt;
+  if (threadIdx.x == 0) bcnt = 0;            // reused by the int8 branch below
+  __syncthreads();
+  overflow = ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
+  if (!overflow && a.tile_cand) {
+    // phase B2 (int8 mirror): the pairs the sweep left for each such tile; a tile with more than four local
+    // candidates hands over all of its rows
+    for (int q = threadIdx.x; q < ntl; q += blockDim.x) {
+      const long long t = tlist[q];
+      const int n = a.tile_ncand[t];
+      float2 prs[4];                           // fetched together with the count: one round trip
+#pragma unroll
+      for (int i = 0; i < 4; ++i) prs[i] = a.tile_cand[t * 4 + i];
+      if (n <= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 pr = prs[i];
+          if (i < n && (double)pr.x >= lmax) {
+            const int slot = atomicAdd(&cnt, 1);
+            const long long row = t * a.ptile + (int)pr.y;
+            if (slot < a.cap) a.cand[slot] = row;
+            if (slot < 32) scand[slot] = row;
+          }
+        }
+      } else {
+        const int o = atomicAdd(&bcnt, 1);      // (bcnt is free again after phase B1)
+        if (o < 64) blist[o] = (int)t;
+      }
+    }
+    __syncthreads();
+    const int no = bcnt;
+    overflow = no > 64;
+    if (!overflow) {
+      for (int o = 0; o < no; ++o) {
+        const long long row = (long long)blist[o] * a.ptile + threadIdx.x;      // ptile == 256 rows: threads 0..255
+        if ((int)threadIdx.x < a.ptile && row < n_rows && a.norms[row] != 0.) {
+          const int slot = atomicAdd(&cnt, 1);
+          if (slot < a.cap) a.cand[slot] = row;
+          if (slot < 32) scand[slot] = row;
+        }
+      }
+      __syncthreads();
+      overflow = cnt > a.cap;
+    }
+  } else if (!overflow && a.u16) {
+    // phase B2 (fp16 mirror): recompute the per-row intervals of each such tile from the mirror -- the sweep
+    // wrote none.  Thread = two adjacent rows of the tile (one 4-byte load per plane, 1 KiB per plane and
+    // block), up to 64 planes in flight; fp32 chain, same interval formula and delta as the sweep.
+    const double delta = (MODE == 0) ? a.delta : a.delta * (*a.v_norm);
+    if (threadIdx.x < 256)
+    for (int q = 0; q < ntl; ++q) {
+      const long long t = tlist[q];
+      const bc_h2* __restrict__ tp = reinterpret_cast<const bc_h2*>(a.u16 + (size_t)t * a.sp * BC_HTILE) + threadIdx.x;
+      float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+      // sp is a multiple of BC_HU = 10: batches of 50 planes (all loads of a batch in flight), then of 10
+      int k0 = 0;
+      for (; k0 + 50 <= a.sp; k0 += 50) {
+        bc_h2 x[50];
+#pragma unroll
+        for (int u = 0; u < 50; ++u) x[u] = tp[(size_t)(k0 + u) * (BC_HTILE / 2)];
+#pragma unroll
+        for (int u = 0; u < 50; ++u) bc_rs_accumulate<MODE>(x[u], a.v, k0 + u, a0, a1);
+      }
+      for (; k0 < a.sp; k0 += BC_HU) {
+        bc_h2 x[BC_HU];
+#pragma unroll
+        for (int u = 0; u < BC_HU; ++u) x[u] = tp[(size_t)(k0 + u) * (BC_HTILE / 2)];
+#pragma unroll
+        for (int u = 0; u < BC_HU; ++u) bc_rs_accumulate<MODE>(x[u], a.v, k0 + u, a0, a1);
+      }
+      const unsigned lv = a.live[t * 64 + (threadIdx.x >> 2)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = 2 * threadIdx.x + j;                    // row within the tile
+        if ((lv >> (i & 7)) & 1u) {
+          double Ub, Lb;
+          bc_score_interval<MODE>((double)a0[j], (double)a1[j], delta, a.post_div, Ub, Lb);
+          if (Ub >= lmax) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < a.cap) a.cand[slot] = t * BC_HTILE + i;
+            if (slot < 32) scand[slot] = t * BC_HTILE + i;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    overflow = cnt > a.cap;
+  } else if (!overflow) {
+    // phase B2 (fp32 mirror): one wave per such tile, all of the tile's stored upper bounds in flight at once
+    for (int q = wave; q < ntl; q += nw) {
+      const long long t = tlist[q];
+      float u8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = lane + 64 * e;
+        u8[e] = i < a.ptile ? a.ub[t * a.ptile + i] : -INFINITY;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (u8[e] != -INFINITY && (double)u8[e] >= lmax) {
+          const int slot = atomicAdd(&cnt, 1);
+          if (slot < a.cap) a.cand[slot] = t * a.ptile + lane + 64 * e;
+          if (slot < 32) scand[slot] = t * a.ptile + lane + 64 * e;
+        }
+    }
+    __syncthreads();
+    overflow = cnt > a.cap;
+  }
+  if (threadIdx.x == 0) {
+    a.ctrl[1] = overflow ? 1 : 0;              // observable: the last launch overflowed
+    if (overflow) a.ctrl[3] += 1;              // ... and how often since creation
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(a.ctrl + 4);   // diagnostics: sweeps, candidates rescored
+    st[0] += 1;
+    st[1] += overflow ? 0 : (unsigned long long)cnt;
+  }
+  if (overflow) return 1;
+  FSTAMP(12);
+
+  const int count = cnt;
+  double bv = -INFINITY, bnorm = 0.;
+  long long bi = LLONG_MAX;
+  const bool keep_rows = count <= 32 && a.s <= 256;      // the winner's row stays on chip: no reload for the record
+  if (count <= 32) {
+    // the usual case, a handful of candidates: a wave per candidate (the first four waves)
+    if (wave < 4)
+      for (int j = wave; j < count; j += 4) {
+        const long long r = scand[j];
+        const double nr = a.norms[r];
+        const double sc = bc_exact_score_wave<MODE>(a.tiles, a.v, r, a.s, nr, a.post_div, strips[wave]);
+        const long long gi = a.row_offset + r;
+        if (bc_better(sc, gi, bv, bi)) {
+          bv = sc; bi = gi; bnorm = nr;
+          if (keep_rows) {                               // (wave-uniform branch; the strip still holds the row)
+            for (int k = lane; k < a.s; k += BC_WAVE) bestrow[wave][k] = strips[wave][k];
+          }
+        }
+      }
+  } else {
+    for (int j = threadIdx.x; j < count; j += blockDim.x) {
+      const long long r = a.cand[j];
+      const double sc = bc_exact_score<MODE>(a.tiles, a.v, r, a.s, a.norms[r], a.post_div);
+      const long long gi = a.row_offset + r;
+      if (bc_better(sc, gi, bv, bi)) { bv = sc; bi = gi; }
+    }
+  }
+  FSTAMP(13);
+  if (!keep_rows) bc_wave_argmax(bv, bi);     // (keep_rows: every lane of a scoring wave already holds the wave's best)
+  __syncthreads();
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; snorm[wave] = bnorm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int bw = 0;
+    for (int w = 1; w < nw; ++w)
+      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; bw = w; }
+    const bool valid = bi != LLONG_MAX;
+    rec[0] = bv;
+    reinterpret_cast<long long*>(rec)[1] = valid ? bi : -1;
+    rec[2] = valid ? (keep_rows ? snorm[bw] : a.norms[bi - a.row_offset]) : 0.0;
+    rec[3] = valid ? 1.0 : 0.0;
+    win = valid ? bi - a.row_offset : -1;
+    swave = bw;
+  }
+  __syncthreads();
+  const long long r = win;
+  if (keep_rows && r >= 0) {
+    const double* src = bestrow[swave];
+    for (int k = threadIdx.x; k < a.s; k += blockDim.x) rec[BC_REC_HDR + k] = src[k];
+  } else {
+    for (int k = threadIdx.x; k < a.s; k += blockDim.x) rec[BC_REC_HDR + k] = (r >= 0) ? a.tiles[bc_tile_off(r, k, a.s)] : 0.0;
+  }
+  return 0;
+}

@@ -9,7 +9,15 @@
 // (giga.py:20-30 / frankwolfe.py:16).  All replicated state (sparse w, selected
 // columns, xw = A.w) lives in device memory; every rank runs the identical finish
 // kernel on identical gathered records, so ranks stay bit-identical.
-#include "bc_internal.h"
+#ifdef BC_FIN_STAMPS          // diagnostic build: phase time stamps of the single-block step kernels
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_fin_stamps[64];
+#define FSTAMP(i) do { if (threadIdx.x == 0) g_fin_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int bc_debug_fin_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_stamps), sizeof(g_fin_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+#include "bc_rescore_dev.h"
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -30,6 +38,8 @@ void bc_pref_set_cap(bc_pref* p, int cap);
 const int* bc_pref_ctrl(const bc_pref* p);
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
                    const int* skip_flag, double* rec_dev);
+int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
+                         const int* skip_flag, double* rec_dev, RescoreArgs* r_out);
 
 struct SnnlsState {
   long long nnz;        // length of the (idx, val) list, selection order; val may be 0
@@ -47,7 +57,8 @@ struct SnnlsState {
   int sel_valid;
   int last_status;      // status of the last step-wise call
   int overflow;         // list capacity exceeded (host bug guard)
-  int pad;
+  int pf_overflow;      // the pre-filter's candidate lists overflowed in this step: nothing was consumed, the host
+                        // re-runs the step with the exact fp64 sweep (sticky until it does; later launches are no-ops)
   double v_norm;        // ||v|| of the dot-mode sweep vector (scales the pre-filter's error bound)
 };
 
@@ -99,6 +110,11 @@ struct bc_snnls {
   double* cand_all_owned = nullptr;
   long long nnz_upper = 0;   // host-side upper bound on the list length
   long long iter_upper = 0;
+  RescoreArgs rs;                 // argument block of the rescoring stage for the step in flight (fused finish)
+  bool rs_pending = false;        // step_local ran the sweep only: step_finish must run the fused rescoring + finish
+  bool exact_step = false;        // the step in flight uses the exact fp64 sweep (redo after a pre-filter overflow)
+  bool pref_suspended = false;    // repeated overflows: the rest of this build call sweeps in fp64
+  int consec_overflow = 0;
 };
 
 // ------------------------------------------------------------------ device building blocks (single block)
@@ -111,10 +127,11 @@ struct bc_snnls {
 
 // xw = sum_j val[j] * cols[j], err = ||xw - b||, ||xw||^2 and the positive count.  The list is split over
 // G = blockDim/S thread groups (fixed split => deterministic), partial vectors are combined in group order.
-// PF: the first 16 terms of every thread's share come from `c16` (cols prefetched at kernel start, slot u <->
+#define BC_PF_NC 32     // list columns per thread requested up front by the _pf kernels (32 x G = 160 entries at S = 100)
+// PF: the first BC_PF_NC terms of every thread's share come from `c16` (cols prefetched at kernel start, slot u <->
 // list entry g + u*G) except the entry appended in this very step (`at_new`), whose column is P.xf.
 template <bool PF>
-__device__ void dev_xw_err_t(const SnnlsDev& P, SnnlsState& S, double* red, const double (&c16)[16], long long at_new) {
+__device__ void dev_xw_err_t(const SnnlsDev& P, SnnlsState& S, double* red, const double (&c16)[BC_PF_NC], long long at_new) {
   __shared__ double part[BC_FIN_THREADS];
   __shared__ int npos_sh;
   const int s = P.s;
@@ -133,7 +150,7 @@ __device__ void dev_xw_err_t(const SnnlsDev& P, SnnlsState& S, double* red, cons
       long long j = g;
       if (PF) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < BC_PF_NC; ++u) {
           if (j < nnz) {
             const double vj = P.val[j];
             const double cv = (j == at_new) ? P.xf[k] : c16[u];
@@ -220,7 +237,7 @@ __device__ void dev_xw_err_t(const SnnlsDev& P, SnnlsState& S, double* red, cons
 }
 
 __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
-  const double none[16] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+  const double none[BC_PF_NC] = {0.};
   dev_xw_err_t<false>(P, S, red, none, -1);
 }
 
@@ -265,7 +282,7 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
         S.v_norm = sqrt(vn);
       }
     }
-    if (lane == 0) S.skip = S.select_fail | S.reached_limit;
+    if (lane == 0) S.skip = S.select_fail | S.reached_limit | S.pf_overflow;
   }
   __syncthreads();
 }
@@ -277,6 +294,21 @@ __device__ void dev_pick(const SnnlsDev& P, SnnlsState& S, double* red) {
   __shared__ int src_rec;
   __shared__ long long src_list;
   const int s = P.s;
+  if (P.world == 1 && ALG != BC_ALG_OMP) {
+    // one record: nothing to reduce (the shuffle argmax below costs ~3.5k cycles of ds_bpermute latency)
+    const double* rec = P.cand_all;
+    const bool valid = rec[3] != 0.0;
+    if (threadIdx.x == 0) {
+      S.sel_valid = valid ? 1 : 0;
+      S.sel_f = valid ? reinterpret_cast<const long long*>(rec)[1] : -1;
+      S.sel_score = valid ? rec[0] : -INFINITY;
+      if (valid) S.sel_norm = rec[2];
+    }
+    if (valid)
+      for (int k = threadIdx.x; k < s; k += blockDim.x) P.xf[k] = rec[BC_REC_HDR + k];
+    __syncthreads();
+    return;
+  }
   if (threadIdx.x < BC_WAVE) {
     // wave 0: one record header per lane (independent loads), shuffle argmax on (score, global index)
     // carrying the record slot; the winner's column is copied straight from its record
@@ -520,6 +552,17 @@ __device__ __forceinline__ void dev_trace(const SnnlsDev& P, SnnlsState& S, long
   }
 }
 
+// any gathered record carrying the overflow marker?  (block-uniform; every rank sees the same records)
+__device__ bool dev_records_overflow(const double* cand_all, int world, int rec_len) {
+  __shared__ int ovf;
+  if (threadIdx.x == 0) ovf = 0;
+  __syncthreads();
+  for (int r = threadIdx.x; r < world; r += blockDim.x)
+    if (cand_all[(size_t)r * rec_len + 3] < 0.) ovf = 1;
+  __syncthreads();
+  return ovf != 0;
+}
+
 // ------------------------------------------------------------------ kernels (grid = 1 block)
 template <int ALG>
 __global__ __launch_bounds__(BC_FIN_THREADS) void k_prep(SnnlsDev P, int reset_retry) {
@@ -559,7 +602,11 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P0, int
     }
   }
   __syncthreads();
-  if (S.reached_limit) return;                       // snnls.py:32-34 / :73-74
+  if (S.reached_limit || S.pf_overflow) return;      // snnls.py:32-34 / :73-74; a pending exact redo consumes nothing
+  if (!P.fuse_winner && !S.select_fail && dev_records_overflow(P0.cand_all, P.world, P.rec_len)) {
+    if (threadIdx.x == 0) { S.pf_overflow = 1; S.skip = 1; *P0.st = S; }
+    return;
+  }
   const bool guard = S.npos > 0;                     // snnls.py:44-45 (check_error_monotone is True for GIGA/FW)
   int fail = S.select_fail;                          // _select raised
   long long f = -1;
@@ -628,14 +675,18 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P0, int
 // fit the LDS budget (nnz_hint + 1 <= BC_PF_MAXNNZ, world * rec_len <= BC_PF_MAXREC, S <= blockDim).
 #define BC_PF_MAXNNZ 1024
 #define BC_PF_MAXREC 2048
-template <int ALG>
-__global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, int nnz_hint) {
+// RS: the pre-filter's rescoring stage (bc_rescore_dev.h) runs INSIDE this launch, between the up-front loads and
+// the step: its record goes straight into LDS (single rank, no exchange).  One launch per greedy step besides the
+// sweep instead of two (k_rescore 11.7 us + k_step_finish_pf 12.6 us in round 1).
+template <int ALG, bool RS>
+__global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, int nnz_hint, RescoreArgs ra, long long n_rows) {
   extern __shared__ double pf_lds[];
   __shared__ SnnlsState S;
   __shared__ double red[64];
   __shared__ int sh_fail;
   const int s = P0.s;
-  const int nrec = P0.fuse_winner ? 0 : P0.world * P0.rec_len;
+  const int nrec = RS ? P0.rec_len : (P0.fuse_winner ? 0 : P0.world * P0.rec_len);
+  FSTAMP(0);
   double* l_b = pf_lds;
   double* l_bn = l_b + s;
   double* l_xw = l_bn + s;
@@ -651,16 +702,17 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
     l_bn[k] = P0.bn[k];
     l_xw[k] = P0.xw[k];
   }
-  for (int i = threadIdx.x; i < nrec; i += blockDim.x) l_rec[i] = P0.cand_all[i];
+  if (!RS)
+    for (int i = threadIdx.x; i < nrec; i += blockDim.x) l_rec[i] = P0.cand_all[i];
   for (int j = threadIdx.x; j < nnz_hint; j += blockDim.x) {
     l_val[j] = P0.val[j];
     l_idx[j] = P0.idx[j];
   }
   const int G = blockDim.x / s;
   const int g = threadIdx.x / s, kk = threadIdx.x - g * s;
-  double c16[16];
+  double c16[BC_PF_NC];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
+  for (int u = 0; u < BC_PF_NC; ++u) {
     c16[u] = 0.;
     if (g < G && nnz_hint > 0) {
       long long j = g + (long long)u * G;
@@ -678,7 +730,21 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
   P.val = l_val;
   P.idx = l_idx;
   if (nrec) P.cand_all = l_rec;
-  if (S.reached_limit) return;                       // snnls.py:32-34 / :73-74
+  if (RS) { P.world = 1; P.fuse_winner = 0; }
+  FSTAMP(1);
+  if (S.reached_limit || S.pf_overflow) return;      // snnls.py:32-34 / :73-74; a pending exact redo consumes nothing
+  bool pf_ovf = false;
+  if (RS) {
+    if (!S.skip) pf_ovf = bc_rescore_block<(ALG == BC_ALG_GIGA) ? 0 : 1>(ra, n_rows, l_rec) != 0;
+    __syncthreads();
+    FSTAMP(2);
+  } else if (!P.fuse_winner && !S.select_fail) {
+    pf_ovf = dev_records_overflow(l_rec, P.world, P.rec_len);
+  }
+  if (pf_ovf) {
+    if (threadIdx.x == 0) { S.pf_overflow = 1; S.skip = 1; *P0.st = S; }
+    return;
+  }
   if (S.nnz > nnz_hint) {                            // the host's bound on the list length was wrong: refuse
     if (threadIdx.x == 0) { S.overflow = 1; *P0.st = S; }
     return;
@@ -695,14 +761,18 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
     if (!S.sel_valid) fail = 1;
     f = S.sel_f;
   }
+  FSTAMP(3);
   if (!fail) {
     double alpha = 0., beta = 0.;
     fail = dev_step_sizes<ALG>(P, S, red, alpha, beta);
+    FSTAMP(4);
     if (!fail) {
       for (int k = threadIdx.x; k < s; k += blockDim.x) P.xw_prev[k] = P.xw[k];
       dev_apply(P, S, alpha, beta);                  // on the LDS copy of (val, idx); a new column goes to global cols
+      FSTAMP(5);
       const long long at_new = (S.nnz == nnz0 + 1) ? nnz0 : -1;
       dev_xw_err_t<true>(P, S, red, c16, at_new);
+      FSTAMP(6);
       wrote = true;
       if (guard) {
         if (S.err_cur > err0) {                      // snnls.py:58-61: nothing was written back yet, just drop it
@@ -731,9 +801,11 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
     sh_fail = fail;
   }
   __syncthreads();
+  FSTAMP(7);
   dev_trace(P, S, f, sh_fail);
   __syncthreads();
   dev_prep<ALG>(P, S, red);
+  FSTAMP(8);
   // ---- write back
   for (int k = threadIdx.x; k < s; k += blockDim.x) P0.xw[k] = P.xw[k];
   if (wrote) {
@@ -745,6 +817,7 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
     S.sel_valid = 0;
     *P0.st = S;
   }
+  FSTAMP(9);
 }
 
 template <int ALG>
@@ -753,6 +826,10 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_pick(SnnlsDev P) {
   __shared__ double red[64];
   if (threadIdx.x == 0) S = *P.st;
   __syncthreads();
+  if (!S.select_fail && dev_records_overflow(P.cand_all, P.world, P.rec_len)) {
+    if (threadIdx.x == 0) { S.last_status = BC_RETRY_EXACT; *P.st = S; }     // some rank's pre-filter overflowed
+    return;
+  }
   if (!S.select_fail) dev_pick<ALG>(P, S, red);
   if (threadIdx.x == 0) {
     S.last_status = S.select_fail ? BC_NUMERICAL_PRECISION : (S.sel_valid ? BC_OK : BC_INVALID_ARGUMENT);
@@ -1086,7 +1163,6 @@ extern "C" int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n) {
   int ctrl[4] = {0, 0, 0, 0};
   BC_HIP(hipMemcpyAsync(ctrl, bc_pref_ctrl(h->pref), sizeof(ctrl), hipMemcpyDeviceToHost, h->ctx->stream));
   BC_HIP(hipStreamSynchronize(h->ctx->stream));
-  if (ctrl[2]) { bc_set_error("pre-filter fallback hand-shake timed out"); return -1; }
   *n = ctrl[3];
   return BC_OK;
 }
@@ -1166,13 +1242,42 @@ static int launch_prep(bc_snnls* h, int reset_retry) {
   return BC_OK;
 }
 
-static int launch_sweep(bc_snnls* h, bool with_record) {
-  if (h->pref) {
-    // reduced-precision pre-filter -> candidates -> exact fp64 rescoring into the record (a candidate
-    // overflow is handled inside the rescoring launch by a full fp64 sweep)
+// the finish kernel may take the sweep's block candidates directly when nobody else needs the record
+static bool fuse_winner(const bc_snnls* h) { return h->d.world == 1 && h->cand_send_owned && !h->pref && !h->comm; }
+static bool use_pref(const bc_snnls* h) { return h->pref && !h->pref_suspended && !h->exact_step; }
+
+#define BC_RS_MAX_DYN_LDS (48 * 1024)   // dynamic LDS the fused kernel may ask for (on top of ~42 KB static: rescoring strips, lists)
+// one-round-of-loads finish kernel (k_step_finish_pf) possible for the step in flight?
+static bool finish_pf_ok(const bc_snnls* h, long long nrec) {
+  static const int no_pf = getenv("BC_FINISH_NOPF") ? atoi(getenv("BC_FINISH_NOPF")) : 0;
+  return !no_pf && h->d.s <= BC_FIN_THREADS && h->nnz_upper + 1 <= BC_PF_MAXNNZ && nrec <= BC_PF_MAXREC && h->nnz_upper + 1 <= h->d.cap;
+}
+// ... with the rescoring stage inside the same launch (single rank, pre-filtered sweep)?
+static bool fused_rescore_ok(const bc_snnls* h) {
+  static const int no_fuse = getenv("BC_FINISH_NOFUSE") ? atoi(getenv("BC_FINISH_NOFUSE")) : 0;
+  if (no_fuse || !use_pref(h) || h->d.world != 1 || h->comm || !h->cand_send_owned) return false;
+  if (!finish_pf_ok(h, h->d.rec_len)) return false;
+  const size_t lds = ((size_t)5 * h->d.s + h->d.rec_len + 2 * (size_t)(h->nnz_upper + 1)) * sizeof(double);
+  return lds <= BC_RS_MAX_DYN_LDS;
+}
+
+static int launch_sweep(bc_snnls* h, bool with_record, bool allow_fused) {
+  h->rs_pending = false;
+  if (use_pref(h)) {
+    // reduced-precision pre-filter -> candidates -> exact fp64 rescoring into the record
+    if (allow_fused && fused_rescore_ok(h)) {
+      h->rs_pending = true;       // step_finish runs rescoring + finish as one launch
+      return bc_pref_launch_sweep(h->pref, mode_of(h), h->d.v, &h->d.st->v_norm, 1.0, &h->d.st->skip, h->cand_send, &h->rs);
+    }
     return bc_pref_launch(h->pref, mode_of(h), h->d.v, &h->d.st->v_norm, 1.0, &h->d.st->skip, h->cand_send);
   }
-  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, with_record ? h->cand_send : nullptr);
+  const bool rec = with_record || h->exact_step || h->pref != nullptr;     // (pref suspended: the finish reads the record)
+  return bc_launch_sweep(h->phi, mode_of(h), h->d.v, 1.0, &h->d.st->skip, rec ? h->cand_send : nullptr);
+}
+
+__global__ void k_clear_pf_overflow(SnnlsState* st) {
+  st->pf_overflow = 0;
+  st->skip = st->select_fail | st->reached_limit;
 }
 
 // ---- fused loop
@@ -1185,33 +1290,61 @@ extern "C" int bc_snnls_build_begin(bc_snnls* h, int itrs) {
   int rc = ensure_capacity(h, h->nnz_upper + itrs);
   if (!rc) rc = ensure_trace(h, h->iter_upper + itrs);
   if (rc) return rc;
+  h->pref_suspended = false;
+  h->consec_overflow = 0;
+  h->exact_step = false;
   return launch_prep(h, 1);
 }
 
-// the finish kernel may take the sweep's block candidates directly when nobody else needs the record
-static bool fuse_winner(const bc_snnls* h) { return h->d.world == 1 && h->cand_send_owned && !h->pref && !h->comm; }
-
 extern "C" int bc_snnls_step_local(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
-  return launch_sweep(h, !fuse_winner(h));
+  h->exact_step = false;
+  return launch_sweep(h, !fuse_winner(h), true);
+}
+
+extern "C" int bc_snnls_step_local_exact(bc_snnls* h) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_clear_pf_overflow, dim3(1), dim3(1), 0, h->ctx->stream, h->d.st);
+  BC_HIP(hipGetLastError());
+  h->exact_step = true;
+  return launch_sweep(h, true, false);
 }
 
 extern "C" int bc_snnls_step_finish(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
   SnnlsDev d = h->d;
-  d.fuse_winner = fuse_winner(h) ? 1 : 0;
+  const bool rec_based = h->exact_step || h->pref != nullptr;
+  d.fuse_winner = (fuse_winner(h) && !rec_based) ? 1 : 0;
   d.blk_val = h->phi->blk_val;
   d.blk_idx = h->phi->blk_idx;
   d.nblk = h->phi->sweep_blocks;
-  static const int no_pf = getenv("BC_FINISH_NOPF") ? atoi(getenv("BC_FINISH_NOPF")) : 0;
-  const long long nrec = d.fuse_winner ? 0 : (long long)d.world * d.rec_len;
-  if (!no_pf && d.s <= BC_FIN_THREADS && h->nnz_upper + 1 <= BC_PF_MAXNNZ && nrec <= BC_PF_MAXREC && h->nnz_upper + 1 <= d.cap) {
+  const bool fused = h->rs_pending;
+  h->rs_pending = false;
+  h->exact_step = false;
+  const long long nrec = fused ? d.rec_len : (d.fuse_winner ? 0 : (long long)d.world * d.rec_len);
+  if (fused || finish_pf_ok(h, nrec)) {
     const int hint = (int)h->nnz_upper;
     const size_t lds = ((size_t)5 * d.s + nrec + 2 * (size_t)(hint + 1)) * sizeof(double);
-    if (h->alg == BC_ALG_GIGA)
-      hipLaunchKernelGGL(k_step_finish_pf<BC_ALG_GIGA>, dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint);
-    else
-      hipLaunchKernelGGL(k_step_finish_pf<BC_ALG_FW>, dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint);
+    const long long n_rows = h->phi->n_rows;
+    if (fused) {
+      static bool attr_done = false;       // 42 KB static + up to 48 KB dynamic LDS: above the 64 KB default limit
+      if (!attr_done) {
+        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_GIGA, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
+        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_FW, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
+        attr_done = true;
+      }
+      if (h->alg == BC_ALG_GIGA)
+        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, true>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+      else
+        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_FW, true>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+    } else {
+      if (h->alg == BC_ALG_GIGA)
+        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, false>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+      else
+        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_FW, false>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+    }
     BC_HIP(hipGetLastError());
     h->nnz_upper += 1;
     h->iter_upper += 1;
@@ -1229,7 +1362,7 @@ extern "C" int bc_snnls_step_finish(bc_snnls* h) {
   return BC_OK;
 }
 
-extern "C" int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* iterations_consumed) {
+extern "C" int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* iterations_consumed, int* pending_exact) {
   if (!h) return BC_INVALID_ARGUMENT;
   SnnlsState st;
   int rc = fetch_state(h, &st);
@@ -1238,6 +1371,13 @@ extern "C" int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* 
   h->iter_upper = st.iter;
   if (reached_numeric_limit) *reached_numeric_limit = st.reached_limit;
   if (iterations_consumed) *iterations_consumed = (int)st.iter;
+  if (pending_exact) *pending_exact = st.pf_overflow;
+  if (st.pf_overflow) {
+    // all ranks see the same replicated state, so they take this branch together
+    if (++h->consec_overflow >= 3) h->pref_suspended = true;     // e.g. a design full of exact duplicates: stop trying
+  } else {
+    h->consec_overflow = 0;
+  }
   return BC_OK;
 }
 
@@ -1247,14 +1387,36 @@ extern "C" int bc_snnls_build(bc_snnls* h, int itrs, int* reached_numeric_limit)
     bc_set_error("bc_snnls_build: world > 1 without a bound bc_comm: the host must all-gather between step_local and step_finish");
     return BC_INVALID_ARGUMENT;
   }
+  const long long iter0 = h->iter_upper;
   int rc = bc_snnls_build_begin(h, itrs);
-  for (int i = 0; i < itrs && !rc; ++i) {
-    rc = bc_snnls_step_local(h);
+  if (rc) return rc;
+  int left = itrs, lim = 0;
+  while (true) {
+    for (int i = 0; i < left && !rc; ++i) {
+      rc = bc_snnls_step_local(h);
+      if (!rc) rc = exchange(h);
+      if (!rc) rc = bc_snnls_step_finish(h);
+    }
+    if (rc) return rc;
+    int consumed = 0, pending = 0;
+    rc = bc_snnls_build_end(h, &lim, &consumed, &pending);
+    if (rc) return rc;
+    if (!pending) break;
+    // the pre-filter overflowed at step `consumed - iter0`: that step and everything enqueued after it were no-ops.
+    // Redo it through the exact sweep, then go on with what is left.
+    rc = bc_snnls_step_local_exact(h);
     if (!rc) rc = exchange(h);
     if (!rc) rc = bc_snnls_step_finish(h);
+    if (rc) return rc;
+    left = itrs - (int)(consumed - iter0) - 1;
+    if (left <= 0) {
+      rc = bc_snnls_build_end(h, &lim, nullptr, nullptr);
+      if (rc) return rc;
+      break;
+    }
   }
-  if (rc) return rc;
-  return bc_snnls_build_end(h, reached_numeric_limit, nullptr);
+  if (reached_numeric_limit) *reached_numeric_limit = lim;
+  return BC_OK;
 }
 
 // ---- step-wise protocol
@@ -1262,7 +1424,17 @@ extern "C" int bc_snnls_select_local(bc_snnls* h) {
   if (!h) return BC_INVALID_ARGUMENT;
   int rc = launch_prep(h, 0);
   if (rc) return rc;
-  return launch_sweep(h, true);
+  h->exact_step = false;
+  h->pref_suspended = false;
+  return launch_sweep(h, true, false);
+}
+
+extern "C" int bc_snnls_select_local_exact(bc_snnls* h) {
+  if (!h) return BC_INVALID_ARGUMENT;
+  h->exact_step = true;
+  const int rc = launch_sweep(h, true, false);
+  h->exact_step = false;
+  return rc;
 }
 
 extern "C" int bc_snnls_select_pick(bc_snnls* h, int64_t* f) {
@@ -1272,6 +1444,7 @@ extern "C" int bc_snnls_select_pick(bc_snnls* h, int64_t* f) {
   int rc = fetch_state(h, &st);
   if (rc) return rc;
   *f = st.sel_f;
+  if (st.last_status == BC_RETRY_EXACT) return BC_RETRY_EXACT;                   // no error text: the caller re-sweeps exactly
   if (st.last_status == BC_NUMERICAL_PRECISION) bc_set_error("cdirnrm < TOL");   // giga.py:28-29
   if (st.last_status == BC_INVALID_ARGUMENT) bc_set_error("bc_snnls_select: no selectable row");
   return st.last_status;
@@ -1284,6 +1457,11 @@ extern "C" int bc_snnls_select(bc_snnls* h, int64_t* f) {
     return BC_INVALID_ARGUMENT;
   }
   int rc = bc_snnls_select_local(h);
+  if (!rc) rc = exchange(h);
+  if (rc) return rc;
+  rc = bc_snnls_select_pick(h, f);
+  if (rc != BC_RETRY_EXACT) return rc;
+  rc = bc_snnls_select_local_exact(h);          // a pre-filter overflowed on some rank: the same step, exact sweep
   if (!rc) rc = exchange(h);
   if (rc) return rc;
   return bc_snnls_select_pick(h, f);

@@ -91,12 +91,28 @@ class HipEngine:
         if not self.exchange:
             N.call('bc_snnls_build', self.h, int(itrs), C.byref(lim))
         else:
+            # the host carries the records between the two halves of a step (gloo, ranks sharing a GPU)
+            done0 = C.c_int()
+            N.call('bc_snnls_build_end', self.h, None, C.byref(done0), None)
             N.call('bc_snnls_build_begin', self.h, int(itrs))
-            for _ in range(int(itrs)):
-                N.call('bc_snnls_step_local', self.h)
+            left = int(itrs)
+            while left > 0:
+                for _ in range(left):
+                    N.call('bc_snnls_step_local', self.h)
+                    self._xchg.all_gather()
+                    N.call('bc_snnls_step_finish', self.h)
+                done, pending = C.c_int(), C.c_int()
+                N.call('bc_snnls_build_end', self.h, C.byref(lim), C.byref(done), C.byref(pending))
+                if not pending.value:
+                    break
+                # a rank's pre-filter overflowed at that step (every rank sees it in the gathered records):
+                # nothing was consumed since; redo the step with the exact sweep, then continue
+                N.call('bc_snnls_step_local_exact', self.h)
                 self._xchg.all_gather()
                 N.call('bc_snnls_step_finish', self.h)
-            N.call('bc_snnls_build_end', self.h, C.byref(lim), None)
+                left = int(itrs) - (done.value - done0.value) - 1
+                if left <= 0:
+                    N.call('bc_snnls_build_end', self.h, C.byref(lim), None, None)
         return bool(lim.value)
 
     # ---- step-wise protocol
@@ -108,7 +124,12 @@ class HipEngine:
         else:
             N.call('bc_snnls_select_local', self.h)
             self._xchg.all_gather()
-            N.call('bc_snnls_select_pick', self.h, C.byref(f))
+            rc = N.load().bc_snnls_select_pick(self.h, C.byref(f))
+            if rc == N.BC_RETRY_EXACT:          # a rank's pre-filter overflowed: same step through the exact sweep
+                N.call('bc_snnls_select_local_exact', self.h)
+                self._xchg.all_gather()
+                rc = N.load().bc_snnls_select_pick(self.h, C.byref(f))
+            N.check(rc)
         return f.value
 
     def reweight(self, f):

@@ -45,6 +45,8 @@ extern "C" {
 #define BC_OK 0
 #define BC_NUMERICAL_PRECISION 1
 #define BC_INVALID_ARGUMENT 2
+#define BC_RETRY_EXACT 3 /* bc_snnls_select_pick only: a rank's pre-filter overflowed, redo the sweep exactly
+                            (bc_snnls_select_local_exact, all-gather, select_pick); never leaves bc_snnls_select */
 
 #define BC_TILE_ROWS 128
 
@@ -175,8 +177,9 @@ int bc_snnls_destroy(bc_snnls* h);
  * default; BC_PREFILTER=0 / 8 / 16 / 32 in the environment forces it.  Selections and weights are identical either way
  * (candidates are rescored from the fp64 Phi with the arithmetic of the fp64 sweep). */
 int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
-/* Diagnostic: how many sweeps since creation overflowed the pre-filter's candidate list and were redone,
- * inside the same launch, by the full fp64 sweep. */
+/* Diagnostic: how many sweeps since creation overflowed the pre-filter's candidate lists (thousands of exactly
+ * duplicated rows, say).  Such a step consumes nothing: it is marked on the device, the rest of the enqueued
+ * launches become no-ops, and the host re-runs it with the exact fp64 sweep (stream-ordered, no in-launch hand-shake). */
 int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n);
 /* Diagnostic: sweeps run through the pre-filter since creation, rows it handed to the exact fp64 rescoring in
  * total (candidates / sweeps = how selective the reduced-precision bounds are on this data), and fallbacks. */
@@ -196,8 +199,12 @@ int bc_snnls_record_doubles(const bc_snnls* h, int32_t* n);
  * (snnls.py:31-79 incl. the monotone guard, revert, retry-once-then-stop).   */
 int bc_snnls_build_begin(bc_snnls* h, int itrs);      /* resets the per-call retry flag (snnls.py:40) */
 int bc_snnls_step_local(bc_snnls* h);                 /* K3 sweep + local winner -> cand_send */
+int bc_snnls_step_local_exact(bc_snnls* h);           /* the same through the fp64 sweep: redo of a step whose pre-filter overflowed */
 int bc_snnls_step_finish(bc_snnls* h);                /* winner over cand_all, reweight, guard, prep next */
-int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* iterations_consumed);
+/* pending_exact (may be NULL): 1 when the enqueued steps stopped at a pre-filter overflow -- the caller runs ONE
+ * step as step_local_exact / all-gather / step_finish and then continues with the remaining iterations
+ * (iterations_consumed tells how many are done); bc_snnls_build does all of that by itself. */
+int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* iterations_consumed, int* pending_exact);
 /* = begin; itrs x (step_local; step_finish); end   -- single-rank convenience */
 int bc_snnls_build(bc_snnls* h, int itrs, int* reached_numeric_limit);
 
@@ -206,6 +213,7 @@ int bc_snnls_build(bc_snnls* h, int itrs, int* reached_numeric_limit);
  * (giga.py:28-29).  For world > 1 call select_local, all-gather, select_pick. */
 int bc_snnls_select(bc_snnls* h, int64_t* f);
 int bc_snnls_select_local(bc_snnls* h);
+int bc_snnls_select_local_exact(bc_snnls* h);         /* after select_pick returned BC_RETRY_EXACT */
 int bc_snnls_select_pick(bc_snnls* h, int64_t* f);
 /* reweight with column f.  The column is taken from the last select's candidate
  * records when f is among them, else gathered from the local shard

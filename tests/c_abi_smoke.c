@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
                   (void*)bc_phi_argmax, (void*)bc_snnls_create, (void*)bc_snnls_destroy, (void*)bc_snnls_prefilter_active,
                   (void*)bc_snnls_prefilter_fallbacks, (void*)bc_snnls_prefilter_stats,
                   (void*)bc_snnls_set_tolerance, (void*)bc_snnls_bind_exchange, (void*)bc_snnls_record_doubles,
-                  (void*)bc_snnls_build_begin, (void*)bc_snnls_step_local, (void*)bc_snnls_step_finish, (void*)bc_snnls_build_end,
+                  (void*)bc_snnls_build_begin, (void*)bc_snnls_step_local, (void*)bc_snnls_step_local_exact, (void*)bc_snnls_step_finish, (void*)bc_snnls_build_end, (void*)bc_snnls_select_local_exact,
                   (void*)bc_snnls_build, (void*)bc_snnls_select, (void*)bc_snnls_select_local, (void*)bc_snnls_select_pick,
                   (void*)bc_snnls_reweight, (void*)bc_snnls_error, (void*)bc_snnls_size, (void*)bc_snnls_weights,
                   (void*)bc_snnls_set_weights, (void*)bc_snnls_columns, (void*)bc_snnls_reset, (void*)bc_snnls_get_flags,
