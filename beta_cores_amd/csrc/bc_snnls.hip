@@ -127,7 +127,7 @@ struct bc_snnls {
 
 // xw = sum_j val[j] * cols[j], err = ||xw - b||, ||xw||^2 and the positive count.  The list is split over
 // G = blockDim/S thread groups (fixed split => deterministic), partial vectors are combined in group order.
-#define BC_PF_NC 32     // list columns per thread requested up front by the _pf kernels (32 x G = 160 entries at S = 100)
+#define BC_PF_NC 16     // list columns per thread requested up front by the _pf kernels (32 was measured: no gain)
 // PF: the first BC_PF_NC terms of every thread's share come from `c16` (cols prefetched at kernel start, slot u <->
 // list entry g + u*G) except the entry appended in this very step (`at_new`), whose column is P.xf.
 template <bool PF>
