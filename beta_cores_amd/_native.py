@@ -60,6 +60,10 @@ _SIGNATURES = {
     'bc_comm_info': [vp, c_i32p, c_i32p],
     'bc_comm_all_gather': [vp, vp, vp, C.c_int64],
     'bc_comm_selftest': [vp],
+    'bc_comm_precheck': [vp],
+    'bc_comm_abort': [vp],
+    'bc_comm_sum_doubles': [vp, vp, C.c_int64, vp],
+    'bc_phi_colsum_all': [vp, vp, vp],
     'bc_snnls_bind_comm': [vp, vp],
     'bc_snnls_prefilter_active': [vp, c_ip],
     'bc_snnls_prefilter_fallbacks': [vp, C.POINTER(C.c_int64)],

@@ -112,10 +112,9 @@ class _GreedyVICoreset(Coreset):
         return DevicePhi.from_host(np.ascontiguousarray(vecs, dtype=np.float64), ctx=getattr(self.ll_projector, 'ctx', None))
 
     def _colsum(self, vecs):
-        b = vecs.sum(axis=0)
         if self.comm is not None:
-            b = self.comm.sum_in_rank_order(b)
-        return b
+            return self.comm.colsum(vecs)          # in-library all-gather + rank-order sum over RCCL (dist.py)
+        return vecs.sum(axis=0)
 
     def _best_correlation(self, vecs, resid):
         """`np.argmax(corrs)`, `corrs.max()` for corrs = vecs.resid / ||vecs_i|| / S (bcores.py:78-81), one K3 sweep.

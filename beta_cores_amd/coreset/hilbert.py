@@ -52,10 +52,11 @@ class HilbertCoreset(Coreset):
                     raise NotImplementedError('all-zero projection rows with sharded data')
                 self._zero_map = np.cumsum(vecs.norms() == 0.)      # rows dropped before each index
                 solver_kw['allow_zero_rows'] = True
-            b = vecs.sum(axis=0)
             if sharded:
-                b = comm.sum_in_rank_order(b)
+                b = comm.colsum(vecs)                      # all ranks' shards, summed in rank order inside the library
                 solver_kw['comm'] = comm
+            else:
+                b = vecs.sum(axis=0)
             self.snnls = snnls(vecs.T, b, **solver_kw)
         else:
             if sharded:

@@ -26,6 +26,7 @@ typedef int (*fn_comm_init_rank)(nccl_comm_t*, int, nccl_unique_id, int);
 typedef int (*fn_comm_destroy)(nccl_comm_t);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t);
 typedef const char* (*fn_error_string)(int);
+typedef int (*fn_comm_abort)(nccl_comm_t);
 
 struct RcclApi {
   void* lib = nullptr;
@@ -34,6 +35,7 @@ struct RcclApi {
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_gather all_gather = nullptr;
   fn_error_string error_string = nullptr;
+  fn_comm_abort comm_abort = nullptr;      // optional
 };
 RcclApi g_rccl;
 
@@ -54,6 +56,7 @@ int rccl_load(const char* path) {
   a.comm_destroy = (fn_comm_destroy)dlsym(lib, "ncclCommDestroy");
   a.all_gather = (fn_all_gather)dlsym(lib, "ncclAllGather");
   a.error_string = (fn_error_string)dlsym(lib, "ncclGetErrorString");
+  a.comm_abort = (fn_comm_abort)dlsym(lib, "ncclCommAbort");
   if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather) {
     bc_set_error("RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather");
     dlclose(lib);
@@ -73,6 +76,8 @@ struct bc_comm {
   bc_ctx* ctx = nullptr;
   nccl_comm_t nccl = nullptr;
   int rank = 0, world = 1;
+  double* sum_buf = nullptr;       // scratch of bc_comm_sum_doubles: [count] send | [world][count] gathered | [count] result
+  size_t sum_cap = 0;              // count the scratch holds
 };
 
 extern "C" int bc_comm_load(const char* rccl_library_path) { return rccl_load(rccl_library_path); }
@@ -112,7 +117,36 @@ extern "C" int bc_comm_destroy(bc_comm* c) {
   if (!c) return BC_OK;
   (void)hipStreamSynchronize(c->ctx->stream);
   if (c->nccl) (void)g_rccl.comm_destroy(c->nccl);
+  if (c->sum_buf) (void)hipFree(c->sum_buf);
   delete c;
+  return BC_OK;
+}
+
+// Tear the communicator down WITHOUT waiting for outstanding collectives (ncclCommAbort): what a rank does
+// when it fails in the middle of a multi-rank loop, so that it exits instead of leaving its peers' next
+// all-gather waiting for it forever (they then fail out of RCCL instead of hanging).
+extern "C" int bc_comm_abort(bc_comm* c) {
+  if (!c) return BC_OK;
+  if (c->nccl) {
+    if (g_rccl.comm_abort) (void)g_rccl.comm_abort(c->nccl);
+    else (void)g_rccl.comm_destroy(c->nccl);
+    c->nccl = nullptr;
+  }
+  return BC_OK;
+}
+
+// What bc_comm_create needs LOCALLY (library present, device usable): run it on every rank and agree on the
+// outcome BEFORE entering ncclCommInitRank -- a rank that fails here would otherwise leave the others inside the
+// collective bootstrap.
+extern "C" int bc_comm_precheck(bc_ctx* ctx) {
+  if (!ctx) { bc_set_error("bc_comm_precheck: bad argument"); return BC_INVALID_ARGUMENT; }
+  int rc = rccl_load(nullptr);
+  if (rc) return rc;
+  BC_HIP(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  BC_HIP(hipMalloc(&p, 4096));
+  BC_HIP(hipFree(p));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
   return BC_OK;
 }
 
@@ -133,6 +167,44 @@ int bc_comm_all_gather_dev(bc_comm* c, const double* send_dev, double* recv_dev,
 extern "C" int bc_comm_all_gather(bc_comm* c, const void* send_dev, void* recv_dev, int64_t count) {
   if (!c || !send_dev || !recv_dev || count < 0) { bc_set_error("bc_comm_all_gather: bad argument"); return BC_INVALID_ARGUMENT; }
   return bc_comm_all_gather_dev(c, (const double*)send_dev, (double*)recv_dev, (size_t)count);
+}
+
+// Sum of `count` doubles over ranks IN RANK ORDER (the same bits on every rank and on every run, unlike a ring
+// all-reduce): all-gather on the context's stream, then one small kernel adds rank 0, 1, ... in turn.  Replaces the
+// host -> torch.distributed -> host bounce of the replicated S-vector sums (b = Phi^T 1 of a sharded projection,
+// bcores.py:77 per gradient step; hilbert.py:17 once).
+__global__ void k_sum_rank_order(const double* __restrict__ gathered, int world, long long count, double* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    double acc = gathered[i];
+    for (int r = 1; r < world; ++r) acc = acc + gathered[(size_t)r * count + i];
+    out[i] = acc;
+  }
+}
+
+extern "C" int bc_comm_sum_doubles(bc_comm* c, const double* in_dev, int64_t count, double* out_host) {
+  if (!c || !in_dev || !out_host || count <= 0) { bc_set_error("bc_comm_sum_doubles: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (!c->nccl) { bc_set_error("bc_comm_sum_doubles: the communicator was aborted"); return -1; }
+  bc_ctx* ctx = c->ctx;
+  BC_HIP(hipSetDevice(ctx->device));
+  if ((size_t)count > c->sum_cap) {
+    if (c->sum_buf) (void)hipFree(c->sum_buf);
+    c->sum_buf = nullptr;
+    c->sum_cap = 0;
+    BC_HIP(hipMalloc((void**)&c->sum_buf, (size_t)count * (c->world + 1) * sizeof(double)));
+    c->sum_cap = (size_t)count;
+  }
+  if ((size_t)count > ctx->pinned_doubles) { bc_set_error("bc_comm_sum_doubles: at most %zu doubles", ctx->pinned_doubles); return BC_INVALID_ARGUMENT; }
+  double* gathered = c->sum_buf;
+  double* result = c->sum_buf + (size_t)count * c->world;
+  int rc = bc_comm_all_gather_dev(c, in_dev, gathered, (size_t)count);
+  if (rc) return rc;
+  const int blocks = (int)((count + 255) / 256 < 64 ? (count + 255) / 256 : 64);
+  hipLaunchKernelGGL(k_sum_rank_order, dim3(blocks), dim3(256), 0, ctx->stream, gathered, c->world, (long long)count, result);
+  BC_HIP(hipGetLastError());
+  BC_HIP(hipMemcpyAsync(ctx->pinned, result, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(out_host, ctx->pinned, (size_t)count * sizeof(double));
+  return BC_OK;
 }
 
 // Wiring check, run once after creation: every rank contributes a rank-coded pattern and verifies the

@@ -648,6 +648,16 @@ extern "C" int bc_phi_colsum(bc_phi* p, double* out) {
   return BC_OK;
 }
 
+struct bc_comm;
+extern "C" int bc_comm_sum_doubles(bc_comm* c, const double* in_dev, int64_t count, double* out_host);
+
+// b = Phi^T 1 over ALL ranks' row shards (hilbert.py:17, bcores.py:77): this shard's column sums are already in HBM
+// (K1 fuses them); they are all-gathered and added in rank order without leaving the device.
+extern "C" int bc_phi_colsum_all(bc_phi* p, bc_comm* c, double* out) {
+  if (!p || !c || !out) { bc_set_error("bc_phi_colsum_all: bad argument"); return BC_INVALID_ARGUMENT; }
+  return bc_comm_sum_doubles(c, p->colsum, p->s, out);
+}
+
 extern "C" int bc_phi_norms(bc_phi* p, double* out) {
   if (!p || (!out && p->n_rows)) { bc_set_error("bc_phi_norms: bad argument"); return BC_INVALID_ARGUMENT; }
   if (p->n_rows)

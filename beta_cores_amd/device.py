@@ -212,6 +212,12 @@ class DevicePhi:
         N.call('bc_phi_colsum', self.h, _ptr(out))
         return out
 
+    def colsum_all(self, native_comm):
+        """Column sums over ALL ranks' shards, added in rank order on the device (bc_phi_colsum_all)."""
+        out = np.empty(self.shape[1])
+        N.call('bc_phi_colsum_all', self.h, native_comm, _ptr(out))
+        return out
+
     def norms(self):
         out = np.empty(self.shape[0])
         N.call('bc_phi_norms', self.h, _ptr(out))

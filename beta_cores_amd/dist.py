@@ -76,6 +76,31 @@ class _Exchange:
             self.torch.cuda.current_stream(self.ctx.device).synchronize()
 
 
+def _with_deadline(fn, what, rank):
+    """Run a COLLECTIVE bootstrap call with a deadline (BC_RCCL_TIMEOUT seconds, default 180).  If a peer died or
+    never arrived the call cannot return; there is no way to cancel it from here either, so the process exits
+    non-zero -- the launcher (torchrun) then takes the whole job down instead of leaving every rank blocked."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            fn()
+        except BaseException as e:        # noqa: BLE001 -- handed to the caller's thread
+            box['err'] = e
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(float(os.environ.get('BC_RCCL_TIMEOUT', '180')))
+    if t.is_alive():
+        import sys
+        sys.stderr.write('beta_cores_amd: rank %d: %s did not return within BC_RCCL_TIMEOUT -- a peer is missing; '
+                         'exiting so the job is torn down\n' % (rank, what))
+        sys.stderr.flush()
+        os._exit(70)
+    if 'err' in box:
+        raise box['err']
+
+
 class ShardComm:
     """torch.distributed process group + the shard arithmetic the solvers need."""
 
@@ -140,9 +165,10 @@ class ShardComm:
 
         handle, why = None, None
         uid = (C.c_ubyte * 128)()
-        try:                              # local part: find RCCL, rank 0 draws the communicator id
+        try:                              # local part: find RCCL, check the device, rank 0 draws the communicator id
             lib = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
             N.call('bc_comm_load', lib.encode() if os.path.exists(lib) else None)
+            N.call('bc_comm_precheck', ctx.h)          # everything bc_comm_create needs locally, voted on below
             if self.rank == 0:
                 N.call('bc_comm_unique_id', C.cast(uid, C.c_void_p), 128)
         except Exception as e:            # noqa: BLE001 -- any failure here means "use the torch transport"
@@ -154,9 +180,10 @@ class ShardComm:
             uid = (C.c_ubyte * 128)(*t.cpu().tolist())
             try:                          # collective part: communicator + wiring check (rank-coded pattern)
                 h = C.c_void_p()
-                N.call('bc_comm_create', ctx.h, C.cast(uid, C.c_void_p), self.rank, self.world, C.byref(h))
+                _with_deadline(lambda: N.call('bc_comm_create', ctx.h, C.cast(uid, C.c_void_p), self.rank, self.world,
+                                              C.byref(h)), 'ncclCommInitRank', self.rank)
                 handle = h
-                N.call('bc_comm_selftest', h)
+                _with_deadline(lambda: N.call('bc_comm_selftest', h), 'RCCL self-test', self.rank)
             except Exception as e:        # noqa: BLE001
                 why = e
             if not agreed(why is None):
@@ -172,6 +199,22 @@ class ShardComm:
             fin.atexit = False            # at interpreter exit the process teardown reclaims it; peers may be gone
         cache[key] = (handle, fin, ctx)      # keeps ctx alive as long as the communicator
         return handle
+
+    def colsum(self, vecs):
+        """b = sum over all ranks' shards of the column sums of a DevicePhi (hilbert.py:17, bcores.py:77): inside the
+        library over RCCL when the native exchange is up (all-gather + rank-order sum on the device, one host
+        copy), else the same sum through torch.distributed on host arrays.  Bit-identical either way."""
+        nc = self.native_comm(vecs.ctx) if self.world > 1 or os.environ.get('BC_FORCE_EXCHANGE') == '1' else None
+        if nc is not None:
+            return vecs.colsum_all(nc)
+        return self.sum_in_rank_order(vecs.colsum())
+
+    def abort(self):
+        """ncclCommAbort on the native communicators: a rank that failed mid-loop calls this before it exits."""
+        from . import _native as N
+        for handle, _, _ in self.__dict__.get('_native', {}).values():
+            if handle is not None:
+                N.load().bc_comm_abort(handle)
 
     def close(self):
         """Destroy the native communicators (call before torch.distributed.destroy_process_group)."""

@@ -89,7 +89,14 @@ class HipEngine:
         self._live_tol()
         lim = C.c_int()
         if not self.exchange:
-            N.call('bc_snnls_build', self.h, int(itrs), C.byref(lim))
+            try:
+                N.call('bc_snnls_build', self.h, int(itrs), C.byref(lim))
+            except RuntimeError:
+                # a HIP / RCCL failure in the middle of the multi-rank loop: the peers' next all-gather would wait
+                # for this rank forever -- abort the communicator so they fail out of RCCL too, then re-raise
+                if self.native_exchange and self.world > 1:
+                    self.comm.abort()
+                raise
         else:
             # the host carries the records between the two halves of a step (gloo, ranks sharing a GPU)
             done0 = C.c_int()

@@ -104,6 +104,15 @@ int bc_comm_info(const bc_comm* c, int32_t* rank, int32_t* world);
 int bc_comm_all_gather(bc_comm* c, const void* send_dev, void* recv_dev, int64_t count);
 /* collective wiring check: rank-coded pattern gathered and verified element by element */
 int bc_comm_selftest(bc_comm* c);
+/* everything bc_comm_create needs locally (RCCL found, device usable): call on every rank and agree on the
+ * result BEFORE the collective bootstrap, so that a rank which cannot join never leaves the others inside it */
+int bc_comm_precheck(bc_ctx* ctx);
+/* tear down without waiting for outstanding collectives (ncclCommAbort): a rank that fails mid-loop exits
+ * instead of leaving its peers blocked */
+int bc_comm_abort(bc_comm* c);
+/* sum of `count` doubles over ranks, added IN RANK ORDER on the device (bit-stable), result on the host:
+ * replaces vecs.sum(axis=0) of a row-sharded projection (hilbert.py:17, bcores.py:77) */
+int bc_comm_sum_doubles(bc_comm* c, const double* in_dev, int64_t count, double* out_host);
 
 /* ---- data rows (Z) resident on the device ----------------------------- */
 /* replaces the `data`/`pts` ndarray argument of Projector.project (projector.py:23,51) */
@@ -135,6 +144,8 @@ int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta,
 int bc_phi_shape(const bc_phi* phi, int64_t* n_rows, int32_t* s, int64_t* row_offset);
 /* b = Phi^T 1 over the local rows (hilbert.py:17 `vecs.sum(axis=0)`, bcores.py:77) */
 int bc_phi_colsum(bc_phi* phi, double* out_s);
+/* the same summed over all ranks' row shards through a communicator (bc_comm_sum_doubles; bc_comm is declared above) */
+int bc_phi_colsum_all(bc_phi* phi, bc_comm* c, double* out_s);
 /* row norms sqrt(sum_s Phi[i,s]^2) (giga.py:10, hilbert.py:16, bcores.py:78) */
 int bc_phi_norms(bc_phi* phi, double* out_n);
 /* number of all-zero rows (dropped at hilbert.py:16 / bcores.py:67) and sum of norms (frankwolfe.py:21,24) */
