@@ -25,11 +25,19 @@ def linreg_problem(n=5000, d=12, s=48, seed=23):
     return Z, th
 
 
+def overflow_problem(n=6000, s=32, seed=4):
+    rng = np.random.RandomState(seed)
+    phi = rng.randn(n, 12).dot(rng.randn(12, s)) + 0.3 * rng.randn(n, s)
+    phi -= phi.mean(axis=1)[:, None]
+    phi[rng.choice(n, 200, replace=False)] = phi[17]              # 200 exact copies of one row, on both shards
+    return phi
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    if mode in ('gpu_nccl1', 'gpu_nccl1_torch'):
+    if mode in ('gpu_nccl1', 'gpu_nccl1_torch', 'gpu_nccl1_overflow'):
         import torch
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
@@ -62,6 +70,37 @@ def main():
         idx, val = s.sparse_weights()
         res['idx'], res['val'], res['err'] = idx, val, np.array(s.error())
         res['w_dense'] = s.weights()
+    elif mode in ('gpu_overflow', 'gpu_nccl1_overflow'):
+        # a pre-filter whose candidate lists overflow (200 exact copies of one row, capacity 2): the step is marked on
+        # the device and redone with the exact sweep -- through the host-driven exchange (two ranks, one GPU, gloo)
+        # and inside bc_snnls_build with the RCCL all-gather in the loop (one rank)
+        os.environ['BC_PREFILTER'] = '8'
+        os.environ['BC_PREFILTER_CAP'] = '2'
+        if mode == 'gpu_nccl1_overflow':
+            import torch
+            os.environ['BC_FORCE_EXCHANGE'] = '1'
+            stream = torch.cuda.Stream()
+            torch.cuda.set_stream(stream)
+            ctx = bc.Context(device=0, stream=stream.cuda_stream)
+        else:
+            ctx = bc.Context(device=0)
+        bc.set_default_context(ctx)
+        phi = overflow_problem()
+        b = phi.sum(axis=0)
+        bounds = bc.shard_bounds(phi.shape[0], world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        for nm, cls in (('giga', bc.snnls.GIGA), ('fw', bc.snnls.FrankWolfe)):
+            s = cls(phi[lo:hi].T, b, comm=comm, row_offset=lo)
+            assert s._eng.prefilter == 8
+            if mode == 'gpu_nccl1_overflow':
+                assert s._eng.native_exchange
+            s.build(12)
+            s.build(8)
+            idx, val = s.sparse_weights()
+            res[nm + '_idx'], res[nm + '_val'], res[nm + '_err'] = idx, val, np.array(s.error())
+            res[nm + '_trace_f'] = s._eng.trace()[0]
+            res[nm + '_fallbacks'] = np.array(s._eng.prefilter_fallbacks())
+            res[nm + '_next'] = np.array(s._select())            # step-wise protocol through the same situation
     elif mode in ('gpu_nccl1', 'gpu_nccl1_torch'):
         # one rank, RCCL backend, exchange forced on: the exact code path of `bench.py --gpus N`
         # (native: RCCL called by the C library inside bc_snnls_build; torch: one torch.distributed call per step)
@@ -87,6 +126,11 @@ def main():
         res['trace_f'] = h.snnls._eng.trace()[0]
         f = h.snnls._select()                       # step-wise path through the collective as well
         res['next_f'] = np.array(f)
+        if mode == 'gpu_nccl1':
+            # the replicated S-vector sum inside the library (all-gather + rank-order sum on the device)
+            phi = h.snnls._eng.phi
+            res['colsum_native'] = comm.colsum(phi)
+            res['colsum_local'] = phi.colsum()
     elif mode in ('gpu_hilbert', 'gpu_fw', 'gpu_bcores'):
         Z, th = linreg_problem()
         bounds = bc.shard_bounds(Z.shape[0], world)

@@ -47,3 +47,23 @@ def test_bench_sweep_modes_agree():
     b = run_bench('--no-cpu', env={'BC_PREFILTER': '8'})
     assert a['coreset'] == b['coreset']            # same size, same error, same number of failed steps
     assert a['config']['sweep'] == 'fp64' and b['config']['sweep'].startswith('int8')
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver may call it) starts two fresh rank
+    processes through torch.distributed.run and relays rank 0's line.  Rehearsed here with both ranks on the one
+    GPU this box has and gloo carrying the records (RCCL refuses two ranks per device)."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '2',
+           '--rows', '400000', '--dim', '24', '--samples', '40', '--no-cpu', '--no-extra']
+    e = dict(os.environ, BC_BENCH_DEVICE='0', BC_BENCH_BACKEND='gloo')
+    e.pop('WORLD_SIZE', None)
+    e.pop('RANK', None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 10 and d['config']['rows_per_gpu'] == 200064 and d['value'] > 0
+    one = run_bench('--no-cpu', '--no-extra', '--rows', '400000', '--steps', '10', '--warmup', '2')
+    assert one['coreset']['size'] == d['coreset']['size']
+    assert abs(one['coreset']['error'] - d['coreset']['error']) <= 1e-9 * one['coreset']['error']

@@ -77,3 +77,49 @@ def test_rccl_exchange_path_single_rank(tmp_path, mode):
     np.testing.assert_array_equal(r0['trace_f'], single.snnls._eng.trace()[0])
     assert np.array_equal(r0['pts'], Z[single.idcs])
     assert int(r0['next_f']) == single.snnls._select()
+
+
+def test_native_colsum_matches_local_sum(tmp_path):
+    """bc_phi_colsum_all (RCCL all-gather + rank-order sum inside the library) on a 1-rank group returns this
+    rank's own column sums bit for bit."""
+    (r0,) = launch('gpu_nccl1', tmp_path, world=1)
+    assert np.array_equal(r0['colsum_native'], r0['colsum_local'])
+
+
+@pytest.mark.parametrize('mode,world', [('gpu_overflow', 2), ('gpu_nccl1_overflow', 1)])
+def test_prefilter_overflow_across_ranks(tmp_path, mode, world):
+    """A pre-filter overflow on ANY rank makes every rank redo that step with the exact fp64 sweep (the marker
+    travels in the gathered records): results equal the single-rank fp64-sweep run, in the fused loop over both
+    transports and in the step-wise protocol."""
+    import os
+    import beta_cores_amd as bc
+    from dist_worker import overflow_problem
+    phi = overflow_problem()
+    b = phi.sum(axis=0)
+    old = os.environ.get('BC_PREFILTER')
+    os.environ['BC_PREFILTER'] = '0'
+    try:
+        refs = {nm: cls(phi.T, b) for nm, cls in (('giga', bc.snnls.GIGA), ('fw', bc.snnls.FrankWolfe))}
+    finally:
+        if old is None:
+            os.environ.pop('BC_PREFILTER', None)
+        else:
+            os.environ['BC_PREFILTER'] = old
+    res = launch(mode, tmp_path, world=world)
+    for nm, ref in refs.items():
+        ref.build(20)
+        ridx, rval = ref.sparse_weights()
+        nxt = ref._select()
+        for r in res:
+            np.testing.assert_array_equal(r[nm + '_trace_f'], ref._eng.trace()[0])
+            np.testing.assert_array_equal(r[nm + '_idx'], ridx)
+            if nm == 'fw' and world > 1:
+                # Frank-Wolfe scales by the sum of ALL row norms: two shard totals added in rank order instead of one
+                # total -- the one quantity of the solver that depends on the world size, in the last bits
+                np.testing.assert_allclose(r[nm + '_val'], rval, rtol=1e-12)
+                np.testing.assert_allclose(float(r[nm + '_err']), ref.error(), rtol=1e-12)
+            else:
+                np.testing.assert_array_equal(r[nm + '_val'], rval)
+                assert float(r[nm + '_err']) == ref.error()
+            assert int(r[nm + '_next']) == nxt
+        assert sum(int(r[nm + '_fallbacks']) for r in res) >= 1

@@ -124,3 +124,97 @@ def test_fullsize_properties(env, cfg):
     np.testing.assert_allclose(h.wts, ref.w[ridx], rtol=1e-5)
     del phi, phib, data, Z
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ BASELINE configs[3]: N = 10M, D = 128
+def _traces_with_prefilter(bc, phi, b, steps, cls=None):
+    """The same greedy loop through the int8 pre-filter + exact rescoring and through the exact fp64 sweep."""
+    import os
+    cls = cls or bc.snnls.GIGA
+    out = {}
+    for prec in ('8', '0'):
+        old = os.environ.get('BC_PREFILTER')
+        os.environ['BC_PREFILTER'] = prec
+        try:
+            s = cls(phi.T, b)
+        finally:
+            if old is None:
+                os.environ.pop('BC_PREFILTER', None)
+            else:
+                os.environ['BC_PREFILTER'] = old
+        assert s._eng.prefilter == int(prec)
+        s.build(steps)
+        out[prec] = (s._eng.trace(), s.sparse_weights(), s.error(), s)
+    return out
+
+
+@pytest.mark.parametrize('shard', ['full_10M', 'rank3_of_8'])
+def test_config4_headline_size(env, shard):
+    """The headline workload itself (bench.py's data recipe): all 10M rows on one GPU, and the 1 250 048-row shard
+    rank 3 of 8 holds (row_offset = 3 750 144 != 0, global indices).  int8-pre-filter trace == fp64-sweep trace for
+    30 steps, scattered-row K1 vs the oracle, reductions cross-checked, invariants, and a 200k-row prefix through
+    device and oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    bc, torch, ctx = env
+    N, D, S = 10_000_000, 128, 100
+    dev = torch.device('cuda', ctx.device)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(39)
+    thstar = torch.randn((D,), generator=g0, dtype=torch.float64, device=dev)
+    bounds = bc.shard_bounds(N, 8)
+    lo, hi = (0, N) if shard == 'full_10M' else (bounds[3], bounds[4])
+    assert shard == 'full_10M' or (lo, hi - lo) == (3_750_144, 1_250_048)
+    Z = bench.gen_rows(torch, dev, lo, hi, D, thstar)
+    torch.cuda.synchronize()
+    n = hi - lo
+    data = bc.DeviceData.from_torch(Z, ctx=ctx, row_offset=lo)
+    rng = np.random.default_rng(40)
+    # Theta from this shard's own posterior (any fixed S x D matrix would do for the checks below)
+    mu, L, _ = bc.weighted_post(np.zeros(D), np.eye(D), 1.0, data, None)
+    theta = mu + rng.standard_normal((S, D)).dot(L.T)
+    model = bc.likelihoods.LinearRegression(1.0)
+    prj = bc.DeviceProjector(lambda k, w, p: theta, S, model, ctx=ctx)
+    phi = prj.project(data)
+    assert phi.shape == (n, S) and phi.row_offset == lo
+    b = phi.colsum()
+    assert phi.norm_stats()[0] == 0
+    e3 = np.zeros(S); e3[3] = 1.
+    col3 = phi.matvec(e3)
+    assert abs(col3.sum() - b[3]) <= 1e-9 * max(1., np.abs(col3).sum())
+    assert np.abs(phi.matvec(np.ones(S))).max() <= 1e-9 * (1. + np.abs(col3).max())
+    # K1 vs the oracle on rows scattered over the whole shard (first, last, tile edges, random)
+    pick = np.unique(np.concatenate(([0, 1, 127, 128, n - 129, n - 128, n - 1], rng.choice(n, 400, replace=False))))
+    ll = lambda z, t: M.linreg_loglik(z, t, 1.0)
+    ref_rows = C.project(ll, data.rows(pick), theta)
+    got_rows = phi.rows(pick)
+    assert np.abs(got_rows - ref_rows).max() <= 1e-10 * (1. + np.abs(ref_rows).max())
+    np.testing.assert_allclose(phi.norms()[pick], np.sqrt((ref_rows ** 2).sum(axis=1)), rtol=1e-9)
+    # int8 pre-filter + exact rescoring vs the exact fp64 sweep: identical traces, weights and errors
+    tr = _traces_with_prefilter(bc, phi, b, 30)
+    (f8, st8, e8), (i8, v8), err8, s8 = tr['8']
+    (f0, st0, e0), (i0, v0), err0, _ = tr['0']
+    assert np.array_equal(f8, f0) and np.array_equal(st8, st0) and np.array_equal(e8, e0)
+    assert np.array_equal(i8, i0) and np.array_equal(v8, v0) and err8 == err0
+    assert f8.min() >= lo and f8.max() < hi and s8._eng.prefilter_fallbacks() == 0     # global row numbers
+    tr_fw = _traces_with_prefilter(bc, phi, b, 12, bc.snnls.FrankWolfe)
+    assert np.array_equal(tr_fw['8'][0][0], tr_fw['0'][0][0]) and np.array_equal(tr_fw['8'][1][1], tr_fw['0'][1][1])
+    # invariants of the loop at this size (error recomputed from gathered rows, monotone, nnz <= m)
+    check_invariants(bc, phi, bc.snnls.GIGA(phi.T, b), 12)
+    del tr, tr_fw, s8
+    # a 200k-row prefix of the shard through device and oracle: identical selections
+    ns = 200_000
+    Zp = Z[:ns].cpu().numpy()
+    ref = RefGIGA(*(lambda P: (P.T, P.sum(axis=0)))(C.project(ll, Zp, theta)))
+    ref.build(15)
+    h = bc.HilbertCoreset(Zp, bc.DeviceProjector(lambda k, w, p: theta, S, model, ctx=ctx))
+    h.build(15, 15)
+    np.testing.assert_array_equal(h.snnls._eng.trace()[0], [t[0] for t in ref.trace])
+    ridx = np.where(ref.w > 0)[0]
+    np.testing.assert_array_equal(h.idcs, ridx)
+    np.testing.assert_allclose(h.wts, ref.w[ridx], rtol=1e-5)
+    del phi, data, Z, h
+    prj.forget()
+    torch.cuda.empty_cache()
