@@ -2,5 +2,6 @@
 (BatchPSVI, DiffPrivBatchPSVI and UniformSamplingCoreset are out of scope: SURVEY section 2 #12)."""
 from .coreset import Coreset
 from .hilbert import HilbertCoreset
-from .greedy_vi import BetaCoreset, SparseVICoreset
+from .bcores import BetaCoreset
+from .sparsevi import SparseVICoreset
 from .projector import (Projector, BlackBoxProjector, BetaBlackBoxProjector, DeviceProjector, DeviceBetaProjector)

@@ -44,13 +44,12 @@ class Coreset(object):
         if self.reached_numeric_limit:
             return
         if sz < self.size():
-            raise ValueError(self.alg_name + '.build(): requested coreset of size < the current size, but cannot '
-                             'shrink coresets; returning. Requested size = ' + str(sz) + ' current size = '
-                             + str(self.size()))
+            raise ValueError('%s.build(): a coreset cannot shrink -- asked for sz = %d, it already holds %d points'
+                             % (self.alg_name, sz, self.size()))
         self._build(itrs, sz)
         if self.reached_numeric_limit:
-            self.log.warning('the numeric limit has been reached. No more points will be added. size = '
-                             + str(self.size()) + ', error = ' + str(self.error()))
+            self.log.warning('numeric limit reached: no further points will be added (size %d, error %g)'
+                             % (self.size(), self.error()))
 
     def optimize(self):
         try:
@@ -59,9 +58,8 @@ class Coreset(object):
             self._optimize()
             cost1 = self.error()
             if cost1 > cost0 * (1. + util.TOL):
-                raise NumericalPrecisionError(
-                    'self.optimize() returned a solution with increasing error. Numeric limit possibly reached: '
-                    'preverr = ' + str(cost0) + ' err = ' + str(cost1) + '.')
+                raise NumericalPrecisionError('optimize() made the error grow (%g -> %g): numeric limit, weights restored'
+                                              % (cost0, cost1))
         except NumericalPrecisionError as e:
             self.log.warning(e)
             self.wts, self.idcs, self.pts = saved

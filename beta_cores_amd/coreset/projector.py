@@ -210,6 +210,7 @@ class _DeviceProjectorBase(Projector):
         key = id(pts)
         hit = self._pins.get(key)
         if hit is not None and hit[0]() is pts:
+            hit[3] += 1                     # pins nest: the copy goes when the last holder unpins
             return hit[1]
         arr = np.atleast_2d(pts)
         dd = DeviceData(arr, ctx=self.ctx)
@@ -219,12 +220,16 @@ class _DeviceProjectorBase(Projector):
             ref = weakref.ref(pts, lambda _, k=key, pins=self._pins: pins.pop(k, None))
         except TypeError:
             ref = lambda: pts
-        self._pins[key] = (ref, dd, fin)
+        self._pins[key] = [ref, dd, fin, 1]
         return dd
 
     def unpin(self, pts):
-        hit = self._pins.pop(id(pts), None)
-        if hit is not None:
+        hit = self._pins.get(id(pts))
+        if hit is None:
+            return
+        hit[3] -= 1
+        if hit[3] <= 0:
+            self._pins.pop(id(pts), None)
             hit[2].detach()
             _guard_release(id(pts))
 

@@ -375,3 +375,105 @@ def test_group_sum_matches_numpy_bits(bc):
     np.testing.assert_allclose(got.colsum(), want.sum(axis=0), rtol=1e-12, atol=1e-9)
     with pytest.raises(ValueError):
         dev.group_sum([[0, n]])
+
+
+# ------------------------------------------------------------------ projector residency rules (round 2)
+def test_project_results_never_alias(bc):
+    """Every project() returns its own buffers while an earlier result is alive (the reference returns a fresh array,
+    projector.py:24): a solver built on the first Phi must not see the second projection."""
+    rng = np.random.RandomState(31)
+    n, d, s = 6000, 7, 24
+    Z = rng.randn(n, d + 1)
+    ths = [rng.randn(s, d) * 0.4, rng.randn(s, d) * 0.4]
+    cur = [0]
+    prj = bc.DeviceProjector(lambda k, w, p: ths[cur[0]], s, bc.likelihoods.LinearRegression(1.0))
+    phi1 = prj.project(Z)
+    host1 = np.asarray(phi1).copy()
+    b1 = phi1.sum(axis=0)
+    solver = bc.snnls.GIGA(phi1.T, b1)
+    solver.build(5)
+    cur[0] = 1
+    prj.update(np.array([]), np.array([]))
+    phi2 = prj.project(Z)
+    assert phi2.h.value != phi1.h.value
+    assert np.array_equal(np.asarray(phi1), host1)                      # untouched by the second projection
+    assert not np.array_equal(np.asarray(phi2), host1)
+    ref = bc.snnls.GIGA(host1.T, b1)
+    ref.build(15)
+    solver.build(10)
+    assert np.array_equal(solver.sparse_weights()[0], ref.sparse_weights()[0])
+    assert np.array_equal(solver.sparse_weights()[1], ref.sparse_weights()[1])
+
+
+def test_live_arrays_are_read_and_pins_are_loud(bc):
+    """Default: project(ndarray) reads the LIVE array (an in-place edit is seen, like projector.py:24).  pin() keeps
+    a device copy and makes the host array read-only for as long as it is pinned."""
+    rng = np.random.RandomState(32)
+    n, d, s = 5000, 5, 16
+    Z = rng.randn(n, d + 1)
+    th = rng.randn(s, d) * 0.3
+    prj = bc.DeviceProjector(fixed(th), s, bc.likelihoods.LinearRegression(1.0))
+    a = np.asarray(prj.project(Z)).copy()
+    Z[10] += 1.0                                                        # in-place edit of a >= 4096-row array
+    b = np.asarray(prj.project(Z))
+    assert not np.array_equal(a[10], b[10]) and np.array_equal(np.delete(a, 10, 0), np.delete(b, 10, 0))
+    check_phi(prj.project(Z), M.linreg_loglik(Z, th, 1.0))
+    dd = prj.pin(Z)
+    assert prj.pin(Z) is dd and not Z.flags.writeable
+    with pytest.raises(ValueError):
+        Z[11] += 1.0                                                    # loud instead of silently stale
+    c = np.asarray(prj.project(Z))
+    assert np.array_equal(b, c)
+    prj.unpin(Z)
+    assert not Z.flags.writeable            # pins nest (pin was called twice above)
+    prj.unpin(Z)
+    assert Z.flags.writeable
+    Z[11] += 1.0
+    assert not np.array_equal(np.asarray(prj.project(Z))[11], c[11])
+    # a coreset that re-projects all rows per gradient step pins them itself and lets go when it dies
+    alg = bc.SparseVICoreset(Z, prj, opt_itrs=2)
+    assert not Z.flags.writeable
+    alg.build(1, 1)
+    del alg
+    import gc
+    gc.collect()
+    assert Z.flags.writeable
+
+
+def test_repeated_large_subsamples_do_not_grow_device_memory(bc):
+    """BetaCoreset / SparseVI with n_subsample >= 4096 project a NEW data[sub_idcs] array per gradient step: its
+    device copy and its Phi must be recycled, not accumulated."""
+    import torch
+    rng = np.random.RandomState(33)
+    n, d, s = 40000, 6, 32
+    Z = rng.randn(n, d + 1)
+    th = rng.randn(s, d) * 0.3
+    prj = bc.DeviceBetaProjector(fixed(th), s, bc.likelihoods.LinearRegression(1.0))
+    free = []
+    for it in range(40):
+        sub = Z[rng.randint(n, size=10000)]
+        phi = prj.project_f(sub, 0.2)
+        _ = phi.colsum()
+        del phi, sub
+        if it in (9, 39):
+            bc.default_context().sync()
+            free.append(torch.cuda.mem_get_info()[0])
+    assert free[0] - free[1] < 8 * 2 ** 20, (free[0] - free[1]) / 2 ** 20      # < 8 MiB drift over 30 projections
+
+
+def test_device_tolerance_follows_util_tol(bc):
+    """The reference reads util.TOL at every use (giga.py:28): set_tolerance() after a solver exists must reach the
+    device-side numeric-limit checks."""
+    rng = np.random.RandomState(34)
+    phi = rng.randn(3000, 20)
+    phi -= phi.mean(axis=1)[:, None]
+    s = bc.snnls.GIGA(phi.T, phi.sum(axis=0))
+    s.build(3)
+    assert s.size() == 3 and not s.reached_numeric_limit
+    old = bc.util.TOL
+    try:
+        bc.util.set_tolerance(10.)            # ||cdir|| <= 1 < TOL: every _select now raises (giga.py:28-29)
+        s.build(3)
+        assert s.reached_numeric_limit and s.size() == 3
+    finally:
+        bc.util.set_tolerance(old)
