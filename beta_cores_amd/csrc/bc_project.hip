@@ -18,10 +18,13 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double bc_d2v __attribute__((ext_vector_type(2)));
+typedef unsigned int bc_u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int bc_u2v __attribute__((ext_vector_type(2)));
 // Z is read once and Phi written once per projection; the non-temporal policy on both streams
 // (aux = 2 is the `nt` bit of buffer loads on gfx950) was measured and changes nothing here (the kernel
 // is MFMA-bound: 3.18 ms vs 3.05-3.11 ms at N=4M, D=128), so it stays off unless built with -DBC_K1_NT.
@@ -49,7 +52,16 @@ struct ProjArgs {
   int dz, d, dk, s, model;
   int s_total, s_off;     // RAW passes (S > 256): this launch fills samples [s_off, s_off + s) of s_total, un-centred
   double c[8];            // model constants, see model_constants()
+#ifdef BC_K1_STAMPS       // diagnostic build: s_memtime of wave 0 at phase boundaries, 32 slots per tile
+  unsigned long long* stamps;
+#endif
 };
+#ifdef BC_K1_STAMPS
+#define KSTAMP(i) do { if (a.stamps && threadIdx.x == 0) { a.stamps[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0 || (i) == 24) a.stamps[(size_t)blockIdx.x * 32 + ((i) == 0 ? 30 : 31)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define KSTAMP(i) do { } while (0)
+#endif
 
 template <int MODEL>
 __device__ __forceinline__ double bc_model_value(double p, double ra, double sa, const double* c) {
@@ -130,21 +142,15 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   const int S = a.s;
   const int row_base = (JT == 2) ? 32 * w + 2 * j : 16 * w + j;   // this lane's first data row in the tile
 
-  double4_t acc[JT][NT];
-#pragma unroll
-  for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-    for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
+  double4_t acc[JT][NT];     // written by the first k-step
   double tv[JT];
-#pragma unroll
-  for (int jt = 0; jt < JT; ++jt) tv[jt] = 0.;
 
   // Staging through buffer loads: a wave-uniform descriptor per operand (SGPRs), ONE 32-bit
   // per-thread byte offset shared by all passes, and a scalar offset per pass -- no 64-bit
   // address VGPRs.  The Z descriptor covers exactly this tile's valid rows, so rows past the end
   // of the data read as 0 (hardware range check); columns past D are clamped to a valid column
   // and multiply the zero padding of Theta.
-  static_assert(NTHR % KC == 0 && NTHR % (KC / 2) == 0, "staging map");
+  static_assert(NTHR % KC == 0 && NTHR % (KC / 2) == 0 && KC % 8 == 0, "staging map");
   constexpr int ZROWS = NTHR / KC;          // rows of Z covered by one pass
   constexpr int TROWS = NTHR / (KC / 2);    // rows of Theta covered by one pass
   const int zc = tid % KC, zrw = tid / KC;
@@ -156,14 +162,19 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   const int toff = (trw * a.dk + tc) * 8;
   double zr[ZP];
   double2 tr[TP];
-  auto load_chunk = [&](int d0) {
+  // Loads of one chunk in NPART slices: the first chunk is requested in one go, every later one in slices spread over
+  // the contraction of the chunk before it.  (Issued in one go after the barrier, the 23 loads of a chunk held the
+  // wave in the issue stage for 2-4k cycles -- the CU's memory pipeline takes them at ~20 B per cycle -- before its
+  // first MFMA of the chunk: 15 % of the tile's time with nothing on the matrix pipe from this wave.)
+  constexpr int NPART = KC / 8;
+  auto load_part = [&](int d0, int part) {
     const int col = min(d0 + zc, a.d - 1);
     const int voff = (zrw * a.dz + col) * 8;
 #pragma unroll
-    for (int q = 0; q < ZP; ++q)
+    for (int q = part * ZP / NPART; q < (part + 1) * ZP / NPART; ++q)
       zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * ZROWS * a.dz * 8, BC_K1_Z_AUX));
 #pragma unroll
-    for (int q = 0; q < TP; ++q)   // rows past NR are outside the descriptor and read as 0
+    for (int q = part * TP / NPART; q < (part + 1) * TP / NPART; ++q)   // rows past NR are outside the descriptor and read as 0
       tr[q] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, (q * TROWS * a.dk + d0) * 8, 0));
   };
   auto store_chunk = [&]() {
@@ -177,7 +188,9 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   };
 
   const int nchunks = a.dk / KC;
-  load_chunk(0);
+  KSTAMP(0);
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) load_part(0, part);
   // per-row extra (y / x^T Siginv x): requested now, consumed in the epilogue (a dependent load there cost its
   // full memory latency per tile)
   double ra_pf[JT];
@@ -190,15 +203,20 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       else if (MODEL >= BC_MODEL_GAUSS_LL) ra_pf[jt] = a.rowaux[gr];
     }
   }
+  const double4_t zero4 = {0., 0., 0., 0.};
   for (int c = 0; c < nchunks; ++c) {
     store_chunk();
+    KSTAMP(1 + 5 * c);
     __syncthreads();
-    if (c + 1 < nchunks) load_chunk((c + 1) * KC);
+    KSTAMP(2 + 5 * c);
+    const bool more = c + 1 < nchunks;
     const double* zrow0 = Zl + row_base * LDZ + g;
     const double* trow = Tl + j * LDT + g;
     const double* tquad = Tl + (NT * 16 + (j & 3)) * LDT + g;
-#pragma unroll 2
-    for (int kk = 0; kk < KC / 4; ++kk) {
+    // one k-step (4 features): NT*JT 16x16x4 products + the tail quad.  FIRST: the very first step of the tile starts
+    // the accumulators from the instruction's inline-constant 0 (no zero-fill of 100+ VGPRs per tile).
+    auto kstep = [&](int kk, auto first) {
+      constexpr bool FIRST = decltype(first)::value;
       double bz[JT];
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt) bz[jt] = zrow0[jt * LDZ + kk * 4];
@@ -206,7 +224,8 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       for (int st = 0; st < NT; ++st) {
         const double at = trow[st * 16 * LDT + kk * 4];
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bz[jt], acc[jt][st], 0, 0, 0);
+        for (int jt = 0; jt < JT; ++jt)
+          acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bz[jt], FIRST ? zero4 : acc[jt][st], 0, 0, 0);
       }
       if (TL > 0) {
         // the 25th sample quad (S in 97..100) on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per
@@ -217,10 +236,20 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         // vector pipe: 8 v_fma_f64 + 4 operand reads per k-step and 8 shuffles per tile instead of 2 + 1 + 0.)
         const double at = tquad[kk * 4];
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) tv[jt] = __builtin_amdgcn_mfma_f64_4x4x4f64(at, bz[jt], tv[jt], 0, 0, 0);
+        for (int jt = 0; jt < JT; ++jt) tv[jt] = __builtin_amdgcn_mfma_f64_4x4x4f64(at, bz[jt], FIRST ? 0. : tv[jt], 0, 0, 0);
       }
+    };
+#pragma unroll
+    for (int kp = 0; kp < NPART; ++kp) {
+      if (more) load_part((c + 1) * KC, kp);
+      if (kp == 0 && c == 0) kstep(0, std::true_type{});
+      else kstep(2 * kp, std::false_type{});
+      kstep(2 * kp + 1, std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);     // keeps each slice of loads with its pair of k-steps
     }
+    KSTAMP(4 + 5 * c);
     __syncthreads();
+    KSTAMP(5 + 5 * c);
   }
   const int s_tail = NT * 16 + g;
 
@@ -249,6 +278,105 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   // column partials reuse the staging LDS (all of it: Zl and Tl are dead after the loop)
   constexpr bool LDSCP = (JT == 2) && (NTHR / 64) * NR * 17 <= 128 * LDZ + NR * LDT;
   double* colpart = LDSCP ? lds : Tl;   // LDSCP: [waves][NR][17], else [waves][NR]
+  if (TL > 0) {
+    // 96 < S <= 100 (every BASELINE config): all samples of the NT tiles are real ones and every lane holds some, so
+    // the `s < S` predicates vanish.  Rows past the end of the shard (last tile only) read as zeros, give finite
+    // model values, and are zeroed after the fact under a block-uniform branch instead of a select per element.
+    // "All S values of the row are equal" is not tracked per element either: such a row shows up afterwards as a
+    // centred row with a vanishing norm and is then examined exactly (below).
+    const bool full_tile = rows_here == BC_TILE;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      const double ra = ra_pf[jt];
+      double sum = 0.;
+#pragma unroll
+      for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const double v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[16 * st + g + 4 * reg] : 0., a.c);
+          acc[jt][st][reg] = v;
+          sum += v;
+        }
+      {
+        const double v = (s_tail < S) ? bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c) : 0.;
+        tv[jt] = v;
+        sum += v;
+      }
+      sum += __shfl_xor(sum, 16, BC_WAVE);
+      sum += __shfl_xor(sum, 32, BC_WAVE);
+      double mean = sum / (double)S;                 // lls.mean(axis=1), tree order
+      double sq = 0.;
+#pragma unroll
+      for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const double v = acc[jt][st][reg] - mean;
+          acc[jt][st][reg] = v;
+          sq = fma(v, v, sq);
+        }
+      {
+        const double v = (s_tail < S) ? tv[jt] - mean : 0.;
+        tv[jt] = v;
+        sq = fma(v, v, sq);
+      }
+      sq += __shfl_xor(sq, 16, BC_WAVE);
+      sq += __shfl_xor(sq, 32, BC_WAVE);
+      // A row whose S values are all the same number c (a data row with all-zero features): the reference subtracts
+      // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny
+      // constant residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The
+      // tree-order sum above rounds differently and would flip that zero / non-zero status, so such rows are
+      // re-centred with NumPy's order.  Every constant row lands here: its centred values are a few ulp of c, i.e.
+      // sq <= S*(8 eps c)^2, a thousand times inside the bound below (and NaN rows never do: they stay NaN as in the
+      // reference).  Inside the bound each v was within 1e-11 of the mean, so v - mean was exact (Sterbenz) and
+      // mean + (v - mean) gives v back exactly: "all v equal" is decided, exactly, on the centred values.
+      const double tiny = 1e-12 * mean;
+      const bool suspect = sq <= (double)S * (tiny * tiny);
+      if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) {
+        double d0 = acc[jt][0][0];
+        asm volatile("" : "+v"(d0));                 // keeps the 25 compares below out of the straight-line code
+        bool same = suspect;
+#pragma unroll
+        for (int st = 0; st < NT; ++st)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) same &= (acc[jt][st][reg] == d0);
+        if (s_tail < S) same &= (tv[jt] == d0);
+        int ok = same ? 1 : 0;
+        ok &= (d0 == __shfl_xor(d0, 16, BC_WAVE)) ? 1 : 0;
+        ok &= __shfl_xor(ok, 16, BC_WAVE);
+        ok &= (d0 == __shfl_xor(d0, 32, BC_WAVE)) ? 1 : 0;
+        ok &= __shfl_xor(ok, 32, BC_WAVE);
+        if (ok) {                                    // the four lanes of a constant row take this together
+          const double cval = mean + d0;
+          mean = bc_np_sum_const_256(cval, S) / (double)S;
+          const double v = cval - mean;
+          sq = 0.;
+#pragma unroll
+          for (int st = 0; st < NT; ++st)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              acc[jt][st][reg] = v;
+              sq = fma(v, v, sq);
+            }
+          const double vt = (s_tail < S) ? v : 0.;
+          tv[jt] = vt;
+          sq = fma(vt, vt, sq);
+        }
+        // the four lanes of a row agree on `ok`: a recomputed row adds up its four new partial sums, every other
+        // row keeps the total it had
+        double sq2 = ok ? sq : 0.;
+        sq2 += __shfl_xor(sq2, 16, BC_WAVE);
+        sq2 += __shfl_xor(sq2, 32, BC_WAVE);
+        if (ok) sq = sq2;
+      }
+      if (!full_tile && !(r0 + row_base + jt < a.n_rows)) {
+#pragma unroll
+        for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
+        tv[jt] = 0.;
+        sq = 0.;
+      }
+      if (g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
+    }
+  } else {
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) {
     const long long gr = r0 + row_base + jt;
@@ -335,55 +463,46 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     sq += __shfl_xor(sq, 32, BC_WAVE);
     if (g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
   }
-  // store the tile (JT == 2: two adjacent rows per lane -> 16-byte stores, 256 B contiguous per 16 lanes)
-  double* tbase = a.tiles + (size_t)tile * S * BC_TILE + row_base;
-#pragma unroll
-  for (int st = 0; st < NT; ++st) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int s = 16 * st + g + 4 * reg;
-      double cp;
-      if (JT == 2) {
-        if (TL > 0 || s < S) bc_store2(tbase + (size_t)s * BC_TILE, acc[0][st][reg], acc[JT - 1][st][reg]);
-        cp = acc[0][st][reg] + acc[JT - 1][st][reg];
-      } else {
-        if (s < S) tbase[(size_t)s * BC_TILE] = acc[0][st][reg];
-        cp = acc[0][st][reg];
-      }
-      // per-tile column partial (K2): sum over the tile's rows.  JT == 2 kernels park each lane's pair sum in LDS
-      // ([wave][sample][16 row pairs], rows padded to 17) and let one thread per sample add them up in a fixed
-      // order -- a 4-step fp64 shuffle reduction per value cost ~8 % of the kernel (0.25 ms per 4M rows).
-      if (LDSCP) {
-        colpart[(w * NR + s) * 17 + j] = cp;
-      } else {
-        cp += __shfl_xor(cp, 1, BC_WAVE);
-        cp += __shfl_xor(cp, 2, BC_WAVE);
-        cp += __shfl_xor(cp, 4, BC_WAVE);
-        cp += __shfl_xor(cp, 8, BC_WAVE);
-        if (j == 0) colpart[w * NR + s] = cp;
-      }
-    }
   }
-  if (TL > 0) {
+  KSTAMP(21);
+  // store the tile (JT == 2: two adjacent rows per lane -> 16-byte stores, 256 B contiguous per 16 lanes) through a
+  // buffer descriptor of exactly this tile's S*128 doubles: one per-lane byte offset for all stores, the sample's
+  // offset as the instruction's scalar operand (no 64-bit address arithmetic per store), samples >= S dropped by the
+  // hardware range check.  Column partials: one LDS base per lane, constant offsets.
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tiles + (size_t)tile * S * BC_TILE), 0,
+                                                       S * BC_TILE * 8, 0x00020000);
+  const int woff = (g * BC_TILE + row_base) * 8;
+  double* cpl = LDSCP ? colpart + (w * NR + g) * 17 + j : colpart + w * NR + g;
+  auto put = [&](int s0, double v0, double v1) {       // sample s0 + g of this lane's row(s)
     double cp;
     if (JT == 2) {
-      if (s_tail < S) bc_store2(tbase + (size_t)s_tail * BC_TILE, tv[0], tv[JT - 1]);
-      cp = tv[0] + tv[JT - 1];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bc_u4v, (bc_d2v){v0, v1}), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
+      cp = v0 + v1;
     } else {
-      if (s_tail < S) tbase[(size_t)s_tail * BC_TILE] = tv[0];
-      cp = tv[0];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bc_u2v, v0), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
+      cp = v0;
     }
+    // per-tile column partial (K2): sum over the tile's rows.  JT == 2 kernels park each lane's pair sum in LDS
+    // ([wave][sample][16 row pairs], rows padded to 17) and let one thread per sample add them up in a fixed
+    // order -- a 4-step fp64 shuffle reduction per value cost ~8 % of the kernel (0.25 ms per 4M rows).
     if (LDSCP) {
-      colpart[(w * NR + s_tail) * 17 + j] = cp;
+      cpl[s0 * 17] = cp;
     } else {
       cp += __shfl_xor(cp, 1, BC_WAVE);
       cp += __shfl_xor(cp, 2, BC_WAVE);
       cp += __shfl_xor(cp, 4, BC_WAVE);
       cp += __shfl_xor(cp, 8, BC_WAVE);
-      if (j == 0) colpart[w * NR + s_tail] = cp;
+      if (j == 0) cpl[s0] = cp;
     }
-  }
+  };
+#pragma unroll
+  for (int st = 0; st < NT; ++st)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) put(16 * st + 4 * reg, acc[0][st][reg], acc[JT - 1][st][reg]);
+  if (TL > 0) put(NT * 16, tv[0], tv[JT - 1]);
+  KSTAMP(22);
   __syncthreads();
+  KSTAMP(23);
   constexpr int NW = NTHR / 64;
   for (int s = tid; s < S; s += NTHR) {
     double t = 0.;
@@ -401,6 +520,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     }
     a.tile_part[(size_t)tile * S + s] = t;
   }
+  KSTAMP(24);
 }
 
 // S > 256, second stage: centre the rows of one tile (subtract the mean over all s_total samples; constant
@@ -739,7 +859,10 @@ static int model_constants(int model, const double* p, int np, int d, double* c,
 
 template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0>
 static int launch_project(bc_ctx* ctx, const ProjArgs& a, long long ntiles) {
-  const size_t lds = (size_t)(128 * (KC + 1) + (NT * 16 + TL) * (KC + 2)) * sizeof(double);
+  size_t lds = (size_t)(128 * (KC + 1) + (NT * 16 + TL) * (KC + 2)) * sizeof(double);
+#ifdef BC_K1_STAMPS
+  if (getenv("BC_K1_EXTRA_LDS")) lds += (size_t)atoi(getenv("BC_K1_EXTRA_LDS"));   // diagnostic: fewer blocks per CU
+#endif
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT, RAW, TL>),
@@ -784,6 +907,9 @@ static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const doubl
   BC_HIP(hipSetDevice(ctx->device));
   ProjArgs a;
   memset(&a, 0, sizeof(a));
+#ifdef BC_K1_STAMPS
+  a.stamps = getenv("BC_K1_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("BC_K1_STAMP_PTR"), nullptr, 10) : nullptr;
+#endif
   const double* siginv = nullptr;
   if (model_constants(model, params, n_params, d, a.c, &siginv) != BC_OK) {
     bc_set_error("bc_project: model %d expects a different number of parameters than %d (d = %d)", model, n_params, d);
