@@ -66,12 +66,14 @@ struct ProjArgs {
 template <int MODEL>
 __device__ __forceinline__ double bc_model_value(double p, double ra, double sa, const double* c) {
   switch (MODEL) {
+    // (2p)*y is evaluated as p*(2y): doubling is exact, so the product rounds to the same double, and 2y -- like y*y --
+    // is a per-row value that stays out of the per-sample code
     case BC_MODEL_LINREG_LL: {            // c0 - c1*(y^2 - 2*p*y + p^2)
-      const double q = (ra * ra - (2. * p) * ra) + p * p;
+      const double q = (ra * ra - p * (2. * ra)) + p * p;
       return c[0] - c[1] * q;
     }
     case BC_MODEL_LINREG_BETA: {          // k0*(k1*exp(k2*q) + k3)
-      const double q = (ra * ra - (2. * p) * ra) + p * p;
+      const double q = (ra * ra - p * (2. * ra)) + p * p;
       return c[0] * (c[1] * exp(c[2] * q) + c[3]);
     }
     case BC_MODEL_LOGISTIC_LL: {          // m = -z.th ; m < 100 ? -log1p(exp(m)) : -m
@@ -166,15 +168,17 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   // the contraction of the chunk before it.  (Issued in one go after the barrier, the 23 loads of a chunk held the
   // wave in the issue stage for 2-4k cycles -- the CU's memory pipeline takes them at ~20 B per cycle -- before its
   // first MFMA of the chunk: 15 % of the tile's time with nothing on the matrix pipe from this wave.)
-  constexpr int NPART = KC / 8;
+  constexpr int NPART = KC / 8;                        // pairs of k-steps per chunk
+  constexpr int NSL = KC / 4 > 2 ? KC / 4 - 2 : 1;     // slices: one per k-step, none in the chunk's last two (their
+                                                       // loads would not be back when the chunk is written to LDS)
   auto load_part = [&](int d0, int part) {
     const int col = min(d0 + zc, a.d - 1);
     const int voff = (zrw * a.dz + col) * 8;
 #pragma unroll
-    for (int q = part * ZP / NPART; q < (part + 1) * ZP / NPART; ++q)
+    for (int q = part * ZP / NSL; q < (part + 1) * ZP / NSL; ++q)
       zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * ZROWS * a.dz * 8, BC_K1_Z_AUX));
 #pragma unroll
-    for (int q = part * TP / NPART; q < (part + 1) * TP / NPART; ++q)   // rows past NR are outside the descriptor and read as 0
+    for (int q = part * TP / NSL; q < (part + 1) * TP / NSL; ++q)   // rows past NR are outside the descriptor and read as 0
       tr[q] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, (q * TROWS * a.dk + d0) * 8, 0));
   };
   auto store_chunk = [&]() {
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   const int nchunks = a.dk / KC;
   KSTAMP(0);
 #pragma unroll
-  for (int part = 0; part < NPART; ++part) load_part(0, part);
+  for (int part = 0; part < NSL; ++part) load_part(0, part);
   // per-row extra (y / x^T Siginv x): requested now, consumed in the epilogue (a dependent load there cost its
   // full memory latency per tile)
   double ra_pf[JT];
@@ -241,11 +245,13 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     };
 #pragma unroll
     for (int kp = 0; kp < NPART; ++kp) {
-      if (more) load_part((c + 1) * KC, kp);
+      if (more && 2 * kp < NSL) load_part((c + 1) * KC, 2 * kp);
       if (kp == 0 && c == 0) kstep(0, std::true_type{});
       else kstep(2 * kp, std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);     // keeps each slice of loads with its k-step
+      if (more && 2 * kp + 1 < NSL) load_part((c + 1) * KC, 2 * kp + 1);
       kstep(2 * kp + 1, std::false_type{});
-      __builtin_amdgcn_sched_barrier(0);     // keeps each slice of loads with its pair of k-steps
+      __builtin_amdgcn_sched_barrier(0);
     }
     KSTAMP(4 + 5 * c);
     __syncthreads();
