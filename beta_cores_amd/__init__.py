@@ -2,7 +2,8 @@
 
 Drop-in for the `bayesiancoresets` names on this path (bayesiancoresets/__init__.py:1):
     import beta_cores_amd as bc
-    bc.HilbertCoreset, bc.BetaCoreset, bc.SparseVICoreset, bc.BlackBoxProjector, bc.BetaBlackBoxProjector,
+    bc.HilbertCoreset, bc.BetaCoreset, bc.SparseVICoreset, bc.BatchPSVICoreset, bc.UniformSamplingCoreset,
+    bc.BlackBoxProjector, bc.BetaBlackBoxProjector,
     bc.Projector, bc.snnls.{GIGA, FrankWolfe, OrthoPursuit, ImportanceSampling, UniformSampling},
     bc.util.{nn_opt, set_verbosity, TOL, set_tolerance}
 plus the device-resident projector bc.DeviceProjector / bc.DeviceBetaProjector (K1 on the GPU).
@@ -13,7 +14,8 @@ from . import util
 from . import snnls
 from .util.errors import NumericalPrecisionError
 from .device import Context, DeviceData, DevicePhi, default_context, set_default_context
-from .coreset import (Coreset, HilbertCoreset, BetaCoreset, SparseVICoreset, Projector, BlackBoxProjector,
+from .coreset import (Coreset, HilbertCoreset, BetaCoreset, SparseVICoreset, BatchPSVICoreset, UniformSamplingCoreset,
+                      Projector, BlackBoxProjector,
                       BetaBlackBoxProjector, DeviceProjector, DeviceBetaProjector)
 from . import likelihoods
 from .posterior import weighted_gram, weighted_post, weighted_post_corrected, gaussian_weighted_post
@@ -21,6 +23,7 @@ from .dist import ShardComm, shard_bounds
 
 __all__ = ['util', 'snnls', 'likelihoods', 'NumericalPrecisionError', 'Context', 'DeviceData', 'DevicePhi',
            'default_context', 'set_default_context', 'Coreset', 'HilbertCoreset', 'BetaCoreset', 'SparseVICoreset',
+           'BatchPSVICoreset', 'UniformSamplingCoreset',
            'Projector', 'BlackBoxProjector', 'BetaBlackBoxProjector', 'DeviceProjector', 'DeviceBetaProjector',
            'ShardComm', 'shard_bounds', 'weighted_gram', 'weighted_post', 'weighted_post_corrected',
            'gaussian_weighted_post']

@@ -40,6 +40,7 @@ _SIGNATURES = {
     'bc_phi_from_host': [vp, vp, C.c_int64, C.c_int32, C.c_int64, vpp],
     'bc_phi_create': [vp, C.c_int64, C.c_int32, vpp],
     'bc_project': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, C.c_int64, vpp],
+    'bc_project_grad_x': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, vp],
     'bc_phi_shape': [vp, c_i64p, c_i32p, c_i64p],
     'bc_phi_colsum': [vp, vp],
     'bc_phi_norms': [vp, vp],

@@ -281,9 +281,24 @@ class DeviceProjector(_DeviceProjectorBase):
     """GPU counterpart of BlackBoxProjector: `project(pts)` returns a DevicePhi."""
 
     def project(self, pts, grad=False):
-        if grad:
-            raise NotImplementedError('x-gradients of the log-likelihood (BatchPSVI) are out of this path\'s scope')
-        return self._run(pts, self.model.model_id, self.model.params())
+        """projector.py:23-32.  With `grad` also the x-gradient tensor of the log-likelihood at `pts` (M x S x W host
+        array, centred over its last axis as the reference does it): bc_project_grad_x, meant for the coreset's
+        pseudo-points (BatchPSVICoreset, bpsvi.py:39-40)."""
+        lls = self._run(pts, self.model.model_id, self.model.params())
+        if not grad:
+            return lls
+        return lls, self._grad_x(pts)
+
+    def _grad_x(self, pts):
+        if not self.model.has_grad_x:
+            raise ValueError('grad_loglikelihood was requested but this model has none')
+        dd, _ = self.device_data(pts)
+        theta = self.model.theta_for_device(self.samples)
+        params = np.ascontiguousarray(self.model.params(), dtype=np.float64)
+        out = np.empty((dd.shape[0], int(theta.shape[0]), dd.shape[1]))
+        N.call('bc_project_grad_x', self.ctx.h, dd.h, int(self.model.model_id), _ptr(theta), int(theta.shape[0]),
+               _ptr(params), int(params.shape[0]), _ptr(out))
+        return out
 
 
 class DeviceBetaProjector(_DeviceProjectorBase):

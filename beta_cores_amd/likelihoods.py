@@ -15,6 +15,7 @@ class _Model:
     model_id = None
     beta_model_id = None
     beta_grad_model_id = None
+    has_grad_x = False        # d/dx of the log-likelihood (bc_project_grad_x)
 
     def theta_for_device(self, samples):
         return np.ascontiguousarray(np.atleast_2d(samples), dtype=np.float64)
@@ -25,7 +26,8 @@ class _Model:
 
 class LinearRegression(_Model):
     """Rows z = [x (D), y].  log-lik: model_linreg.py:4-10 == model_neurlinr.py:90-97;
-    beta-likelihood: model_neurlinr.py:102-110."""
+    beta-likelihood: model_neurlinr.py:102-110; x-gradient: model_linreg.py:12-17."""
+    has_grad_x = True
     model_id = LINREG_LL
     beta_model_id = LINREG_BETA
 
@@ -40,7 +42,8 @@ class LinearRegression(_Model):
 
 
 class LogisticRegression(_Model):
-    """Rows z = y*x (D).  log-lik: model_lr.py:72-79; beta-likelihood: model_lr.py:81-86."""
+    """Rows z = y*x (D).  log-lik: model_lr.py:72-79; beta-likelihood: model_lr.py:81-86; z-gradient: :107-114."""
+    has_grad_x = True
     model_id = LOGISTIC_LL
     beta_model_id = LOGISTIC_BETA
 
@@ -52,8 +55,9 @@ class LogisticRegression(_Model):
 
 
 class GaussianLocation(_Model):
-    """Rows x (d), known covariance.  gaussian.py:7-15 (log-lik), :34-44 (beta-likelihood),
+    """Rows x (d), known covariance.  gaussian.py:7-15 (log-lik), :17-20 (x-gradient), :34-44 (beta-likelihood),
     :46-62 (d/dbeta)."""
+    has_grad_x = True
     model_id = GAUSS_LL
     beta_model_id = GAUSS_BETA
     beta_grad_model_id = GAUSS_BETA_GRAD

@@ -2,11 +2,12 @@
 """Gaussian-location coresets with outliers -- the reference's examples/zellner_gaussian/main.py
 experiment (data recipe :33-54, algorithms :97-108, KL metrics :153-167) on the MI355X path.
 
-    python examples/zellner_gaussian.py BCORES 1          # alg in {BCORES, SVI, GIGAO, GIGAR}, trial seed
+    python examples/zellner_gaussian.py BCORES 1          # alg in {BCORES, BPSVI, SVI, GIGAO, GIGAR, RAND, PRIOR}, trial seed
 
 Differences from the reference script: `import beta_cores_amd as bc`, the projectors are the device
-ones (K1 on the GPU) and `weighted_post` is `bc.gaussian_weighted_post` (K4).  BPSVI / RAND / PRIOR are
-outside this path's scope.  Results are printed, not pickled.
+ones (K1 on the GPU) and `weighted_post` is `bc.gaussian_weighted_post` (K4).  BPSVI is built for m = 1..M one after
+the other instead of in a multiprocessing pool (main.py:126-135): every build starts from the RNG state the pool's
+forked children would inherit.  Results are printed, not pickled.
 """
 import os
 import sys
@@ -76,16 +77,33 @@ def run(nm='BCORES', tr=1, N=5000, d=50, M=40, opt_itrs=200, n_subsample_opt=200
         alg = bc.HilbertCoreset(Xc, prj_optimal)
     elif nm == 'GIGAR':
         alg = bc.HilbertCoreset(Xc, prj_realistic)
+    elif nm == 'BPSVI':
+        alg = bc.BatchPSVICoreset(Xc, prj_w, opt_itrs=opt_itrs, n_subsample_opt=n_subsample_opt,
+                                  step_sched=lambda m: lambda i: i0 / (1. + i))
+    elif nm == 'RAND':
+        alg = bc.UniformSamplingCoreset(Xc)
+    elif nm == 'PRIOR':
+        alg = None
     else:
-        raise SystemExit('alg must be one of BCORES, SVI, GIGAO, GIGAR')
+        raise SystemExit('alg must be one of BCORES, BPSVI, SVI, GIGAO, GIGAR, RAND, PRIOR')
 
     w, p, idl = [np.array([0.])], [np.zeros((1, Xc.shape[1]))], [np.zeros(0, dtype=np.int64)]
+    fork_state = np.random.get_state()
     for m in range(1, M + 1):
+        if nm == 'PRIOR':
+            w.append(np.array([0.]))
+            p.append(np.zeros((1, Xc.shape[1])))
+            idl.append(np.zeros(0, dtype=np.int64))
+            continue
+        if nm == 'BPSVI':
+            np.random.set_state(fork_state)          # main.py:126-135: each m is built in a forked child of the pool
         alg.build(1, m)
         got = alg.get()
         w.append(got[0].copy())
         p.append(got[1].copy())
         idl.append(got[2].copy())
+    if nm == 'BPSVI':
+        np.random.set_state(fork_state)              # the parent's own stream never moved
     rkl, fkl = np.zeros(M + 1), np.zeros(M + 1)
     if verbose:
         print('%4s %12s %12s' % ('m', 'reverse KL', 'forward KL'))

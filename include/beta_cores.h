@@ -141,6 +141,13 @@ int bc_phi_create(bc_ctx* ctx, int64_t cap_rows, int32_t s, bc_phi** out);
  * re-projects every gradient call, bcores.py:141-146). Fuses row norms and column sums (K2). */
 int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
+/* x-gradients of the log-likelihood at `data`'s rows (the coreset's pseudo-points), centred over the coordinate axis:
+ * what BlackBoxProjector.project(pts, grad=True) returns next to the projection (projector.py:27-32) and
+ * BatchPSVICoreset moves its points with (bpsvi.py:39-57).  model: BC_MODEL_LINREG_LL (model_linreg.py:12-17,
+ * W = D+1), BC_MODEL_LOGISTIC_LL (model_lr.py:107-114, W = D) or BC_MODEL_GAUSS_LL (gaussian.py:17-20, W = d), params as
+ * for bc_project.  out: host, M x S x W row-major (M = rows of `data`, W = its row width). */
+int bc_project_grad_x(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                      const double* params, int32_t n_params, double* out);
 int bc_phi_shape(const bc_phi* phi, int64_t* n_rows, int32_t* s, int64_t* row_offset);
 /* b = Phi^T 1 over the local rows (hilbert.py:17 `vecs.sum(axis=0)`, bcores.py:77) */
 int bc_phi_colsum(bc_phi* phi, double* out_s);

@@ -6,6 +6,7 @@
   bayesiancoresets/coreset/hilbert.py:6-43      HilbertCoreset
   bayesiancoresets/coreset/bcores.py:8-156      BetaCoreset (all four tangent-space modes; learn_beta as pinned by F15)
   bayesiancoresets/coreset/sparsevi.py:8-139    SparseVI
+  bayesiancoresets/coreset/bpsvi.py:6-65        BatchPSVICoreset (pseudo-points moved by x-gradients)
   bayesiancoresets/util/opt.py:36-77            nn_opt / partial_nn_opt
 """
 import numpy as np
@@ -17,6 +18,15 @@ def project(loglik, pts, samples):
     v = loglik(pts, samples)
     v -= v.mean(axis=1)[:, np.newaxis]
     return v
+
+
+def project_grad(loglik, grad_loglik, pts, samples):
+    """projector.py:23-32 with grad=True: the gradient tensor (M, S, D) is centred over its LAST axis (axis=2, the
+    coordinates of x -- not the samples), exactly as the reference writes it"""
+    v = project(loglik, pts, samples)
+    g = grad_loglik(pts, samples)
+    g -= g.mean(axis=2)[:, :, np.newaxis]
+    return v, g
 
 
 def project_f(beta_lik, pts, samples, beta):
@@ -231,3 +241,64 @@ class RefGreedyVI:
     def get(self):
         keep = self.wts > 0
         return self.wts[keep], self.pts[keep, :], self.idcs[keep]
+
+
+class RefBatchPSVI:
+    """bpsvi.py:6-65.  `sampler(wts, pts)` -> Theta (projector.py:34-35); loglik / grad_loglik take (pts, samples)."""
+
+    def __init__(self, data, loglik, grad_loglik, sampler, opt_itrs, n_subsample_opt=None,
+                 step_sched=lambda m: lambda i: 1. / (1. + i), projector_draw=True):
+        self.data = data
+        self.loglik, self.grad_loglik, self.sampler = loglik, grad_loglik, sampler
+        self.opt_itrs = opt_itrs
+        self.n_subsample_opt = None if n_subsample_opt is None else min(data.shape[0], n_subsample_opt)   # bpsvi.py:11
+        self.step_sched = step_sched
+        self.wts, self.idcs, self.pts = np.array([]), np.array([], dtype=np.int64), np.zeros((0, data.shape[1]))
+        # the projector draws its first Theta when IT is constructed (projector.py:17); a caller that already accounted
+        # for that draw (one projector shared by several coresets, as in the driver) passes projector_draw=False
+        self.samples = sampler(np.array([]), np.array([])) if projector_draw else None
+
+    def build(self, itrs, sz):                                                                           # bpsvi.py:17-25
+        init_idcs = np.random.choice(self.data.shape[0], size=sz, replace=False)
+        self.pts = self.data[init_idcs]
+        self.wts = self.data.shape[0] / sz * np.ones(sz)
+        self.idcs = init_idcs
+        self.optimize()
+
+    def _get_projection(self, n_subsample, w, p):                                                        # bpsvi.py:27-43
+        self.samples = self.sampler(w, p)
+        if n_subsample is None:
+            sub_idcs = None
+            vecs = project(self.loglik, self.data, self.samples)
+            sum_scaling = 1.
+        else:
+            sub_idcs = np.random.randint(self.data.shape[0], size=n_subsample)
+            vecs = project(self.loglik, self.data[sub_idcs], self.samples)
+            sum_scaling = self.data.shape[0] / n_subsample
+        if p.size > 0:
+            corevecs, pgrads = project_grad(self.loglik, self.grad_loglik, p, self.samples)
+        else:
+            corevecs, pgrads = np.zeros((0, vecs.shape[1])), np.zeros((0, vecs.shape[1], p.shape[1]))
+        return vecs, sum_scaling, sub_idcs, corevecs, pgrads
+
+    def optimize(self):                                                                                  # bpsvi.py:45-62
+        sz = self.wts.shape[0]
+        d = self.pts.shape[1]
+
+        def grd(x):
+            w = x[:sz]
+            p = x[sz:].reshape((sz, d))
+            vecs, sum_scaling, sub_idcs, corevecs, pgrads = self._get_projection(self.n_subsample_opt, w, p)
+            resid = sum_scaling * vecs.sum(axis=0) - w.dot(corevecs)
+            wgrad = -corevecs.dot(resid) / corevecs.shape[1]
+            ugrad = -(w[:, np.newaxis, np.newaxis] * pgrads * resid[np.newaxis, :, np.newaxis]).sum(axis=1) / corevecs.shape[1]
+            return np.hstack((wgrad, ugrad.reshape(sz * d)))
+
+        x0 = np.hstack((self.wts, self.pts.reshape(sz * d)))
+        xf = partial_nn_opt(x0, grd, np.arange(sz), self.opt_itrs, step_sched=self.step_sched(sz))
+        self.wts = xf[:sz]
+        self.pts = xf[sz:].reshape((sz, d))
+
+    def get(self):                                                                                       # coreset.py:25-26
+        return self.wts[self.wts > 0], self.pts[self.wts > 0, :], self.idcs[self.wts > 0]
+

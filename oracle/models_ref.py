@@ -133,3 +133,31 @@ def gaussian_KL(mu0, Sig0, mu1, Sig1inv):
     t2 = np.dot((mu1 - mu0), np.dot(Sig1inv, mu1 - mu0))
     t3 = -np.linalg.slogdet(Sig1inv)[1] - np.linalg.slogdet(Sig0)[1]
     return 0.5 * (t1 + t2 + t3 - mu0.shape[0])
+
+
+# ---- x-gradients of the log-likelihood (BatchPSVICoreset: bpsvi.py:39-40 through projector.py:27-32)
+def linreg_grad_x_loglik(z, th, sigsq):
+    """model_linreg.py:12-17 (== model_neurlinr.py:99-100): (M, S, D+1), the last column is d/dy's stand-in 1"""
+    x, y = _split_xy(z)
+    th = np.atleast_2d(th)
+    return 1. / sigsq * (y[:, np.newaxis] - x.dot(th.T))[:, :, np.newaxis] \
+        * np.hstack((th, np.ones(th.shape[0])[:, np.newaxis]))[np.newaxis, :, :]
+
+
+def logistic_grad_z_loglik(z, th):
+    """model_lr.py:107-114: (M, S, D)"""
+    z = np.atleast_2d(z)
+    th = np.atleast_2d(th)
+    m = -z.dot(th.T)
+    idcs = m < 100
+    m[idcs] = np.exp(m[idcs]) / (1. + np.exp(m[idcs]))
+    m[np.logical_not(idcs)] = 1.
+    return m[:, :, np.newaxis] * th[np.newaxis, :, :]
+
+
+def gauss_grad_x_loglik(x, th, Siginv):
+    """gaussian.py:17-20: (M, S, d)"""
+    x = np.atleast_2d(x)
+    th = np.atleast_2d(th)
+    return th.dot(Siginv)[np.newaxis, :, :] - x.dot(Siginv)[:, np.newaxis, :]
+

@@ -48,9 +48,11 @@ def import_reference():
     import bayesiancoresets.coreset.bcores as bcores
     import bayesiancoresets.coreset.sparsevi as sparsevi
     import bayesiancoresets.coreset.projector as projector
+    import bayesiancoresets.coreset.bpsvi as bpsvi
+    import bayesiancoresets.coreset.sampling as csampling
     import model_linreg, model_neurlinr, model_lr, gaussian
     return types.SimpleNamespace(opt=opt, snnls=snnls, hilbert=hilbert, bcores=bcores, sparsevi=sparsevi,
-                                 projector=projector, linreg=model_linreg, neurlinr=model_neurlinr,
+                                 projector=projector, bpsvi=bpsvi, csampling=csampling, linreg=model_linreg, neurlinr=model_neurlinr,
                                  lr=model_lr, gaussian=gaussian)
 
 
@@ -753,6 +755,212 @@ def f15_learn_beta():
     save('f15_learn_beta', **out)
 
 
+def f16_bpsvi():
+    """BatchPSVICoreset (bpsvi.py:6-65): pseudo-points initialised by np.random.choice, then `opt_itrs` projected-ADAM
+    steps on (weights, points) whose gradient needs project(data) [K1 + K2] and project(points, grad=True)
+    (projector.py:27-32: the x-gradient tensor, centred over its LAST axis).  Also the three x-gradient formulas
+    themselves (model_linreg.py:12-17, model_lr.py:107-114, gaussian.py:17-20) on seeded inputs."""
+    rng = np.random.RandomState(16)
+    out = {}
+    # ---- formulas
+    M, S, D = 9, 12, 5
+    z = rng.randn(M, D + 1)
+    th = rng.randn(S, D)
+    out['lin_z'], out['lin_th'] = z, th
+    for sg in (1.0, 2.5):
+        out['lin_grad_%g' % sg] = R.linreg.gaussian_grad_x_loglikelihood(z, th, sg)
+    zl = rng.randn(M, D) * 2.
+    zl[0] *= 80.                                   # m = -z.th beyond the branch at 100 on some samples
+    out['log_z'] = zl
+    out['log_grad'] = R.lr.grad_z_log_likelihood(zl, th)
+    A = rng.randn(D, D)
+    Sig = A.dot(A.T) + D * np.eye(D)
+    Siginv = np.linalg.inv(Sig)
+    xg = rng.randn(M, D) * 3.
+    out['gau_x'], out['gau_Siginv'] = xg, Siginv
+    out['gau_grad'] = R.gaussian.gaussian_grad_x_loglikelihood(xg, th, Siginv)
+    # centred as the projector does it
+    prj = R.projector.BlackBoxProjector(lambda n, w, p: th, S, lambda a, b: R.linreg.gaussian_loglikelihood(a, b, 2.5),
+                                        lambda a, b: R.linreg.gaussian_grad_x_loglikelihood(a, b, 2.5))
+    lls, glls = prj.project(z.copy(), grad=True)
+    out['lin_proj_lls'], out['lin_proj_glls'] = lls, glls
+
+    # ---- the coreset, Gaussian location model (the zellner recipe shrunk) and linear regression
+    N, d, Sp = 240, 4, 24
+    Sigm = 50. * np.eye(d)
+    Sinv = np.linalg.inv(Sigm)
+    logdet = np.linalg.slogdet(Sigm)[1]
+    X = np.concatenate((rng.multivariate_normal(np.zeros(d), Sigm, N), rng.multivariate_normal(np.zeros(d) + 15., 0.5 * Sigm, N // 10)))
+    mu0, Sig0inv = np.zeros(d), np.eye(d)
+    Eg = rng.randn(Sp, d)
+
+    def sampler_g(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts = np.zeros(1)
+            pts = np.zeros((1, d))
+        muw, LSigw, _ = R.gaussian.weighted_post(mu0, Sig0inv, Sinv, pts, wts)
+        return muw + Eg.dot(LSigw.T)
+
+    llg = lambda x, t: quiet(R.gaussian.gaussian_loglikelihood, x, t, Sinv, logdet)
+    glg = lambda x, t: R.gaussian.gaussian_grad_x_loglikelihood(x, t, Sinv)
+    out.update(g_X=X, g_E=Eg, g_Siginv=Sinv, g_logdet=np.array(logdet))
+    Dl = 5
+    Xl = rng.randn(300, Dl)
+    yl = Xl.dot(rng.randn(Dl)) + 0.7 * rng.randn(300)
+    Zl = np.hstack((Xl, yl[:, None]))
+    El = rng.randn(Sp, Dl)
+    sigsq = 1.3
+
+    def sampler_l(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts = np.zeros(1)
+            pts = np.zeros((1, Dl + 1))
+        muw, LSigw, _ = R.linreg.weighted_post(np.zeros(Dl), np.eye(Dl), sigsq, pts, wts)
+        return muw + El.dot(LSigw.T)
+
+    lll = lambda a, b: R.linreg.gaussian_loglikelihood(a, b, sigsq)
+    gll = lambda a, b: R.linreg.gaussian_grad_x_loglikelihood(a, b, sigsq)
+    out.update(l_Z=Zl, l_E=El, l_sigsq=np.array(sigsq))
+    for tag, data, smp, ll, gl in (('g', X, sampler_g, llg, glg), ('l', Zl, sampler_l, lll, gll)):
+        for mode, nsub in (('full', None), ('sub', 60)):
+            np.random.seed(160)
+            prj = R.projector.BlackBoxProjector(smp, Sp, ll, gl)
+            alg = R.bpsvi.BatchPSVICoreset(data, prj, opt_itrs=6, n_subsample_opt=nsub,
+                                           step_sched=lambda m: lambda i: 0.5 / (1. + i))
+            for sz in (3, 5):
+                quiet(alg.build, 1, sz)
+                k = '%s_%s_%d' % (tag, mode, sz)
+                out[k + '_wts'], out[k + '_pts'], out[k + '_idcs'] = alg.wts.copy(), alg.pts.copy(), alg.idcs.copy()
+            out['%s_%s_rng_after' % (tag, mode)] = np.array(np.random.rand())
+    save('f16_bpsvi', **out)
+
+
+def f17_uniform_sampling_coreset():
+    """UniformSamplingCoreset (coreset/sampling.py:5-52), the RAND baseline of the drivers: rows, or whole groups, drawn
+    from the global RNG; build(1, m) for growing m as main.py:140-151 calls it, plus a coreset handed initial points."""
+    rng = np.random.RandomState(17)
+    N, d = 60, 3
+    X = rng.randn(N, d)
+    out = dict(X=X)
+    np.random.seed(170)
+    alg = R.csampling.UniformSamplingCoreset(X, wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    alg.cts, alg.ct_idcs = [], []          # 'wts' in kw makes the constructor take the "initialised" branch: same empty lists
+    for m in range(1, 13):
+        alg.build(1, m)
+        w, p, i = alg.get()
+        out['rows_w_%d' % m], out['rows_p_%d' % m], out['rows_i_%d' % m] = w.copy(), p.copy(), i.copy()
+    out['rows_rng_after'] = np.array(np.random.rand())
+    np.random.seed(171)
+    alg = R.csampling.UniformSamplingCoreset(X, wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    alg.build(9, 9)                        # several draws in one call, repeats counted
+    out['rows9_w'], out['rows9_i'] = alg.wts.copy(), alg.idcs.copy()
+    init = np.array([5, 17, 40])
+    np.random.seed(172)
+    alg = R.csampling.UniformSamplingCoreset(X, wts=np.full(3, N / 3.), idcs=init.copy(), pts=X[init].copy())
+    alg.build(4, 7)
+    out['init_idcs'] = init
+    out['init_w'], out['init_i'], out['init_p'] = alg.wts.copy(), alg.idcs.copy(), alg.pts.copy()
+    groups = [list(range(g * 5, g * 5 + 5)) for g in range(N // 5)]
+    out['groups'] = np.array(groups)
+    np.random.seed(173)
+    alg = R.csampling.UniformSamplingCoreset(X, groups=groups, wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    for t in range(4):
+        alg.build(1, 5 * (t + 1))
+        out['grp_w_%d' % t], out['grp_i_%d' % t], out['grp_p_%d' % t] = alg.wts.copy(), alg.idcs.copy(), alg.pts.copy()
+    out['grp_sel'] = np.array(alg.selected_groups)
+    save('f17_uniform_sampling_coreset', **out)
+
+
+def f18_zellner_gaussian_bpsvi_rand():
+    """The rest of the driver's algorithm table (main.py:101-113): BPSVI, RAND, PRIOR on the recipe of F14.  The script
+    builds BPSVI for m = 1..M in a multiprocessing pool (main.py:126-135): every build runs in a forked child that starts
+    from the parent's RNG state, and which child gets which m is up to the scheduler.  Pinned here in the one
+    deterministic reading of that: every m is built from the parent's state at the fork (state restored per m)."""
+    G = R.gaussian
+    out = {}
+    M, opt_itrs, n_subsample_opt, proj_dim, pihat_noise, i0 = 6, 25, 50, 40, 0.75, 0.1
+    N, d = 400, 6
+    for nm in ('BPSVI', 'RAND', 'PRIOR'):
+        tr = 3
+        np.random.seed(tr)
+        mu0, Sig0 = np.zeros(d), np.eye(d)
+        Sig = 500 * np.eye(d)
+        th = np.zeros(d)
+        Sig0inv, Siginv = np.linalg.inv(Sig0), np.linalg.inv(Sig)
+        logdetSig = np.linalg.slogdet(Sig)[1]
+        X = np.random.multivariate_normal(th, Sig, N)
+        mup, LSigp, LSigpInv = G.weighted_post(mu0, Sig0inv, Siginv, X, np.ones(X.shape[0]))
+        Sigp = LSigp.dot(LSigp.T)
+        SigpInv = LSigpInv.dot(LSigpInv.T)
+        Xc = np.concatenate((X, np.random.multivariate_normal(th + 200, 0.5 * Sig, int(N / 50.)),
+                             np.random.multivariate_normal(th + 150, 0.1 * Sig, int(N / 50.)),
+                             np.random.multivariate_normal(th, 10 * Sig, int(N / 10.))))
+        log_likelihood = lambda x, t: quiet(G.gaussian_loglikelihood, x, t, Siginv, logdetSig)
+        grad_log_likelihood = lambda x, t: G.gaussian_grad_x_loglikelihood(x, t, Siginv)
+        beta_likelihood = lambda x, t, beta: G.gaussian_beta_likelihood(x, t, beta, Siginv, logdetSig)
+        grad_beta = lambda x, t, beta: G.gaussian_beta_gradient(x, t, beta, Siginv, logdetSig)
+        sampler_optimal = lambda n, w, pts: mup + np.random.randn(n, mup.shape[0]).dot(LSigp.T)
+        prj_optimal = R.projector.BlackBoxProjector(sampler_optimal, proj_dim, log_likelihood, grad_log_likelihood)
+        U = np.random.rand()
+        muhat = U * mup + (1. - U) * mu0
+        Sighat = U * Sigp + (1. - U) * Sig0
+        muhat += pihat_noise * np.sqrt((muhat ** 2).sum()) * np.random.randn(muhat.shape[0])
+        Sighat *= np.exp(-2 * pihat_noise * np.fabs(np.random.randn()))
+        LSighat = np.linalg.cholesky(Sighat)
+        sampler_realistic = lambda n, w, pts: mup + np.random.randn(n, mup.shape[0]).dot(LSighat.T)
+        prj_realistic = R.projector.BlackBoxProjector(sampler_realistic, proj_dim, log_likelihood, grad_log_likelihood)
+
+        def sampler_w(sz, wts, pts):
+            if pts.shape[0] == 0:
+                wts = np.zeros(1)
+                pts = np.zeros((1, Xc.shape[1]))
+            muw, LSigw, _ = G.weighted_post(mu0, Sig0inv, Siginv, pts, wts)
+            return muw + np.random.randn(sz, muw.shape[0]).dot(LSigw.T)
+
+        prj_w = R.projector.BlackBoxProjector(sampler_w, proj_dim, log_likelihood, grad_log_likelihood)
+        prj_bw = R.projector.BetaBlackBoxProjector(sampler_w, proj_dim, beta_likelihood, log_likelihood, grad_beta)
+        fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+        w = [np.array([0.])]
+        p = [np.zeros((1, Xc.shape[1]))]
+        if nm == 'BPSVI':
+            alg = R.bpsvi.BatchPSVICoreset(Xc, prj_w, opt_itrs=opt_itrs, n_subsample_opt=n_subsample_opt,
+                                           step_sched=lambda m: lambda i: i0 / (1. + i), **fresh())
+            state = np.random.get_state()
+            for m in range(1, M + 1):
+                np.random.set_state(state)              # a forked child starts from the parent's stream
+                quiet(alg.build, 1, m)
+                got = alg.get()
+                w.append(got[0].copy())
+                p.append(got[1].copy())
+                out['BPSVI_idcs_%d' % m] = got[2].copy()
+            np.random.set_state(state)                  # ... and the parent's own stream never moved
+        elif nm == 'RAND':
+            alg = R.csampling.UniformSamplingCoreset(Xc, **fresh())
+            for m in range(1, M + 1):
+                alg.build(1, m)
+                got = alg.get()
+                w.append(got[0].copy())
+                p.append(got[1].copy())
+                out['RAND_idcs_%d' % m] = got[2].copy()
+        else:
+            for m in range(1, M + 1):
+                w.append(np.array([0.]))
+                p.append(np.zeros((1, Xc.shape[1])))    # (main.py:151 writes Y.shape[0], an undefined name: PRIOR cannot run as shipped)
+        rklw, fklw = np.zeros(M + 1), np.zeros(M + 1)
+        for m in range(M + 1):
+            muw, LSigw, LSigwInv = G.weighted_post(mu0, Sig0inv, Siginv, p[m], w[m])
+            Sigw = LSigw.dot(LSigw.T)
+            rklw[m] = G.gaussian_KL(muw, Sigw, mup, SigpInv)
+            fklw[m] = G.gaussian_KL(mup, Sigp, muw, LSigwInv.dot(LSigwInv.T))
+        out[nm + '_rkl'], out[nm + '_fkl'] = rklw, fklw
+        for m in range(M + 1):
+            out['%s_w_%d' % (nm, m)] = w[m]
+            out['%s_p_%d' % (nm, m)] = p[m]
+        out[nm + '_rng_after'] = np.array(np.random.rand())
+    out['params'] = np.array([N, d, M, opt_itrs, n_subsample_opt, 0, proj_dim, 3])
+    save('f18_zellner_gaussian_bpsvi_rand', **out)
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])
     if only:
@@ -774,3 +982,6 @@ if __name__ == '__main__':
     f13_greedy_vi_zero_rows()
     f14_zellner_gaussian_driver()
     f15_learn_beta()
+    f16_bpsvi()
+    f17_uniform_sampling_coreset()
+    f18_zellner_gaussian_bpsvi_rand()

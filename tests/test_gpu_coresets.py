@@ -239,6 +239,25 @@ def test_f14_example_driver_matches_reference_script(bc, nm):
     assert np.random.rand() == float(g[nm + '_rng_after'])
 
 
+@pytest.mark.parametrize('nm', ['BPSVI', 'RAND', 'PRIOR'])
+def test_f18_example_driver_bpsvi_rand_prior(bc, nm):
+    """the rest of the driver's algorithm table (main.py:101-113) against golden F18: pseudo-coreset points and weights
+    of BatchPSVICoreset (device K1/K2 + bc_project_grad_x), the RAND baseline, the PRIOR row; KL traces; RNG position"""
+    g = load_golden('f18_zellner_gaussian_bpsvi_rand')
+    N, d, M_, opt_itrs, n_sub_opt, _, proj_dim, tr = [int(v) for v in g['params']]
+    ex = _load_example()
+    res = ex.run(nm, tr, N=N, d=d, M=M_, opt_itrs=opt_itrs, n_subsample_opt=n_sub_opt, n_subsample_select=150,
+                 proj_dim=proj_dim, verbose=False)
+    for m in range(M_ + 1):
+        if m > 0 and nm != 'PRIOR':
+            np.testing.assert_array_equal(res['idcs'][m], g['%s_idcs_%d' % (nm, m)])
+        np.testing.assert_allclose(res['w'][m], g['%s_w_%d' % (nm, m)], rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(res['p'][m], g['%s_p_%d' % (nm, m)], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(res['rkl'], g[nm + '_rkl'], rtol=1e-5)
+    np.testing.assert_allclose(res['fkl'], g[nm + '_fkl'], rtol=1e-5)
+    assert np.random.rand() == float(g[nm + '_rng_after'])
+
+
 @pytest.mark.parametrize('tag,nsub', [('full', None), ('sub', 80)])
 @pytest.mark.parametrize('projector', ['device', 'blackbox'])
 def test_f15_learn_beta(bc, tag, nsub, projector):

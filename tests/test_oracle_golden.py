@@ -384,13 +384,23 @@ def run_zellner_gaussian_oracle(nm, params):
     elif nm == 'SVI':
         alg = C.RefGreedyVI(Xc, lambda p, t: C.project(ll, p, t), sampler_w, opt_itrs, sched,
                             n_subsample_select=n_sub_sel, n_subsample_opt=n_sub_opt, size_check_always=True)
+    elif nm == 'BPSVI':
+        alg = C.RefBatchPSVI(Xc, ll, lambda x, t: M.gauss_grad_x_loglik(x, t, Siginv), sampler_w, opt_itrs,
+                             n_subsample_opt=n_sub_opt, step_sched=lambda m: sched,
+                             projector_draw=False)                                 # (prj_w's constructor draw was made above)
     else:
         alg = C.RefHilbert(Xc, ll, th_opt if nm == 'GIGAO' else th_real)
     w, p, idl = [np.array([0.])], [np.zeros((1, d))], [np.zeros(0, dtype=np.int64)]
+    fork_state = np.random.get_state()
     for m in range(1, M_ + 1):
+        if nm == 'BPSVI':
+            np.random.set_state(fork_state)                                        # main.py:126-135: forked pool children
         alg.build(1, m)
         got = alg.get()
         w.append(got[0].copy()); p.append(got[1].copy()); idl.append(got[2].copy())
+    if nm == 'BPSVI':
+        np.random.set_state(fork_state)
+        run_zellner_gaussian_oracle.last_points = p
     rkl, fkl = np.zeros(M_ + 1), np.zeros(M_ + 1)
     for m in range(M_ + 1):
         muw, LSigw, LSigwInv = M.gauss_weighted_post(mu0, Sig0inv, Siginv, p[m], w[m])
@@ -437,3 +447,66 @@ def test_f15_learn_beta(tag, nsub):
         np.testing.assert_allclose(alg.wts, g['%s_init_allw_%d' % (tag, m)], rtol=1e-10)
         np.testing.assert_allclose(alg.beta, float(g['%s_init_beta_%d' % (tag, m)]), rtol=1e-10)
     assert np.random.rand() == float(g['%s_rng_after' % tag])
+
+
+def test_f16_x_gradient_formulas():
+    g = load_golden('f16_bpsvi')
+    z, th = g['lin_z'], g['lin_th']
+    for sg in (1.0, 2.5):
+        np.testing.assert_allclose(M.linreg_grad_x_loglik(z, th, sg), g['lin_grad_%g' % sg], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(M.logistic_grad_z_loglik(g['log_z'], th), g['log_grad'], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(M.gauss_grad_x_loglik(g['gau_x'], th, g['gau_Siginv']), g['gau_grad'], rtol=1e-13, atol=1e-15)
+    lls, glls = C.project_grad(lambda a, b: M.linreg_loglik(a, b, 2.5), lambda a, b: M.linreg_grad_x_loglik(a, b, 2.5), z, th)
+    np.testing.assert_allclose(lls, g['lin_proj_lls'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(glls, g['lin_proj_glls'], rtol=1e-12, atol=1e-13)
+    assert np.abs(glls.mean(axis=2)).max() < 1e-13          # centred over the coordinate axis, as the reference writes it
+
+
+def f16_problem(g, tag):
+    """(data, loglik, grad_loglik, sampler(wts, pts)) of fixture F16's two models"""
+    if tag == 'g':
+        X, E, Si, ld = g['g_X'], g['g_E'], g['g_Siginv'], float(g['g_logdet'])
+        d = X.shape[1]
+        return (X, lambda x, t: M.gauss_loglik(x, t, Si, ld), lambda x, t: M.gauss_grad_x_loglik(x, t, Si),
+                _gauss_sampler(np.zeros(d), np.eye(d), Si, d, E.shape[0], E=E))
+    Z, E, sg = g['l_Z'], g['l_E'], float(g['l_sigsq'])
+    D = Z.shape[1] - 1
+
+    def sampler(wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, D + 1))
+        muw, LSigw, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), sg, pts, wts)
+        return muw + E.dot(LSigw.T)
+    return Z, lambda a, b: M.linreg_loglik(a, b, sg), lambda a, b: M.linreg_grad_x_loglik(a, b, sg), sampler
+
+
+@pytest.mark.parametrize('tag', ['g', 'l'])
+@pytest.mark.parametrize('mode,nsub', [('full', None), ('sub', 60)])
+def test_f16_batch_psvi(tag, mode, nsub):
+    g = load_golden('f16_bpsvi')
+    data, ll, gl, sampler = f16_problem(g, tag)
+    np.random.seed(160)
+    alg = C.RefBatchPSVI(data, ll, gl, sampler, 6, n_subsample_opt=nsub, step_sched=lambda m: lambda i: 0.5 / (1. + i))
+    for sz in (3, 5):
+        alg.build(1, sz)
+        k = '%s_%s_%d' % (tag, mode, sz)
+        np.testing.assert_array_equal(alg.idcs, g[k + '_idcs'])
+        np.testing.assert_allclose(alg.wts, g[k + '_wts'], rtol=1e-10)
+        np.testing.assert_allclose(alg.pts, g[k + '_pts'], rtol=1e-9, atol=1e-11)
+    assert np.random.rand() == float(g['%s_%s_rng_after' % (tag, mode)])
+
+
+def test_f18_zellner_gaussian_bpsvi():
+    """the driver's BPSVI row on the oracle's RefBatchPSVI (F18; RAND is a host class of the product, pinned by F17 and
+    tests/test_sampling_coreset_cpu.py)"""
+    g = load_golden('f18_zellner_gaussian_bpsvi_rand')
+    w, idl, rkl, fkl, rng_after = run_zellner_gaussian_oracle('BPSVI', g['params'])
+    p = run_zellner_gaussian_oracle.last_points
+    for m in range(1, len(w)):
+        np.testing.assert_array_equal(idl[m], g['BPSVI_idcs_%d' % m])
+        np.testing.assert_allclose(w[m], g['BPSVI_w_%d' % m], rtol=1e-9)
+        np.testing.assert_allclose(p[m], g['BPSVI_p_%d' % m], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(rkl, g['BPSVI_rkl'], rtol=1e-7)
+    np.testing.assert_allclose(fkl, g['BPSVI_fkl'], rtol=1e-7)
+    assert rng_after == float(g['BPSVI_rng_after'])
+
