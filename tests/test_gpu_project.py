@@ -477,3 +477,34 @@ def test_device_tolerance_follows_util_tol(bc):
         assert s.reached_numeric_limit and s.size() == 3
     finally:
         bc.util.set_tolerance(old)
+
+
+@pytest.mark.parametrize('S', [97, 100])
+def test_nearly_constant_rows_are_not_flattened(bc, S):
+    """K1 (96 < S <= 100) finds constant rows AFTER centring: a vanishing norm makes a row a suspect, an exact check on
+    the centred values decides.  Rows whose S values differ only in their last digits are suspects too and must come
+    out untouched: centred with their own mean, not constant, norm > 0 -- next to truly constant rows (which take
+    NumPy's rounded mean) and ordinary ones in the same tile and wave."""
+    rng = np.random.RandomState(S)
+    n, d = 700, 7
+    Z = rng.randn(n, d + 1)
+    th = rng.randn(S, d)
+    near = np.arange(5, n, 37)
+    Z[near, :d] = 1e-13 * rng.randn(near.size, d)              # spread of f over the samples ~1e-13 of its size
+    Z[near, d] = 2.                                            # (y away from 0: the spread is 2 y x.th / (2 sigsq))
+    const = np.arange(11, n, 53)
+    Z[const, :d] = 0.
+    phi = bc.DeviceProjector(fixed(th), S, bc.likelihoods.LinearRegression(1.0)).project(Z)
+    dev, nrm = phi.to_host(), phi.norms()
+    ref = M.linreg_loglik(Z, th, 1.0)
+    c = ref[:, 0].copy()
+    ref -= ref.mean(axis=1)[:, None]
+    plain = np.setdiff1d(np.arange(n), np.concatenate((near, const)))
+    np.testing.assert_allclose(dev[plain], ref[plain], rtol=0., atol=1e-11 * (1. + np.abs(ref).max()))
+    for i in const:
+        np.testing.assert_array_equal(dev[i], ref[i])          # the reference's bits (pairwise mean of S copies of c)
+    for i in near:
+        assert not np.all(dev[i] == dev[i, 0])                  # still a row with structure
+        assert np.abs(dev[i] - ref[i]).max() <= 8 * np.spacing(abs(c[i]))        # the means may differ by an ulp or two of c
+        assert np.abs(dev[i]).max() > 50 * np.spacing(abs(c[i]))                 # ... which is far below the row's own size
+        assert nrm[i] > 0. and abs(nrm[i] - np.sqrt((dev[i] ** 2).sum())) <= 1e-12 * nrm[i]
