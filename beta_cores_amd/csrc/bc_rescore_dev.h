@@ -71,6 +71,10 @@ struct RescoreArgs {
   int tile_rounds;           // tiles per sweep wave = ceil(ptiles / (4 * nblk)): block b swept tiles 4b+w + 4*nblk*i
 };
 
+#ifndef FSTAMP      // diagnostic builds define it before including this header (bc_snnls.hip, -DBC_FIN_STAMPS)
+#define FSTAMP(i) do { } while (0)
+#endif
+
 // same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
 template <int MODE>
 __device__ __forceinline__ double bc_exact_score(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
@@ -110,25 +114,25 @@ __device__ __forceinline__ double bc_exact_score(const double* __restrict__ tile
   return a0 / nr / post_div;
 }
 
-// The same score, computed by a whole wave for ONE row: the lanes fetch the row (and the sweep vectors) with one
-// round of independent loads -- lane l holds elements l, l+64, ... -- and then every lane runs the identical
-// sequential fma chain on broadcast values (v_readlane), so the result has the bits of bc_exact_score / k_sweep.
-// With a handful of candidates this replaces ~4 dependent load batches per candidate by one.
 // The same score, computed by a whole wave for ONE row: the lanes fetch the row and the sweep vectors with one
-// round of independent loads -- lane l holds elements l, l+64, ... --, park them in a wave-private LDS strip
-// and every lane then runs the identical sequential fma chain on broadcast LDS reads, so the result has the
-// bits of bc_exact_score / k_sweep.  With a handful of candidates this replaces four dependent load batches and
-// a one-lane chain by one round trip and a pipelined chain.  (Wave-private strip: LDS serves a wave's requests in
-// order, the wavefront-scope fences only keep the compiler from reordering.)
+// round of independent loads -- lane l holds elements l, l+64, ... --, park them in a wave-private LDS strip and
+// then run the sequential fma chains on broadcast LDS reads, so the result has the bits of bc_exact_score / k_sweep.
+// The strip holds PAIRS: half A [k] = (x_k, v0_k), half B [k] = (x_k, v1_k); lanes 0-31 run the first chain on half A,
+// lanes 32-63 the second one on half B -- one 16-byte LDS read and one fma per step and lane (three 8-byte reads and
+// two fmas when every lane ran both chains: the chain was LDS-issue bound, ~5k of the 10k cycles of this phase).
+// With a handful of candidates this replaces four dependent load batches and a one-lane chain by one round trip and
+// a pipelined chain.  (Wave-private strip: LDS serves a wave's requests in order, the wavefront-scope fences only
+// keep the compiler from reordering.)
 template <int MODE>
 __device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
-                                                      int S, double nr, double post_div, double* strip /* [3][256] */) {
+                                                      int S, double nr, double post_div, double* strip /* [2][256][2] */,
+                                                      double* rowcopy = nullptr /* [S]: the row, if the caller wants it */) {
   const int lane = threadIdx.x & 63;
   const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
-  double* sx = strip;
-  double* sa = strip + 256;
-  double* sb = strip + 512;
-  double a0 = 0., a1 = 0.;
+  double2* sA = reinterpret_cast<double2*>(strip);
+  double2* sB = sA + 256;
+  const double2* mine = (MODE == 0 && lane >= 32) ? sB : sA;
+  double acc = 0.;
   for (int base = 0; base < S; base += 256) {
     double x[4], vx[4], vy[4];
 #pragma unroll
@@ -147,27 +151,28 @@ __device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous block's reads come first
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      sx[64 * e + lane] = x[e];
-      sa[64 * e + lane] = vx[e];
-      if (MODE == 0) sb[64 * e + lane] = vy[e];
+      sA[64 * e + lane] = make_double2(x[e], vx[e]);
+      if (MODE == 0) sB[64 * e + lane] = make_double2(x[e], vy[e]);
+      if (rowcopy && base + 64 * e + lane < S) rowcopy[base + 64 * e + lane] = x[e];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    FSTAMP(14);
     const int n = (S - base) < 256 ? (S - base) : 256;
 #pragma unroll 8
     for (int kk = 0; kk < n; ++kk) {
-      const double xk = sx[kk];
-      a0 = fma(xk, sa[kk], a0);
-      if (MODE == 0) a1 = fma(xk, sb[kk], a1);
+      const double2 xv = mine[kk];
+      acc = fma(xv.x, xv.y, acc);
     }
   }
   if (MODE == 0) {
+    const double a0 = bc_readlane(acc, 0), a1 = bc_readlane(acc, 32);
     const double s0 = a0 / nr, s1 = a1 / nr;
     const bool ok = (s1 > -1. + 1e-14) && (1. - s1 * s1 > 0.);
     const double den = ok ? sqrt(1. - s1 * s1) : INFINITY;
     return s0 / den;
   }
-  return a0 / nr / post_div;
+  return acc / nr / post_div;
 }
 
 // one plane of the fp32 chain for a thread's two rows (k_rescore's recomputation of a candidate tile)
@@ -192,16 +197,40 @@ __device__ __forceinline__ void bc_rs_accumulate(bc_h2 x, const double* __restri
 #ifndef FSTAMP
 #define FSTAMP(i) do { } while (0)
 #endif
+// The sweep blocks' bounds a thread of the rescoring block looks at (threads 0..255, blocks t, t+256, ...): a caller
+// with other loads to wait for requests them in the same round (bc_rescore_prefetch) instead of paying a round trip
+// of their own at the start of the rescoring.
+struct RescorePre {
+  double l[4];
+  float u[4];
+};
+
+__device__ __forceinline__ RescorePre bc_rescore_prefetch(const RescoreArgs& a) {
+  RescorePre p;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = threadIdx.x + q * 256;
+    p.l[q] = -INFINITY;
+    p.u[q] = -INFINITY;
+    if (threadIdx.x < 256 && i < a.nblk) {
+      p.l[q] = a.blk_l[i];
+      p.u[q] = a.blk_u[i];
+    }
+  }
+  return p;
+}
+
 template <int MODE>
-__device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* __restrict__ rec) {
+__device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* __restrict__ rec, const RescorePre* pre = nullptr) {
   __shared__ double sv[16];
   __shared__ long long si[16];
   __shared__ long long win;
-  __shared__ int cnt, tcnt, bcnt;
+  __shared__ int cnt, tcnt, bcnt, ocnt;
   __shared__ int tlist[1024];
   __shared__ int blist[64];                  // sweep blocks whose maximum upper bound reaches Lmax
   __shared__ long long scand[32];            // the first candidates, kept on chip (the usual case has 1-3)
-  __shared__ double strips[4][3 * 256];      // bc_exact_score_wave: one strip per scoring wave
+  __shared__ __attribute__((aligned(16))) double strips[4][4 * 256];   // bc_exact_score_wave: one strip per scoring wave
+  __shared__ double currow[4][256];          // ... and the row it is scoring
   __shared__ double bestrow[4][256];         // the row of each scoring wave's best candidate (S <= 256): the record's column
   __shared__ double snorm[16];
   __shared__ int swave;
@@ -209,19 +238,18 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
   bool overflow = false;
   double lmax = -INFINITY;
   float bu[4];                               // this thread's share of the block upper bounds (nblk <= 1024)
+  {
+    const RescorePre mine = pre ? *pre : bc_rescore_prefetch(a);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = threadIdx.x + q * 256;
-    bu[q] = -INFINITY;
-    if (threadIdx.x < 256 && i < a.nblk) {
-      lmax = fmax(lmax, a.blk_l[i]);
-      bu[q] = a.blk_u[i];
+    for (int q = 0; q < 4; ++q) {
+      lmax = fmax(lmax, mine.l[q]);             // (-inf where there is no block: fmax ignores it, a NaN bound too -- as before)
+      bu[q] = mine.u[q];
     }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
   if (lane == 0) sv[wave] = lmax;
-  if (threadIdx.x == 0) { cnt = 0; tcnt = 0; bcnt = 0; }
+  if (threadIdx.x == 0) { cnt = 0; tcnt = 0; bcnt = 0; ocnt = 0; }
   __syncthreads();
   lmax = sv[0];
   for (int w = 1; w < nw; ++w) lmax = fmax(lmax, sv[w]);
@@ -236,7 +264,55 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
     }
   __syncthreads();
   const int nbl = bcnt;
-  if (nbl <= 64) {
+  bool merged = false;                       // int8 mirror, few blocks in play: phases B1 and B2 in one round of loads
+  if (nbl <= 64 && a.tile_cand) {
+    merged = true;
+    const int per = 4 * a.tile_rounds, total = nbl * per;
+    for (int i0 = 0; i0 < total; i0 += 4 * blockDim.x) {
+      float tu[4];
+      long long tt[4];
+      int nc[4];
+      float2 prs[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * blockDim.x + threadIdx.x;
+        tt[u] = -1;
+        tu[u] = -INFINITY;
+        nc[u] = 0;
+        if (idx < total) {
+          const int b = blist[idx / per], q = idx % per;
+          const long long t = (long long)b * 4 + (q & 3) + (long long)(q >> 2) * 4 * a.nblk;
+          if (t < a.ptiles) {
+            tt[u] = t;
+            tu[u] = a.tile_u[t];
+            nc[u] = a.tile_ncand[t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) prs[u][i] = a.tile_cand[t * 4 + i];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tt[u] >= 0 && tu[u] != -INFINITY && (double)tu[u] >= lmax) {
+          atomicAdd(&tcnt, 1);
+          if (nc[u] <= 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float2 pr = prs[u][i];
+              if (i < nc[u] && (double)pr.x >= lmax) {
+                const int slot = atomicAdd(&cnt, 1);
+                const long long row = tt[u] * a.ptile + (int)pr.y;
+                if (slot < a.cap) a.cand[slot] = row;
+                if (slot < 32) scand[slot] = row;
+              }
+            }
+          } else {
+            const int o = atomicAdd(&ocnt, 1);   // more than four local candidates: the tile hands over all its rows
+            if (o < 64) tlist[o] = (int)tt[u];
+          }
+        }
+    }
+  } else if (nbl <= 64) {
     const int per = 4 * a.tile_rounds, total = nbl * per;
     for (int i0 = 0; i0 < total; i0 += 8 * blockDim.x) {
       float tu[8];
@@ -279,10 +355,26 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
   __syncthreads();
   FSTAMP(11);
   const int ntl = tcnt;
-  if (threadIdx.x == 0) bcnt = 0;            // reused by the int8 branch below
+  if (threadIdx.x == 0 && !merged) bcnt = 0; // reused by the int8 branch below
   __syncthreads();
   overflow = ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
-  if (!overflow && a.tile_cand) {
+  if (merged) {
+    // the pairs were consumed with the tile maxima; what is left are the tiles that hand over all of their rows
+    const int no = ocnt;
+    overflow = overflow || no > 64;
+    if (!overflow) {
+      for (int o = 0; o < no; ++o) {
+        const long long row = (long long)tlist[o] * a.ptile + threadIdx.x;      // ptile == 256 rows: threads 0..255
+        if ((int)threadIdx.x < a.ptile && row < n_rows && a.norms[row] != 0.) {
+          const int slot = atomicAdd(&cnt, 1);
+          if (slot < a.cap) a.cand[slot] = row;
+          if (slot < 32) scand[slot] = row;
+        }
+      }
+      __syncthreads();
+      overflow = cnt > a.cap;
+    }
+  } else if (!overflow && a.tile_cand) {
     // phase B2 (int8 mirror): the pairs the sweep left for each such tile; a tile with more than four local
     // candidates hands over all of its rows
     for (int q = threadIdx.x; q < ntl; q += blockDim.x) {
@@ -386,7 +478,7 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
     __syncthreads();
     overflow = cnt > a.cap;
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == blockDim.x - 1) {         // (the last wave scores no candidate: its read-modify-writes delay nobody)
     a.ctrl[1] = overflow ? 1 : 0;              // observable: the last launch overflowed
     if (overflow) a.ctrl[3] += 1;              // ... and how often since creation
     unsigned long long* st = reinterpret_cast<unsigned long long*>(a.ctrl + 4);   // diagnostics: sweeps, candidates rescored
@@ -406,12 +498,12 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
       for (int j = wave; j < count; j += 4) {
         const long long r = scand[j];
         const double nr = a.norms[r];
-        const double sc = bc_exact_score_wave<MODE>(a.tiles, a.v, r, a.s, nr, a.post_div, strips[wave]);
+        const double sc = bc_exact_score_wave<MODE>(a.tiles, a.v, r, a.s, nr, a.post_div, strips[wave], keep_rows ? currow[wave] : nullptr);
         const long long gi = a.row_offset + r;
         if (bc_better(sc, gi, bv, bi)) {
           bv = sc; bi = gi; bnorm = nr;
-          if (keep_rows) {                               // (wave-uniform branch; the strip still holds the row)
-            for (int k = lane; k < a.s; k += BC_WAVE) bestrow[wave][k] = strips[wave][k];
+          if (keep_rows) {                               // (wave-uniform branch; currow still holds the row)
+            for (int k = lane; k < a.s; k += BC_WAVE) bestrow[wave][k] = currow[wave][k];
           }
         }
       }
@@ -430,7 +522,8 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
   __syncthreads();
   if (threadIdx.x == 0) {
     int bw = 0;
-    for (int w = 1; w < nw; ++w)
+    const int nsc = (count <= 32) ? (nw < 4 ? nw : 4) : nw;      // a handful of candidates: only waves 0..3 scored
+    for (int w = 1; w < nsc; ++w)
       if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; bw = w; }
     const bool valid = bi != LLONG_MAX;
     rec[0] = bv;

@@ -103,6 +103,11 @@ struct bc_snnls {
   double* val2 = nullptr;
   double* cols2 = nullptr;
   double* colnorm2 = nullptr;
+  // The small state arrays (st, b, bn, xw, xw_prev, v, xf, the send record) live in ONE allocation and the active
+  // lists (both buffer sets) in another: the single-block step kernel starts every greedy step with cold TLBs (a 1 GB
+  // sweep ran in between), and its first round of loads paid one page-table walk per separately allocated array.
+  void* state_slab = nullptr;
+  void* list_slab = nullptr;
   bc_pref* pref = nullptr;         // reduced-precision pre-filter of the sweep (large shards), see bc_prefilter.hip
   double* cand_send = nullptr;     // this rank's candidate record (S + 4 doubles)
   bool cand_send_owned = true;     // false once the host bound its own exchange buffers
@@ -708,6 +713,8 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
     l_val[j] = P0.val[j];
     l_idx[j] = P0.idx[j];
   }
+  RescorePre pre;
+  if (RS) pre = bc_rescore_prefetch(ra);             // the sweep blocks' bounds travel with the other up-front loads
   const int G = blockDim.x / s;
   const int g = threadIdx.x / s, kk = threadIdx.x - g * s;
   double c16[BC_PF_NC];
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
   if (S.reached_limit || S.pf_overflow) return;      // snnls.py:32-34 / :73-74; a pending exact redo consumes nothing
   bool pf_ovf = false;
   if (RS) {
-    if (!S.skip) pf_ovf = bc_rescore_block<(ALG == BC_ALG_GIGA) ? 0 : 1>(ra, n_rows, l_rec) != 0;
+    if (!S.skip) pf_ovf = bc_rescore_block<(ALG == BC_ALG_GIGA) ? 0 : 1>(ra, n_rows, l_rec, &pre) != 0;
     __syncthreads();
     FSTAMP(2);
   } else if (!P.fuse_winner && !S.select_fail) {
@@ -978,9 +985,8 @@ static int fetch_state(bc_snnls* h, SnnlsState* out) {
 }
 
 static void free_lists(bc_snnls* h) {
-  void* ptrs[] = {h->d.idx, h->d.val, h->d.prev_val, h->d.cols, h->d.colnorm, h->idx2, h->val2, h->cols2, h->colnorm2};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  if (h->list_slab) (void)hipFree(h->list_slab);
+  h->list_slab = nullptr;
   h->d.idx = h->idx2 = nullptr;
   h->d.val = h->val2 = h->d.prev_val = nullptr;
   h->d.cols = h->cols2 = nullptr;
@@ -992,20 +998,22 @@ static int ensure_capacity(bc_snnls* h, long long need) {
   bc_ctx* ctx = h->ctx;
   long long ncap = std::max<long long>(need, std::max<long long>(256, h->d.cap * 2));
   const int s = h->d.s;
-  long long *idx = nullptr, *idx2 = nullptr;
-  double *val = nullptr, *pv = nullptr, *cols = nullptr, *cn = nullptr, *val2 = nullptr, *cols2 = nullptr, *cn2 = nullptr;
-  hipError_t e = hipSuccess;
-  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
-  A((void**)&idx, ncap * sizeof(long long));
-  A((void**)&idx2, ncap * sizeof(long long));
-  A((void**)&val, ncap * sizeof(double));
-  A((void**)&pv, ncap * sizeof(double));
-  A((void**)&val2, ncap * sizeof(double));
-  A((void**)&cn, ncap * sizeof(double));
-  A((void**)&cn2, ncap * sizeof(double));
-  A((void**)&cols, (size_t)ncap * s * sizeof(double));
-  A((void**)&cols2, (size_t)ncap * s * sizeof(double));
+  // one slab: [idx | val | prev_val | colnorm | cols] of the live set first (what the step kernel reads), then the
+  // second set (bc_snnls_set_weights rebuilds into it and swaps)
+  const size_t n8 = (size_t)ncap * 8, ncols = (size_t)ncap * s * 8;
+  const size_t total = 7 * n8 + 2 * ncols;
+  char* slab = nullptr;
+  hipError_t e = hipMalloc((void**)&slab, total);
   if (e != hipSuccess) return bc_hip_fail(e, "hipMalloc(active list)", __FILE__, __LINE__);
+  long long* idx = (long long*)slab;
+  double* val = (double*)(slab + n8);
+  double* pv = (double*)(slab + 2 * n8);
+  double* cn = (double*)(slab + 3 * n8);
+  double* cols = (double*)(slab + 4 * n8);
+  long long* idx2 = (long long*)(slab + 4 * n8 + ncols);
+  double* val2 = (double*)(slab + 5 * n8 + ncols);
+  double* cn2 = (double*)(slab + 6 * n8 + ncols);
+  double* cols2 = (double*)(slab + 7 * n8 + ncols);
   if (h->d.cap > 0) {
     BC_HIP(hipStreamSynchronize(ctx->stream));
     BC_HIP(hipMemcpy(idx, h->d.idx, h->d.cap * sizeof(long long), hipMemcpyDeviceToDevice));
@@ -1014,6 +1022,7 @@ static int ensure_capacity(bc_snnls* h, long long need) {
     BC_HIP(hipMemcpy(cols, h->d.cols, (size_t)h->d.cap * s * sizeof(double), hipMemcpyDeviceToDevice));
   }
   free_lists(h);
+  h->list_slab = slab;
   h->d.idx = idx; h->idx2 = idx2;
   h->d.val = val; h->d.prev_val = pv; h->val2 = val2;
   h->d.colnorm = cn; h->colnorm2 = cn2;
@@ -1048,8 +1057,7 @@ extern "C" int bc_snnls_destroy(bc_snnls* h) {
   bc_pref_destroy(h->pref);
   h->pref = nullptr;
   free_lists(h);
-  void* ptrs[] = {h->d.st, h->d.b, h->d.bn, h->d.xw, h->d.xw_prev, h->d.v, h->d.xf, h->cand_all_owned,
-                  h->cand_send_owned ? h->cand_send : nullptr, h->d.tr_f, h->d.tr_status, h->d.tr_err};
+  void* ptrs[] = {h->state_slab, h->cand_all_owned, h->d.tr_f, h->d.tr_status, h->d.tr_err};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -1104,18 +1112,28 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   d.norms = phi->norms;
   d.n_rows = phi->n_rows;
   d.row_offset = phi->row_offset;
+  {
+    // one slab (see bc_snnls::state_slab): st | b | bn | xw | xw_prev | xf | send record | v (zero tail: the fp16
+    // sweep reads whole plane batches), every piece 256-byte aligned
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_st = 0, o_b = up(sizeof(SnnlsState)), o_bn = o_b + up(s * 8), o_xw = o_bn + up(s * 8), o_xwp = o_xw + up(s * 8),
+                 o_xf = o_xwp + up(s * 8), o_rec = o_xf + up(s * 8), o_v = o_rec + up(d.rec_len * 8),
+                 total = o_v + up(2 * (s + BC_V_PAD) * 8);
+    char* slab = nullptr;
+    hipError_t e0 = hipMalloc((void**)&slab, total);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(slab, 0, total, ctx->stream);
+    if (e0 != hipSuccess) { if (slab) (void)hipFree(slab); bc_snnls_destroy(h); return bc_hip_fail(e0, "hipMalloc(snnls)", __FILE__, __LINE__); }
+    h->state_slab = slab;
+    d.st = (SnnlsState*)(slab + o_st);
+    d.b = (double*)(slab + o_b);
+    d.bn = (double*)(slab + o_bn);
+    d.xw = (double*)(slab + o_xw);
+    d.xw_prev = (double*)(slab + o_xwp);
+    d.xf = (double*)(slab + o_xf);
+    h->cand_send = (double*)(slab + o_rec);
+    d.v = (double*)(slab + o_v);
+  }
   hipError_t e = hipSuccess;
-  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
-  A((void**)&d.st, sizeof(SnnlsState));
-  A((void**)&d.b, s * sizeof(double));
-  A((void**)&d.bn, s * sizeof(double));
-  A((void**)&d.xw, s * sizeof(double));
-  A((void**)&d.xw_prev, s * sizeof(double));
-  A((void**)&d.v, 2 * (s + BC_V_PAD) * sizeof(double));   // zero tail: the fp16 sweep reads whole plane batches
-  if (e == hipSuccess) e = hipMemsetAsync(d.v, 0, 2 * (s + BC_V_PAD) * sizeof(double), ctx->stream);
-  A((void**)&d.xf, s * sizeof(double));
-  A((void**)&h->cand_send, d.rec_len * sizeof(double));
-  if (e != hipSuccess) { bc_snnls_destroy(h); return bc_hip_fail(e, "hipMalloc(snnls)", __FILE__, __LINE__); }
   d.cand_all = h->cand_send;
   rc = ensure_capacity(h, 256);
   if (!rc) rc = ensure_trace(h, 1024);
@@ -1203,8 +1221,7 @@ extern "C" int bc_snnls_bind_exchange(bc_snnls* h, int world, void* cand_send_de
   }
   BC_HIP(hipStreamSynchronize(h->ctx->stream));
   if (cand_send_dev && cand_all_dev) {
-    if (h->cand_send_owned && h->cand_send) (void)hipFree(h->cand_send);
-    h->cand_send = (double*)cand_send_dev;      // borrowed (typically torch tensors)
+    h->cand_send = (double*)cand_send_dev;      // borrowed (typically torch tensors); the own record stays in the state slab
     h->cand_send_owned = false;
     h->d.cand_all = (const double*)cand_all_dev;
   } else {
