@@ -263,9 +263,15 @@ extern "C" int bc_data_destroy(bc_data* d) {
 
 // ------------------------------------------------------------------ Phi storage
 int bc_sweep_grid(const bc_phi* phi) {
-  // memory-bound sweep: at most 8 blocks (32 waves) per CU, one wave per tile
+  // Memory-bound sweep, one wave per tile and a grid-stride loop.  FEWER resident waves stream better: at N = 10M, S = 100
+  // one 4-wave block per CU (each wave keeps 10 KiB in flight) reaches 0.886 of the HBM spec, two 0.873, four 0.857, eight
+  // 0.846 (profiles/r02_notes.md); a wave of a narrow Phi has fewer bytes per tile to keep in flight and needs company
+  // (S = 16: four blocks per CU are best, one loses 40 %).
+  long long per_cu = phi->s >= 64 ? 1 : (phi->s >= 24 ? 2 : 4);
+  const char* env = getenv("BC_SWEEP_BLOCKS_PER_CU");
+  if (env && atoi(env) > 0) per_cu = atoi(env);
   long long want = (phi->ntiles + 3) / 4;
-  long long cap = (long long)phi->ctx->n_cu * 8;
+  long long cap = (long long)phi->ctx->n_cu * per_cu;
   long long g = want < cap ? want : cap;
   return (int)(g < 1 ? 1 : g);
 }

@@ -343,8 +343,10 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   // one wave per tile and a grid-stride loop: size the grid so that all its waves are resident at once
   // (4 per SIMD) and every wave walks the same number of tiles -- a 2x over-subscribed grid left waves with
   // 2 or 3 tiles each (79% balance at 10M rows)
-  // fp16 / fp32 sweeps: 4 waves per SIMD fit (<= 128 VGPRs); the int8 sweep holds 148 VGPRs: 3 per SIMD
-  long long wmax = (long long)ctx->n_cu * (p->prec == 8 ? 12 : 16);
+  // fp16 / fp32 sweeps: 4 waves per SIMD fit (<= 128 VGPRs); the int8 sweep holds 148 VGPRs: 3 per SIMD would fit, 2 are
+  // used (8 waves per CU: 0.805 of the HBM spec against 0.798 with 12; 6 -> 0.71, 4 -> 0.57: below 8 the 5 KiB a wave keeps
+  // in flight no longer cover the latency)
+  long long wmax = (long long)ctx->n_cu * (p->prec == 8 ? 8 : 16);
   const char* genv = getenv("BC_PREF_WAVES_PER_CU");
   if (genv && atoi(genv) > 0) wmax = (long long)ctx->n_cu * atoi(genv);
   const long long rounds = (p->ptiles + wmax - 1) / wmax;
