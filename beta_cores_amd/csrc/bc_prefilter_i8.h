@@ -4,13 +4,18 @@
 //   rowq[i] = (scale_i, delta_i) as two halfs, delta_i >= || q[i, :] * scale_i - u[i, :] ||_2 measured at build time
 //             (scale_i is rounded UP to a half first and the row is quantised with that value, so it is exact)
 //
-// The sweep vectors are quantised per launch to 14 bits + sign, v^_k = (128 d0_k + d1_k) * vstep with int8
-// digits d0 in [-127, 127], d1 in [-64, 64] and vstep = max|v| / 16256, so that
+// The sweep vector that carries the score (GIGA: the residual direction cdir, s0 = u.cdir; FW: the residual) is quantised
+// per launch to 14 bits + sign, v^_k = (128 d0_k + d1_k) * vstep with int8 digits d0 in [-127, 127], d1 in [-64, 64]
+// and vstep = max|v| / 16256, so that
 //   u^ . v^ = scale_i * vstep * (128 * sum_k q d0 + sum_k q d1)
 // is computed EXACTLY with v_dot4_i32_i8 (four products per instruction, no conversions in the loop), and
 //   | u^.v^ - u.v |  <=  delta_i ||v||  +  (1 + delta_i) * sqrt(S) * vstep / 2
-// bounds the distance to the fp64 kernel's dot product (Cauchy-Schwarz twice).  The interval formula and the
-// rest of the pipeline are those of the fp16 / fp32 mirrors (bc_prefilter.hip).
+// bounds the distance to the fp64 kernel's dot product (Cauchy-Schwarz twice).  GIGA's second vector (the weights'
+// direction y^, s1 = u.y^) only enters through 1 / sqrt(1 - s1^2), whose slope s1 / (1 - s1^2)^(3/2) is small for all
+// but the rows nearly parallel to y^: it gets ONE digit (vstep = max|v| / 127) and an error bound of its own
+// (delta1 ~ 2 delta0), which widens the score interval by ~|s0 s1| delta1, a tenth of delta0 -- and takes a quarter
+// of the dot4 instructions out of a loop that is bound by them (profiles/r02_notes.md).  The interval formula is that
+// of the fp16 / fp32 mirrors (bc_prefilter.hip) with the two deltas kept apart.
 //
 // Layout: tiles of 256 rows, [SP4][256] dwords, dword (g, r) = samples 4g..4g+3 of row r; lane l of the wave that
 // owns the tile holds rows 4l..4l+3, so one k-group of a tile is one 1 KiB dwordx4 load.  SP4 = ceil(S/4) rounded
@@ -50,23 +55,25 @@ struct I8Args {
 // above fp32 rounding, so single precision costs nothing in selectivity; every fp32 evaluation error is covered
 // explicitly: g = 1 - s1^2 carries an absolute error <= 2^-23, i.e. a relative one <= 2^-23 / c (c <= g), rsq and
 // the products add <= 4e-7, and the slope term is inflated by another 0.2 %.  Rows with c <= 1e-3 are "uncertain".
+// |s0* - s0| <= delta0, |s1* - s1| <= delta1:  |f* - f| <= delta0 / sqrt(c) + (|s0| + delta0) * a * delta1 / c^(3/2)  with
+// a = |s1| + delta1, c = 1 - a^2 (mean value theorem on 1 / sqrt(1 - s^2), whose derivative is <= a / c^(3/2) on [-a, a]).
 template <int MODE>
-__device__ __forceinline__ void bc_score_interval_f32(float s0, float s1, float delta, float post_div, float& U, float& L) {
+__device__ __forceinline__ void bc_score_interval_f32(float s0, float s1, float delta0, float delta1, float post_div, float& U, float& L) {
   if (MODE == 0) {
-    const float a = fabsf(s1) + delta;
+    const float a = fabsf(s1) + delta1;
     const float c = 1.f - a * a;
     if (!(s0 == s0) || !(s1 == s1) || !(c > 1e-3f)) { U = INFINITY; L = -INFINITY; return; }
     const float rc2 = __frcp_rn(c) * 1.000001f;             // >= 1/c
     const float rc = sqrtf(rc2) * 1.000001f;                // >= 1/sqrt(c)
     const float f = s0 * __frsqrt_rn(1.f - s1 * s1);
-    const float e = delta * (rc + (fabsf(s0) + delta) * a * rc * rc2) * 1.003f + fabsf(f) * (6.1e-8f * rc2 + 6e-7f) + 2e-7f;
+    const float e = (delta0 * rc + (fabsf(s0) + delta0) * a * delta1 * rc * rc2) * 1.003f + fabsf(f) * (6.1e-8f * rc2 + 6e-7f) + 2e-7f;
     U = f + e;
     L = f - e;
   } else {
     if (!(s0 == s0)) { U = INFINITY; L = -INFINITY; return; }
     const float ip = __frcp_rn(fabsf(post_div)) * 1.000001f;
     const float f = s0 / post_div;
-    const float e = (delta * 1.002f + 3e-7f * fabsf(s0)) * ip + 2e-7f * fabsf(f) + 1e-30f;
+    const float e = (delta0 * 1.002f + 3e-7f * fabsf(s0)) * ip + 2e-7f * fabsf(f) + 1e-30f;
     U = f + e;
     L = f - e;
   }
@@ -134,8 +141,8 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
-  constexpr int NV = (MODE == 0) ? 4 : 2;           // (vector, digit) combinations
-  __shared__ __attribute__((aligned(16))) int dig[BC_IMAXG][4];   // packed digits of k-group g: [v0 d0, v0 d1, v1 d0, v1 d1]
+  constexpr int NV = (MODE == 0) ? 3 : 2;           // (vector, digit) combinations: v0 d0, v0 d1 [, v1 single digit]
+  __shared__ __attribute__((aligned(16))) int dig[BC_IMAXG][4];   // packed digits of k-group g: [v0 d0, v0 d1, v1 d, 0]
   __shared__ double vmx[2][4];
   __shared__ float sl[4];
   __shared__ float su[4];
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
     const double vmax1 = fmax(fmax(vmx[1][0], vmx[1][1]), fmax(vmx[1][2], vmx[1][3]));
     // a NaN / inf in v makes every score NaN in the fp64 kernel: hand all rows over (delta = inf below)
     const bool vbad = !(vmax0 < INFINITY) || !(vmax1 < INFINITY) || vmax0 != vmax0 || vmax1 != vmax1;
-    const double vstep0 = vmax0 / 16256., vstep1 = vmax1 / 16256.;
+    const double vstep0 = vmax0 / 16256., vstep1 = vmax1 / 127.;      // v1: one digit
     for (int g = threadIdx.x; g < SP4; g += blockDim.x) {
       unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -189,11 +196,16 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
             const double val = (MODE == 0) ? a.v[2 * k + vv] : a.v[k];
             const double st = vv == 0 ? vstep0 : vstep1;
             int Q = st > 0. ? (int)rint(val / st) : 0;
-            Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
-            const int d0 = (int)rint((double)Q / 128.);
-            const int d1 = Q - 128 * d0;
-            w[2 * vv] |= ((unsigned)d0 & 0xffu) << (8 * j);
-            w[2 * vv + 1] |= ((unsigned)d1 & 0xffu) << (8 * j);
+            if (vv == 0) {
+              Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
+              const int d0 = (int)rint((double)Q / 128.);
+              const int d1 = Q - 128 * d0;
+              w[0] |= ((unsigned)d0 & 0xffu) << (8 * j);
+              w[1] |= ((unsigned)d1 & 0xffu) << (8 * j);
+            } else {
+              Q = Q > 127 ? 127 : (Q < -127 ? -127 : Q);
+              w[2] |= ((unsigned)Q & 0xffu) << (8 * j);
+            }
           }
         }
       }
@@ -253,11 +265,11 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
           const float dr = dl[j];
           // u^.v^ : exact integers, scaled in fp32 (relative error < 3e-7, covered below)
           const float s0 = sc[j] * fvs0 * (128.f * (float)acc[j][0] + (float)acc[j][1]);
-          const float s1 = (MODE == 0) ? sc[j] * fvs1 * (128.f * (float)acc[j][2] + (float)acc[j][3]) : 0.f;
-          float delta = fmaxf(dr * fvn + (1.f + dr) * fev0, (MODE == 0) ? dr * fvn + (1.f + dr) * fev1 : 0.f) * 1.00001f
-                        + 4e-7f * fmaxf(fabsf(s0), fabsf(s1)) + 1e-12f;
+          const float s1 = (MODE == 0) ? sc[j] * fvs1 * (float)acc[j][NV - 1] : 0.f;
+          const float delta0 = (dr * fvn + (1.f + dr) * fev0) * 1.00001f + 4e-7f * fabsf(s0) + 1e-12f;
+          const float delta1 = (MODE == 0) ? (dr * fvn + (1.f + dr) * fev1) * 1.00001f + 4e-7f * fabsf(s1) + 1e-12f : 0.f;
           if (vbad || dr != dr) { Ub[j] = INFINITY; Lb[j] = -INFINITY; }
-          else bc_score_interval_f32<MODE>(s0, s1, delta, fpd, Ub[j], Lb[j]);
+          else bc_score_interval_f32<MODE>(s0, s1, delta0, delta1, fpd, Ub[j], Lb[j]);
           tl = fmaxf(tl, Lb[j]);
           tmax = fmaxf(tmax, Ub[j]);
         }
