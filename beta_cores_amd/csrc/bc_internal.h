@@ -146,6 +146,23 @@ __device__ __forceinline__ double bc_wave_sum_all(double v) {
 
 __device__ __forceinline__ double bc_wave_sum(double v) { return bc_wave_sum_all(v); }
 
+// Wave-wide fmaxf, the maximum in every lane (all 64 lanes active): the same rotation butterfly on one register.
+template <int CTRL>
+__device__ __forceinline__ float bc_dpp_mov_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float bc_wave_max_f32_all(float v) {
+  v = fmaxf(v, bc_dpp_mov_f32<0x128>(v));   // row_ror:8
+  v = fmaxf(v, bc_dpp_mov_f32<0x124>(v));   // row_ror:4
+  v = fmaxf(v, bc_dpp_mov_f32<0x122>(v));   // row_ror:2
+  v = fmaxf(v, bc_dpp_mov_f32<0x121>(v));   // row_ror:1
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // block-wide sum, result broadcast to every thread; red must hold >= 17 doubles
 __device__ __forceinline__ double bc_block_sum(double v, double* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

@@ -274,11 +274,8 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
           tmax = fmaxf(tmax, Ub[j]);
         }
       }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        tl = fmaxf(tl, __shfl_xor(tl, d, BC_WAVE));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, d, BC_WAVE));
-      }
+      tl = bc_wave_max_f32_all(tl);                    // (DPP row rotations + v_readlane: the ds_bpermute tree of
+      tmax = bc_wave_max_f32_all(tmax);                //  __shfl_xor was a dozen dependent LDS round trips per tile)
       // local candidates: rows whose upper bound reaches the tile's best lower bound (ballot compaction, <= 4 kept)
       int base = 0;
 #pragma unroll
