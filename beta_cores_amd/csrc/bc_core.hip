@@ -23,7 +23,7 @@ int bc_hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 extern "C" const char* bc_last_error(void) { return g_err; }
-extern "C" int bc_version(void) { return 200; }
+extern "C" int bc_version(void) { return 201; }
 
 // ------------------------------------------------------------------ context
 extern "C" int bc_ctx_create(int device, void* stream, bc_ctx** out) {

@@ -17,10 +17,21 @@ def by_grid(path):
             if 'k_' not in kn or kn.startswith('void at::') or 'rocblas' in kn:
                 continue
             acc[(kn, int(r.get('Grid_Size') or r['Grid_Size_X']), int(r.get('Workgroup_Size') or r['Workgroup_Size_X']))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    # a grid-stride kernel launched with the same (resident) grid at two problem sizes: split where durations fall
+    # into two clusters more than 3x apart
+    split = {}
+    for key, v in acc.items():
+        sv = sorted(v)
+        cut = next((i for i in range(1, len(sv)) if sv[i] > 3 * sv[i - 1] and i >= 3 and len(sv) - i >= 3), None)
+        if cut is None:
+            split[key + ('',)] = v
+        else:
+            split[key + ('shorter launches',)] = [x for x in v if x < sv[cut]]
+            split[key + ('longer launches',)] = [x for x in v if x >= sv[cut]]
     w = csv.writer(sys.stdout)
-    w.writerow(['Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'Calls', 'AverageNs', 'MinNs', 'MaxNs'])
-    for (kn, g, wg), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-        w.writerow([kn, g, wg, len(v), '%.1f' % (sum(v) / len(v)), min(v), max(v)])
+    w.writerow(['Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'Calls', 'AverageNs', 'MinNs', 'MaxNs', 'Note'])
+    for (kn, g, wg, note), v in sorted(split.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([kn, g, wg, len(v), '%.1f' % (sum(v) / len(v)), min(v), max(v), note])
 
 
 def counters(path):
