@@ -24,70 +24,64 @@ class BatchPSVICoreset(Coreset):
         if comm is not None and comm.world > 1:
             raise NotImplementedError('BatchPSVICoreset initialises its points from rows of the whole data set; '
                                       'row shards are not supported')
-        self.data = data
-        self.ll_projector = ll_projector
-        self.opt_itrs = opt_itrs
-        self.n_subsample_opt = None if n_subsample_opt is None else min(data.shape[0], n_subsample_opt)   # bpsvi.py:11
-        self.step_sched = step_sched
-        self.mup = mup
-        self.SigpInv = SigpInv
-        self._dev_data = None
-        if pin_data and self.n_subsample_opt is None and hasattr(ll_projector, 'pin') and isinstance(data, np.ndarray) \
-                and data.ndim == 2 and data.shape[0] >= 4096:
+        self.data, self.ll_projector = data, ll_projector
+        self.opt_itrs, self.step_sched = opt_itrs, step_sched
+        self.mup, self.SigpInv = mup, SigpInv
+        n = data.shape[0]
+        self.n_subsample_opt = n_subsample_opt if n_subsample_opt is None else min(n, n_subsample_opt)   # bpsvi.py:11
+        self._resident = None
+        wants_pin = pin_data and self.n_subsample_opt is None and hasattr(ll_projector, 'pin')
+        if wants_pin and isinstance(data, np.ndarray) and data.ndim == 2 and n >= 4096:
             # every gradient re-projects ALL rows: keep them in HBM (read-only on the host while pinned)
-            self._dev_data = ll_projector.pin(data)
+            self._resident = ll_projector.pin(data)
             self._unpin = weakref.finalize(self, ll_projector.unpin, data)
         super().__init__(**kw)
 
+    # ---- bpsvi.py:17-25: a fresh random initialisation of all `sz` points, then the optimisation (itrs is unused)
     def _build(self, itrs, sz):
-        """bpsvi.py:17-25: a fresh random initialisation of all `sz` points, then the optimisation (itrs is unused)"""
-        init_idcs = np.random.choice(self.data.shape[0], size=sz, replace=False)
-        self.pts = self.data[init_idcs]
-        self.wts = self.data.shape[0] / sz * np.ones(sz)
-        self.idcs = init_idcs
+        n = self.data.shape[0]
+        self.idcs = np.random.choice(n, size=sz, replace=False)
+        self.pts = self.data[self.idcs]
+        self.wts = np.full(sz, n / sz)
         self._optimize()
 
-    def _get_projection(self, n_subsample, w, p):
-        """bpsvi.py:27-43 -> (column sums of vecs, sum_scaling, sub_idcs, corevecs, pgrads).  Of `vecs` the gradient
-        only uses `vecs.sum(axis=0)` (bpsvi.py:52), so that S-vector is what is returned (K2, on the device)."""
-        self.ll_projector.update(w, p)
-        if n_subsample is None:
-            sub_idcs = None
-            vecs = self.ll_projector.project(self._dev_data if self._dev_data is not None else self.data)
-            sum_scaling = 1.
+    # ---- bpsvi.py:27-43.  Of the data's projection the gradient only uses its column sums (bpsvi.py:52), so that
+    # S-vector (K2, on the device) is what this returns, already scaled to the whole data set.
+    def _data_term(self):
+        m = self.n_subsample_opt
+        if m is None:
+            rows, scale = (self._resident if self._resident is not None else self.data), 1.
         else:
-            sub_idcs = np.random.randint(self.data.shape[0], size=n_subsample)
-            vecs = self.ll_projector.project(self.data[sub_idcs])
-            sum_scaling = self.data.shape[0] / n_subsample
-        if not isinstance(vecs, DevicePhi):
-            vecs = DevicePhi.from_host(np.ascontiguousarray(vecs, dtype=np.float64), ctx=getattr(self.ll_projector, 'ctx', None))
-        S = vecs.shape[1]
-        vsum = vecs.sum(axis=0)
-        if p.size > 0:
-            corevecs, pgrads = self.ll_projector.project(p, grad=True)
-            corevecs, pgrads = np.asarray(corevecs), np.asarray(pgrads)
-        else:
-            corevecs, pgrads = np.zeros((0, S)), np.zeros((0, S, p.shape[1]))
-        return vsum, sum_scaling, sub_idcs, corevecs, pgrads
+            rows, scale = self.data[np.random.randint(self.data.shape[0], size=m)], self.data.shape[0] / m
+        vecs = self.ll_projector.project(rows)
+        if not isinstance(vecs, DevicePhi):            # black-box projector: a host array, reduced on the device
+            ctx = getattr(self.ll_projector, 'ctx', None)
+            vecs = DevicePhi.from_host(np.ascontiguousarray(vecs, dtype=np.float64), ctx=ctx)
+        return scale * vecs.sum(axis=0)
+
+    def _point_terms(self, p, n_samples):
+        if p.size == 0:
+            return np.zeros((0, n_samples)), np.zeros((0, n_samples, p.shape[1]))
+        lls, glls = self.ll_projector.project(p, grad=True)
+        return np.asarray(lls), np.asarray(glls)
+
+    def _gradient(self, x, sz, d):
+        """bpsvi.py:47-57: d/d(weights, points) of the squared tangent-space residual, estimated over the S samples"""
+        w, p = x[:sz], x[sz:].reshape(sz, d)
+        self.ll_projector.update(w, p)                  # new Theta first (bpsvi.py:29), then the RNG draws of _data_term
+        target = self._data_term()
+        corevecs, pgrads = self._point_terms(p, target.shape[0])
+        resid = target - w.dot(corevecs)
+        S = corevecs.shape[1]
+        g_w = -corevecs.dot(resid) / S
+        g_p = -(w[:, np.newaxis, np.newaxis] * pgrads * resid[np.newaxis, :, np.newaxis]).sum(axis=1) / S
+        return np.concatenate((g_w, g_p.ravel()))
 
     def _optimize(self):
-        """bpsvi.py:45-62"""
-        sz = self.wts.shape[0]
-        d = self.pts.shape[1]
-
-        def grd(x):
-            w = x[:sz]
-            p = x[sz:].reshape((sz, d))
-            vsum, sum_scaling, sub_idcs, corevecs, pgrads = self._get_projection(self.n_subsample_opt, w, p)
-            resid = sum_scaling * vsum - w.dot(corevecs)
-            wgrad = -corevecs.dot(resid) / corevecs.shape[1]
-            ugrad = -(w[:, np.newaxis, np.newaxis] * pgrads * resid[np.newaxis, :, np.newaxis]).sum(axis=1) / corevecs.shape[1]
-            return np.hstack((wgrad, ugrad.reshape(sz * d)))
-
-        x0 = np.hstack((self.wts, self.pts.reshape(sz * d)))
-        xf = partial_nn_opt(x0, grd, np.arange(sz), self.opt_itrs, step_sched=self.step_sched(sz))
-        self.wts = xf[:sz].copy()
-        self.pts = xf[sz:].reshape((sz, d)).copy()
+        sz, d = self.wts.shape[0], self.pts.shape[1]
+        x0 = np.concatenate((self.wts, self.pts.ravel()))
+        x = partial_nn_opt(x0, lambda v: self._gradient(v, sz, d), np.arange(sz), self.opt_itrs, step_sched=self.step_sched(sz))
+        self.wts, self.pts = x[:sz].copy(), x[sz:].reshape(sz, d).copy()
 
     def error(self):
-        return 0.          # bpsvi.py:64-65 ("TODO: implement KL estimate")
+        return 0.          # bpsvi.py:64-65 leaves the KL estimate unimplemented

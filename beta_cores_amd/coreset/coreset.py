@@ -19,19 +19,25 @@ class Coreset(object):
 
     def __init__(self, initial_sz=10, wts=None, idcs=None, pts=None):
         self.alg_name, self.log = make_logger(self)
+        self._clear()
+        if wts is not None:
+            self.wts = wts
+        if idcs is not None:
+            self.idcs = idcs
+        if pts is not None:
+            self.pts = pts
+
+    def _clear(self):
+        """the empty coreset: no weights, no indices, no points, numeric limit not reached"""
+        self.wts, self.pts = np.array([]), np.array([])
+        self.idcs = np.array([], dtype=np.int64)
         self.reached_numeric_limit = False
-        self.wts = np.array([]) if wts is None else wts
-        self.idcs = np.array([], dtype=np.int64) if idcs is None else idcs
-        self.pts = np.array([]) if pts is None else pts
 
     def reset(self):
-        self.wts = np.array([])
-        self.idcs = np.array([], dtype=np.int64)
-        self.pts = np.array([])
-        self.reached_numeric_limit = False
+        self._clear()
 
     def size(self):
-        return (self.wts > 0).sum()
+        return np.count_nonzero(self.wts > 0)
 
     def get(self):
         keep = self.wts > 0
