@@ -62,42 +62,49 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   const int ca = a_ok ? a0 + lc : 0, cb = b_ok ? b0 + lc : 0;
   const bool diag = ta == tb;            // the diagonal block of a column panel also owns its X^T (w*y) slice
   double vy = 0.0;
-  double ra[LP], rb[LP];
-  auto load_slab = [&](long long r0) {
+  // raw values of the slab in flight; the weighting and the X^T (w*y) term are applied when the slab is parked in LDS,
+  // so that the loads can be requested in slices spread over the previous slab's k-steps (requested in one go after the
+  // barrier they held the wave in the issue stage before its first MFMA of the slab -- see K1, profiles/r02_notes.md)
+  double va[LP], vb[LP], vw[LP], vyv[LP];
+  constexpr int NSL = KR / 4;            // one slice per k-step
+  static_assert(LP % NSL == 0 || LP < NSL, "slices");
+  auto load_part = [&](long long r0, int part) {
     const long long left = r_end - r0;
     const long long rows_here = left < KR ? (left > 0 ? left : 0) : KR;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0, (int)(rows_here * a.dz * 8), 0x00020000);
 #pragma unroll
-    for (int q = 0; q < LP; ++q) {
+    for (int q = part * LP / NSL; q < (part + 1) * LP / NSL; ++q) {
       const int lr = lr0 + q * RPP;
-      double wr = 1.0;
-      if (a.w) wr = (r0 + lr < r_end) ? a.w[r0 + lr] : 0.0;
-      const double va = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + ca) * 8, 0, 0));
-      const double vb = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + cb) * 8, 0, 0));
-      ra[q] = a_ok ? wr * va : 0.0;      // A panel carries the weights: (w[:,None]*X)
-      rb[q] = b_ok ? vb : 0.0;
-      if (diag) {                        // (w[:,None]*Y[:,None]*X).sum(axis=0), model_linreg.py:31
-        const double yv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + a.d) * 8, 0, 0));
-        vy = fma(ra[q], yv, vy);
-      }
+      vw[q] = 1.0;
+      if (a.w) vw[q] = (r0 + lr < r_end) ? a.w[r0 + lr] : 0.0;
+      va[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + ca) * 8, 0, 0));
+      vb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + cb) * 8, 0, 0));
+      vyv[q] = 0.;
+      if (diag) vyv[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + a.d) * 8, 0, 0));
     }
   };
   auto store_slab = [&]() {
 #pragma unroll
     for (int q = 0; q < LP; ++q) {
       const int lr = lr0 + q * RPP;
-      Al[lr * LDX + lc] = ra[q];
-      Bl[lr * LDX + lc] = rb[q];
+      const double raq = a_ok ? vw[q] * va[q] : 0.0;     // A panel carries the weights: (w[:,None]*X)
+      Al[lr * LDX + lc] = raq;
+      Bl[lr * LDX + lc] = b_ok ? vb[q] : 0.0;
+      if (diag) vy = fma(raq, vyv[q], vy);               // (w[:,None]*Y[:,None]*X).sum(axis=0), model_linreg.py:31
     }
   };
 
-  if (r_begin < r_end) load_slab(r_begin);
+  if (r_begin < r_end) {
+#pragma unroll
+    for (int part = 0; part < NSL; ++part) load_part(r_begin, part);
+  }
   for (long long r0 = r_begin; r0 < r_end; r0 += KR) {
     store_slab();
     __syncthreads();
-    if (r0 + KR < r_end) load_slab(r0 + KR);
+    const bool more = r0 + KR < r_end;
 #pragma unroll
     for (int kk = 0; kk < KR / 4; ++kk) {
+      if (more) load_part(r0 + KR, kk);
       double fa[MT], fb[MT];
 #pragma unroll
       for (int x = 0; x < MT; ++x) fa[x] = Al[(kk * 4 + g) * LDX + wa * (BT / 2) + x * 16 + j];
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       for (int x = 0; x < MT; ++x)
 #pragma unroll
         for (int y = 0; y < MT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[x], fb[y], acc[x][y], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);     // keeps each slice of loads with its k-step
     }
     __syncthreads();
   }

@@ -63,6 +63,28 @@ struct ProjArgs {
 #define KSTAMP(i) do { } while (0)
 #endif
 
+// model_lr.py:81-86 evaluates two exp and three pow per element; here the powers go through
+//   L1 = log(1+e^m),  L2 = log(1+e^-m) = L1 - m   (each taken from the side that cannot overflow)
+//   (1+e^m)^a = exp(a L1),  (1+e^-m)^a = exp(a L2)
+// i.e. one log1p and four exp (the kernel was transcendental-bound: 4x the linear model's time).  Same
+// saturation as the reference's IEEE overflow semantics (m -> +inf: +1, m -> -inf: -1/b); where the reference
+// flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the 1e-11 of the parity tolerance.
+// NOT inlined: with five libm bodies per element inlined into them, the epilogue's fully unrolled loops over the
+// accumulators exceed the unroller's budget, stay rolled, index the accumulator array dynamically and so push it
+// into scratch memory -- 438 scratch stores inside the contraction loop of the S = 100 kernel (4.9 ms per 1M rows
+// against 2.3 ms with the accumulators in registers).
+__device__ __attribute__((noinline)) double bc_logistic_beta_value(double m, double c0, double c1, double c2) {
+  double L1, L2;
+  if (m <= 0.) {
+    L1 = log1p(exp(m));
+    L2 = L1 - m;
+  } else {
+    L2 = log1p(exp(-m));
+    L1 = L2 + m;
+  }
+  return -((c0 * exp(c1 * L1)) - (exp(c2 * L1) + exp(c2 * L2)));
+}
+
 template <int MODEL>
 __device__ __forceinline__ double bc_model_value(double p, double ra, double sa, const double* c) {
   switch (MODEL) {
@@ -80,24 +102,8 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
       const double m = -p;
       return (m < 100.) ? -log1p(exp(m)) : -m;
     }
-    case BC_MODEL_LOGISTIC_BETA: {        // -( (b+1)/b*(1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) )
-      // model_lr.py:81-86 evaluates two exp and three pow per element; here the powers go through
-      //   L1 = log(1+e^m),  L2 = log(1+e^-m) = L1 - m   (each taken from the side that cannot overflow)
-      //   (1+e^m)^a = exp(a L1),  (1+e^-m)^a = exp(a L2)
-      // i.e. one log1p and four exp (the kernel was transcendental-bound: 4x the linear model's time).  Same
-      // saturation as the reference's IEEE overflow semantics (m -> +inf: +1, m -> -inf: -1/b); where the reference
-      // flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the 1e-11 of the parity tolerance.
-      const double m = -p;
-      double L1, L2;
-      if (m <= 0.) {
-        L1 = log1p(exp(m));
-        L2 = L1 - m;
-      } else {
-        L2 = log1p(exp(-m));
-        L1 = L2 + m;
-      }
-      return -((c[0] * exp(c[1] * L1)) - (exp(c[2] * L1) + exp(c[2] * L2)));
-    }
+    case BC_MODEL_LOGISTIC_BETA:          // -( (b+1)/b*(1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) ), out of line (below)
+      return bc_logistic_beta_value(-p, c[0], c[1], c[2]);
     case BC_MODEL_GAUSS_LL: {             // cc - 1/2*(xSx + tSt - 2*xSt)
       const double q = (ra + sa) - 2. * p;
       return c[0] - 1. / 2. * q;
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   constexpr int NPART = KC / 8;                        // pairs of k-steps per chunk
   constexpr int NSL = KC / 4 > 2 ? KC / 4 - 2 : 1;     // slices: one per k-step, none in the chunk's last two (their
                                                        // loads would not be back when the chunk is written to LDS)
-  auto load_part = [&](int d0, int part) {
+  auto load_part = [&](int d0, int part) __attribute__((always_inline)) {
     const int col = min(d0 + zc, a.d - 1);
     const int voff = (zrw * a.dz + col) * 8;
 #pragma unroll
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     for (int q = part * TP / NSL; q < (part + 1) * TP / NSL; ++q)   // rows past NR are outside the descriptor and read as 0
       tr[q] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, (q * TROWS * a.dk + d0) * 8, 0));
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < ZP; ++q) Zl[(q * ZROWS + zrw) * LDZ + zc] = zr[q];
 #pragma unroll
@@ -219,7 +225,10 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     const double* tquad = Tl + (NT * 16 + (j & 3)) * LDT + g;
     // one k-step (4 features): NT*JT 16x16x4 products + the tail quad.  FIRST: the very first step of the tile starts
     // the accumulators from the instruction's inline-constant 0 (no zero-fill of 100+ VGPRs per tile).
-    auto kstep = [&](int kk, auto first) {
+    // (always_inline: left to its heuristics the compiler keeps some of these lambdas out of line in the largest
+    // instantiations -- the beta-logistic one -- and the accumulators they capture by reference then live in scratch:
+    // 438 scratch stores inside the contraction, 2.35 -> 4.9 ms per 1M rows)
+    auto kstep = [&](int kk, auto first) __attribute__((always_inline)) {
       constexpr bool FIRST = decltype(first)::value;
       double bz[JT];
 #pragma unroll
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
                                                        S * BC_TILE * 8, 0x00020000);
   const int woff = (g * BC_TILE + row_base) * 8;
   double* cpl = LDSCP ? colpart + (w * NR + g) * 17 + j : colpart + w * NR + g;
-  auto put = [&](int s0, double v0, double v1) {       // sample s0 + g of this lane's row(s)
+  auto put = [&](int s0, double v0, double v1) __attribute__((always_inline)) {       // sample s0 + g of this lane's row(s)
     double cp;
     if (JT == 2) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bc_u4v, (bc_d2v){v0, v1}), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
