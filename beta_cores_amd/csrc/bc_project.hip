@@ -63,26 +63,73 @@ struct ProjArgs {
 #define KSTAMP(i) do { } while (0)
 #endif
 
+// ---- the two transcendental building blocks of the logistic models, written out (the libm versions are general-purpose:
+// ~150-200 instructions per log1p(exp(m)); these are ~55, which is what the logistic projections are bound by).
+// exp(x) for x <= 0: Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, degree-12 Taylor polynomial in Horner form
+// (next term r^13/13! <= 1.7e-16), v_ldexp.  x below -745 gives 0 like exp().
+__device__ __forceinline__ double bc_exp_nonpos(double x) {
+  x = (x < -800.) ? -800. : x;                       // (a NaN stays a NaN: the result is NaN like exp()'s)
+  const double k = rint(x * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1. / 479001600.;
+  p = fma(p, r, 1. / 39916800.);
+  p = fma(p, r, 1. / 3628800.);
+  p = fma(p, r, 1. / 362880.);
+  p = fma(p, r, 1. / 40320.);
+  p = fma(p, r, 1. / 5040.);
+  p = fma(p, r, 1. / 720.);
+  p = fma(p, r, 1. / 120.);
+  p = fma(p, r, 1. / 24.);
+  p = fma(p, r, 1. / 6.);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.);
+  p = fma(p, r, 1.);
+  return ldexp(p, (int)k);
+}
+
+// log1p(exp(-a)) for a >= 0 (NaN in, NaN out): u = exp(-a) in (0, 1], f = 1 + u in (1, 2] halved above sqrt(2),
+// log f' = 2 atanh(t), t = (f' - 1) / (f' + 1), |t| <= 0.172 (odd series to t^21), plus the first-order correction for
+// the rounding of 1 + u.  Measured against 80-bit arithmetic over m in [-800, 100): at most 4.4 ulp, 0.4 on average
+// (log1p(exp(m)) of glibc: 1.6 / 0.25); exactly log 2 at a = 0.
+__device__ __forceinline__ double bc_log1p_exp_neg(double a) {
+  const double u = bc_exp_nonpos(-a);
+  const double f = 1. + u;
+  const bool hi = f > 1.4142135623730951;
+  const double fp = hi ? 0.5 * f : f;
+  const double t = (fp - 1.) / (fp + 1.);
+  const double t2 = t * t;
+  double q = 2. / 21.;
+  q = fma(q, t2, 2. / 19.);
+  q = fma(q, t2, 2. / 17.);
+  q = fma(q, t2, 2. / 15.);
+  q = fma(q, t2, 2. / 13.);
+  q = fma(q, t2, 2. / 11.);
+  q = fma(q, t2, 2. / 9.);
+  q = fma(q, t2, 2. / 7.);
+  q = fma(q, t2, 2. / 5.);
+  q = fma(q, t2, 2. / 3.);
+  q = fma(q, t2, 2.);
+  const double c = (u - (f - 1.)) / f;
+  return fma(q, t, hi ? 0.6931471805599453 : 0.) + c;
+}
+
 // model_lr.py:81-86 evaluates two exp and three pow per element; here the powers go through
-//   L1 = log(1+e^m),  L2 = log(1+e^-m) = L1 - m   (each taken from the side that cannot overflow)
-//   (1+e^m)^a = exp(a L1),  (1+e^-m)^a = exp(a L2)
-// i.e. one log1p and four exp (the kernel was transcendental-bound: 4x the linear model's time).  Same
-// saturation as the reference's IEEE overflow semantics (m -> +inf: +1, m -> -inf: -1/b); where the reference
-// flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the 1e-11 of the parity tolerance.
-// NOT inlined: with five libm bodies per element inlined into them, the epilogue's fully unrolled loops over the
-// accumulators exceed the unroller's budget, stay rolled, index the accumulator array dynamically and so push it
+//   L1 = log(1+e^m),  L2 = log(1+e^-m) = L1 - m   (the smaller of the two is log1p(e^-|m|), the other one adds |m|)
+//   (1+e^m)^a = exp(a L1),  (1+e^-m)^a = exp(a L2)          (a < 0, L >= 0: arguments <= 0)
+// i.e. one log1p(exp) and three exp.  Same saturation as the reference's IEEE overflow semantics (m -> +inf: +1,
+// m -> -inf: -1/b); where the reference flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the
+// 1e-11 of the parity tolerance.
+// NOT inlined: with four transcendental bodies per element inlined into them, the epilogue's fully unrolled loops over
+// the accumulators exceed the unroller's budget, stay rolled, index the accumulator array dynamically and so push it
 // into scratch memory -- 438 scratch stores inside the contraction loop of the S = 100 kernel (4.9 ms per 1M rows
-// against 2.3 ms with the accumulators in registers).
+// against 1.7 ms with the accumulators in registers).
 __device__ __attribute__((noinline)) double bc_logistic_beta_value(double m, double c0, double c1, double c2) {
-  double L1, L2;
-  if (m <= 0.) {
-    L1 = log1p(exp(m));
-    L2 = L1 - m;
-  } else {
-    L2 = log1p(exp(-m));
-    L1 = L2 + m;
-  }
-  return -((c0 * exp(c1 * L1)) - (exp(c2 * L1) + exp(c2 * L2)));
+  const double am = fabs(m);
+  const double Ls = bc_log1p_exp_neg(am);            // log(1 + e^-|m|)
+  const double Ll = Ls + am;                          // log(1 + e^+|m|)
+  const double L1 = (m <= 0.) ? Ls : Ll, L2 = (m <= 0.) ? Ll : Ls;
+  return -((c0 * bc_exp_nonpos(c1 * L1)) - (bc_exp_nonpos(c2 * L1) + bc_exp_nonpos(c2 * L2)));
 }
 
 template <int MODEL>
@@ -98,9 +145,9 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
       const double q = (ra * ra - p * (2. * ra)) + p * p;
       return c[0] * (c[1] * exp(c[2] * q) + c[3]);
     }
-    case BC_MODEL_LOGISTIC_LL: {          // m = -z.th ; m < 100 ? -log1p(exp(m)) : -m
+    case BC_MODEL_LOGISTIC_LL: {          // m = -z.th ; m < 100 ? -log1p(exp(m)) : -m ;  log1p(e^m) = max(m, 0) + log1p(e^-|m|)
       const double m = -p;
-      return (m < 100.) ? -log1p(exp(m)) : -m;
+      return (m < 100.) ? -(fmax(m, 0.) + bc_log1p_exp_neg(fabs(m))) : -m;
     }
     case BC_MODEL_LOGISTIC_BETA:          // -( (b+1)/b*(1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) ), out of line (below)
       return bc_logistic_beta_value(-p, c[0], c[1], c[2]);

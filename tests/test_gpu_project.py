@@ -508,3 +508,31 @@ def test_nearly_constant_rows_are_not_flattened(bc, S):
         assert np.abs(dev[i] - ref[i]).max() <= 8 * np.spacing(abs(c[i]))        # the means may differ by an ulp or two of c
         assert np.abs(dev[i]).max() > 50 * np.spacing(abs(c[i]))                 # ... which is far below the row's own size
         assert nrm[i] > 0. and abs(nrm[i] - np.sqrt((dev[i] ** 2).sum())) <= 1e-12 * nrm[i]
+
+
+def test_logistic_models_special_values(bc):
+    """The logistic projections evaluate log1p(exp(m)) and exp() with their own short implementations
+    (csrc/bc_project.hip: bc_log1p_exp_neg, bc_exp_nonpos): saturation, the branch at m = 100, huge |m| and NaN rows
+    must behave like the reference's expressions."""
+    rng = np.random.RandomState(3)
+    S, d = 100, 4
+    th = rng.randn(S, d)
+    th[:, 0] = np.abs(th[:, 0]) + 0.5
+    Z = rng.randn(64, d)
+    Z[1, :] = 0.
+    Z[2, :] = [-150., 0., 0., 0.]          # m = +150 th0 > 100 on most samples: the linear branch
+    Z[3, :] = [900., 0., 0., 0.]           # m very negative: log1p(exp(m)) underflows to 0
+    Z[4, :] = [-99.9, 0., 0., 0.]
+    Z[5, 2] = np.nan
+    for beta, raw in ((None, M.logistic_loglik(Z, th)), (0.3, M.logistic_beta_lik(Z, th, 0.3))):
+        prj = bc.DeviceBetaProjector(fixed(th), S, bc.likelihoods.LogisticRegression())
+        got = np.asarray(prj.project(Z) if beta is None else prj.project_f(Z, beta))
+        ref = raw - raw.mean(axis=1)[:, None]
+        ok = np.ones(64, dtype=bool)
+        ok[5] = False
+        assert np.all(np.isnan(got[5])) and np.all(np.isnan(ref[5]))
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=0., atol=1e-11 * (1. + np.abs(raw[ok]).max()))
+        # element-wise relative accuracy where the values are not tiny
+        big = ok[:, None] & (np.abs(raw) > 1e-3)
+        rel = np.abs((got + raw.mean(axis=1)[:, None]) - raw)[big] / np.abs(raw)[big]
+        assert rel.max() < 1e-12, rel.max()
