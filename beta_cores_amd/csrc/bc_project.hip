@@ -120,11 +120,11 @@ __device__ __forceinline__ double bc_log1p_exp_neg(double a) {
 // i.e. one log1p(exp) and three exp.  Same saturation as the reference's IEEE overflow semantics (m -> +inf: +1,
 // m -> -inf: -1/b); where the reference flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the
 // 1e-11 of the parity tolerance.
-// NOT inlined: with four transcendental bodies per element inlined into them, the epilogue's fully unrolled loops over
-// the accumulators exceed the unroller's budget, stay rolled, index the accumulator array dynamically and so push it
-// into scratch memory -- 438 scratch stores inside the contraction loop of the S = 100 kernel (4.9 ms per 1M rows
-// against 1.7 ms with the accumulators in registers).
-__device__ __attribute__((noinline)) double bc_logistic_beta_value(double m, double c0, double c1, double c2) {
+// (With the general libm bodies -- one log1p, four exp -- inlined, the epilogue's fully unrolled loops over the
+// accumulators exceeded the unroller's budget, stayed rolled, indexed the accumulator array dynamically and so pushed it
+// into scratch memory: 438 scratch stores inside the contraction loop of the S = 100 kernel, 4.9 ms per 1M rows.  With
+// the short bodies above the loops unroll again: 0.92 ms.)
+__device__ __forceinline__ double bc_logistic_beta_value(double m, double c0, double c1, double c2) {
   const double am = fabs(m);
   const double Ls = bc_log1p_exp_neg(am);            // log(1 + e^-|m|)
   const double Ll = Ls + am;                          // log(1 + e^+|m|)
