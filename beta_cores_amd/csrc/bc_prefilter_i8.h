@@ -32,6 +32,7 @@
 #define BC_IU 5          // k-groups per batch (5 KiB in flight per wave and buffer)
 #endif
 #define BC_IMAXG 320     // k-groups the digit table holds: S <= 1280
+#define BC_IFLUSH 32     // tiles a wave parks in LDS before it writes their results out
 typedef int bc_i4 __attribute__((ext_vector_type(4)));
 typedef _Float16 bc_hq8 __attribute__((ext_vector_type(8)));   // ... of a lane's four rows
 
@@ -146,6 +147,12 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
   __shared__ double vmx[2][4];
   __shared__ float sl[4];
   __shared__ float su[4];
+  // per-tile results are parked here and written out in bursts of BC_IFLUSH tiles per wave (for 10M rows: once, after the
+  // wave's last tile): 39k x 3 small scattered stores interleaved with the read stream cost the HBM channels their
+  // read/write turn-arounds all through the sweep
+  __shared__ float s_tu[4][BC_IFLUSH];
+  __shared__ int s_nc[4][BC_IFLUSH];
+  __shared__ __attribute__((aligned(16))) float2 s_cd[4][BC_IFLUSH][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float best_l = -INFINITY;
   float umax = -INFINITY;
@@ -221,6 +228,25 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
     // Continuous pipeline: while the last batch of a tile is consumed and its rows are evaluated, the first batch
     // (and the row constants) of the wave's NEXT tile are already in flight.
     const long long tstride = (long long)gridDim.x * 4;
+    int ti = 0;                                      // tiles parked since the last flush
+    long long t_park = t;                            // ... the first of them
+    auto flush = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < ti) {
+        const long long tt = t_park + (long long)lane * tstride;
+        a.tile_u[tt] = s_tu[wave][lane];
+        a.tile_ncand[tt] = s_nc[wave][lane];
+        const float4 c01 = *reinterpret_cast<const float4*>(&s_cd[wave][lane][0]);
+        const float4 c23 = *reinterpret_cast<const float4*>(&s_cd[wave][lane][2]);
+        float4* dst = reinterpret_cast<float4*>(a.tile_cand + tt * 4);
+        dst[0] = c01;
+        dst[1] = c23;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      ti = 0;
+    };
     for (; t < a.ptiles; t += tstride) {
       const bc_i4* __restrict__ p = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
       int acc[4][NV];
@@ -284,17 +310,20 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         const unsigned long long m = __ballot(c);
         if (c) {
           const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (slot < 4) a.tile_cand[t * 4 + slot] = make_float2(Ub[j], (float)(4 * lane + j));
+          if (slot < 4) s_cd[wave][ti][slot] = make_float2(Ub[j], (float)(4 * lane + j));
         }
         base += __popcll(m);
       }
       if (lane == 0) {
-        a.tile_u[t] = tmax;
-        a.tile_ncand[t] = base;
+        s_tu[wave][ti] = tmax;
+        s_nc[wave][ti] = base;
       }
+      if (ti == 0) t_park = t;
+      if (++ti == BC_IFLUSH) flush();
       best_l = fmaxf(best_l, tl);
       umax = fmaxf(umax, tmax);
     }
+    if (ti > 0) flush();
   }
   if (lane == 0) { sl[wave] = best_l; su[wave] = umax; }
   __syncthreads();
