@@ -255,3 +255,26 @@ def test_million_rows_identical(bc):
     tb, wb, eb = out[-1]
     for ta, wa, ea in out[:-1]:
         assert np.array_equal(ta[0], tb[0]) and np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and ea == eb
+
+
+def test_int8_sweep_many_tiles_per_wave(bc, monkeypatch):
+    """The int8 sweep parks per-tile results in LDS and writes them out in bursts of 32 tiles per wave.  With one wave
+    per SIMD-quarter of the chip (BC_PREF_WAVES_PER_CU=1) and 2.3M rows a wave walks 35 tiles: the burst in the middle of
+    the walk and the one at its end must both land where the rescoring looks for them."""
+    import torch
+    g = torch.Generator(device='cuda'); g.manual_seed(21)
+    n, d, s = 2_300_000, 8, 16
+    Z = torch.randn((n, d + 1), generator=g, dtype=torch.float64, device='cuda')
+    th = np.random.default_rng(2).standard_normal((s, d)) * 0.3
+    data = bc.DeviceData.from_torch(Z)
+    phi = bc.DeviceProjector(lambda k, w, p: th, s, bc.likelihoods.LinearRegression(1.0)).project(data)
+    monkeypatch.setenv('BC_PREF_WAVES_PER_CU', '1')
+    out = []
+    for on in (8, 0):
+        with prefilter(on):
+            sv = bc.snnls.GIGA(phi.T, phi.colsum())
+        assert sv._eng.prefilter == on
+        sv.build(25)
+        out.append((sv._eng.trace(), sv._eng.sparse_weights(), sv.error()))
+    (ta, wa, ea), (tb, wb, eb) = out
+    assert np.array_equal(ta[0], tb[0]) and np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and ea == eb
