@@ -157,7 +157,7 @@ def _k1_entry(name, n, d, dz, s, ms, model):
                                    'frac': fl / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}}
 
 
-def other_configs(torch, bc, ctx, dev, barrier):
+def other_configs(torch, bc, ctx, dev, barrier, no_cpu=False):
     """K1 (and K4 for config 5) on the other BASELINE configs, synthetic inputs as SURVEY 8(d) specifies, S = 100."""
     S = 100
     res = []
@@ -181,7 +181,10 @@ def other_configs(torch, bc, ctx, dev, barrier):
     res.append(_k1_entry('configs[1] linreg N=1M D=64', n, d, d + 1, S, ms, 'log-likelihood (model_linreg.py:4-10)'))
     ms, _ = _time_k1(ctx, lambda: prj.project_f(data, 0.1), barrier)
     res.append(_k1_entry('configs[1] linreg N=1M D=64', n, d, d + 1, S, ms, 'beta-likelihood, beta = 0.1 (model_neurlinr.py:102-110)'))
-    del prj, data, Z
+    del prj
+    beta_legs = beta_coreset_leg(bc, ctx, barrier, data, 'configs[1] Zellner linreg N=1M D=64', oracle_rows=None if no_cpu else 100_000,
+                                 Z_host=None if no_cpu else Z[:100_000].cpu().numpy())
+    del data, Z
     # config 3: Zellner logistic regression N = 1M, D = 128
     n, d = 1_000_000, 128
     g.manual_seed(30)
@@ -232,7 +235,147 @@ def other_configs(torch, bc, ctx, dev, barrier):
     res.append(e)
     del prj, data, Z
     torch.cuda.empty_cache()
-    return res
+    return res, beta_legs
+
+
+def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, opt_seed=7, oracle_rows=None, Z_host=None):
+    """The beta-Cores gradient loop (bcores.py:141-150, BetaCoreset._optimize with n_subsample_* = None, learn_beta = False,
+    beta = 0.1): per gradient  sampler (weighted_post on the <= M coreset rows, model_linreg.py:25-34) -> K1 over ALL data
+    rows (store-free: only vecs.sum(axis=0) is needed) -> column sums -> M x S algebra -> one ADAM step on the host.
+    The coreset is pre-initialised with M rows (as the reference's drivers do with wts / idcs / pts,
+    zellner_neural_linear/main.py:147-149) and `_optimize()` runs `grads` gradients."""
+    n, dz = data.shape
+    d = dz - 1
+    S = 100
+    th0, Sig0inv = np.zeros(d), np.eye(d)
+    out = []
+    for M in sizes:
+        rng = np.random.RandomState(opt_seed + M)
+        idcs = np.sort(rng.choice(n, M, replace=False)).astype(np.int64)
+        pts = data.rows(idcs)
+        srng = np.random.RandomState(1000 + M)
+        t_samp = [0.0, 0]
+
+        def sampler_w(k, wts, pts_):           # zellner_neural_linear/main.py:119-124 (the weighted_post form)
+            t0 = time.perf_counter()
+            if pts_.shape[0] == 0:
+                wts, pts_ = np.zeros(1), np.zeros((1, dz))
+            mu, L, _ = bc.weighted_post(th0, Sig0inv, 1.0, pts_, wts, ctx=ctx)
+            r = mu + srng.randn(k, d).dot(L.T)
+            t_samp[0] += time.perf_counter() - t0
+            t_samp[1] += 1
+            return r
+        prj = bc.DeviceBetaProjector(sampler_w, S, bc.likelihoods.LinearRegression(1.0), ctx=ctx)
+        sched = lambda i: 0.01 / (1. + i)
+
+        def make(fused):
+            return bc.BetaCoreset(data, prj, opt_itrs=grads, step_sched=sched, beta=0.1, learn_beta=False,
+                                  wts=np.full(M, float(n) / M), idcs=idcs.copy(), pts=pts.copy(), fused_gradient=fused)
+        alg = make(True)
+        t_call = [0.0, 0]
+        orig = prj.vi_gradient
+
+        def timed_call(*a, **kw):
+            t1 = time.perf_counter()
+            r = orig(*a, **kw)
+            t_call[0] += time.perf_counter() - t1
+            t_call[1] += 1
+            return r
+        prj.vi_gradient = timed_call
+        ctx.enable_timing(0)
+        alg.opt_itrs = 5
+        alg._optimize()                                    # warm-up: buffers, code objects
+        alg.opt_itrs = grads
+        barrier()
+        t_samp[0], t_samp[1], t_call[0], t_call[1] = 0.0, 0, 0.0, 0
+        t0 = time.perf_counter()
+        alg._optimize()
+        barrier()
+        t_fused = (time.perf_counter() - t0) / grads
+        samp_ms = 1e3 * t_samp[0] / max(t_samp[1], 1)
+        call_ms = 1e3 * t_call[0] / max(t_call[1], 1)
+        fused_calls = t_call[1]
+        # instrumented pass: HIP events between the phases of the native call (they cost stream time: not the timed pass)
+        ctx.enable_timing(1)
+        ctx.kernel_time_reset()
+        ctx.phase_times(reset=True)
+        t0 = time.perf_counter()
+        alg._optimize()
+        barrier()
+        t_instr = (time.perf_counter() - t0) / grads
+        ph, ncalls = ctx.phase_times(reset=True)
+        k1_ms, k1_n = ctx.kernel_time(1)
+        ctx.enable_timing(0)
+        prj.vi_gradient = orig
+        ph = {k: v / max(ncalls, 1) for k, v in ph.items()}
+        k1 = k1_ms / max(k1_n, 1)
+        # the general path for comparison: every gradient materialises Phi (8*N*S more bytes) and reads back its column sums
+        alg_m = make(False)
+        alg_m.opt_itrs = 3
+        alg_m._optimize()
+        gm = max(10, grads // 5)
+        alg_m.opt_itrs = gm
+        barrier()
+        t0 = time.perf_counter()
+        alg_m._optimize()
+        barrier()
+        t_mat = (time.perf_counter() - t0) / gm
+        # one whole build step (select: materialised K1 + K3 sweep, then `grads` gradients)
+        alg.opt_itrs = grads
+        barrier()
+        t0 = time.perf_counter()
+        alg.build(1, M + 1)
+        barrier()
+        t_build = time.perf_counter() - t0
+        byt = 8.0 * n * dz
+        fl = 2.0 * n * d * S
+        e = {'config': name, 'N': n, 'D': d, 'S': S, 'M': M, 'beta': 0.1, 'gradients': grads,
+             'ms_per_gradient': 1e3 * t_fused,
+             'k1_store_free_kernel_ms': k1,
+             'non_k1_fraction': max(0.0, 1.0 - k1 / (1e3 * t_fused)),
+             'native_gradient_calls': fused_calls,
+             'breakdown_ms': {'sampler (host LAPACK + K4 on the M coreset rows)': samp_ms,
+                              'native gradient call, wall (Theta upload, K1 x2, column sums, M x S algebra, one sync)': call_ms,
+                              'ADAM step + Python glue': max(0.0, 1e3 * t_fused - samp_ms - call_ms),
+                              'gpu_phases_inside_the_call (HIP events, separate instrumented pass)': ph,
+                              'instrumented_pass_ms_per_gradient': 1e3 * t_instr},
+             'roofline_hbm': {'achieved': byt / (k1 * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': byt / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 'bytes_per_launch': byt,
+                              'note': 'algorithmic bytes 8*N*Dz: Z read once, Phi never written'},
+             'roofline_fp64_mfma': {'achieved': fl / (k1 * 1e-3) / 1e12, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                                    'frac': fl / (k1 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF},
+             'whole_gradient_vs_hbm': byt / t_fused / 1e9 / HBM_PEAK_GBS,
+             'materialising_path_ms_per_gradient': 1e3 * t_mat,
+             'build_step_ms (select + %d gradients)' % grads: 1e3 * t_build}
+        out.append(e)
+        del alg, alg_m, prj
+    if oracle_rows and Z_host is not None:
+        # the same loop through the NumPy oracle on the host, on the first `oracle_rows` rows (row-capped: K1 on the CPU is
+        # ~10 s per million rows and gradient)
+        from oracle import models_ref, coreset_ref
+        Zs = Z_host[:oracle_rows]
+        M = sizes[-1]
+        rng = np.random.RandomState(opt_seed + M)
+        idc = np.sort(rng.choice(oracle_rows, M, replace=False)).astype(np.int64)
+        srng = np.random.RandomState(1000 + M)
+
+        def samp(w, p):
+            if p.shape[0] == 0:
+                w, p = np.zeros(1), np.zeros((1, dz))
+            mu, L, _ = models_ref.linreg_weighted_post(th0, Sig0inv, 1.0, p, w)
+            return mu + srng.randn(S, d).dot(L.T)
+        g_cpu = 4
+        ref = coreset_ref.RefGreedyVI(Zs, lambda p_, th: coreset_ref.project_f(lambda z, t, b: models_ref.linreg_beta_lik(z, t, b, 1.0), p_, th, 0.1),
+                                      samp, g_cpu, lambda i: 0.01 / (1. + i), wts=np.full(M, float(oracle_rows) / M), idcs=idc, pts=Zs[idc])
+        t0 = time.perf_counter()
+        ref.optimize()
+        t_cpu = (time.perf_counter() - t0) / g_cpu
+        out.append({'cpu_baseline': {'kind': 'port', 'config': name, 'rows': int(oracle_rows), 'M': M, 'gradients': g_cpu,
+                                     'ms_per_gradient': 1e3 * t_cpu,
+                                     'ms_per_gradient_scaled_to_N': 1e3 * t_cpu * n / oracle_rows,
+                                     'sample': 'NumPy oracle (oracle/coreset_ref.RefGreedyVI.optimize) on the first %d of %d rows, '
+                                               '%d gradients; K1 on the host is linear in the rows' % (oracle_rows, n, g_cpu)}})
+    return out
 
 
 def main():
@@ -427,7 +570,9 @@ def main():
     # ---------------- the SURVEY 8(d) formulation, driver-timed too: the exact fp64 sweep (8*N*S + 8*N bytes per step)
     if rank == 0 and world == 1 and not args.no_extra:
         out['fp64_sweep'] = fp64_sweep_leg(bc, ctx, alg, cls, barrier, n_local, S, args)
-        out['other_configs'] = other_configs(torch, bc, ctx, dev, barrier)
+        out['other_configs'], beta2 = other_configs(torch, bc, ctx, dev, barrier, no_cpu=args.no_cpu)
+        # the beta-Cores gradient loop (BetaCoreset._optimize, bcores.py:141-150) on configs 2 and 4
+        out['beta_coreset'] = beta2 + beta_coreset_leg(bc, ctx, barrier, data, 'configs[3] Zellner linreg N=%d D=%d' % (N, D))
 
     # ---------------- CPU baseline (rank 0, N=1 launch only): the NumPy oracle
     if rank == 0 and world == 1 and not args.no_cpu:

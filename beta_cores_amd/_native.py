@@ -31,6 +31,7 @@ _SIGNATURES = {
     'bc_ctx_kernel_time': [vp, C.c_int, c_dp, c_i64p],
     'bc_ctx_kernel_time_reset': [vp],
     'bc_ctx_enable_timing': [vp, C.c_int],
+    'bc_ctx_phase_times': [vp, vp, C.c_int32, c_i64p, C.c_int],
     'bc_data_from_host': [vp, vp, C.c_int64, C.c_int32, vpp],
     'bc_data_from_device': [vp, vp, C.c_int64, C.c_int32, vpp],
     'bc_data_create': [vp, C.c_int64, C.c_int32, vpp],
@@ -41,6 +42,8 @@ _SIGNATURES = {
     'bc_phi_create': [vp, C.c_int64, C.c_int32, vpp],
     'bc_project': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, C.c_int64, vpp],
     'bc_project_grad_x': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, vp],
+    'bc_project_colsum': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, vp, vp],
+    'bc_vi_gradient': [vp, vp, vp, C.c_int64, C.c_int, vp, C.c_int32, vp, C.c_int32, vp, C.c_double, vp, vp, vp],
     'bc_phi_shape': [vp, c_i64p, c_i32p, c_i64p],
     'bc_phi_colsum': [vp, vp],
     'bc_phi_norms': [vp, vp],
@@ -64,6 +67,7 @@ _SIGNATURES = {
     'bc_comm_precheck': [vp],
     'bc_comm_abort': [vp],
     'bc_comm_sum_doubles': [vp, vp, C.c_int64, vp],
+    'bc_comm_rank_order_sum_selftest': [vp, vp, C.c_int32, C.c_int64, vp],
     'bc_phi_colsum_all': [vp, vp, vp],
     'bc_snnls_bind_comm': [vp, vp],
     'bc_snnls_prefilter_active': [vp, c_ip],

@@ -33,6 +33,9 @@ class BetaCoreset(GreedyVICoreset):
     def _proj(self, pts, beta):
         return self.ll_projector.project_f(pts, beta)
 
+    def _fused_beta(self, beta):
+        return beta
+
     def _optimize(self):
         """bcores.py:126-150.  learn_beta=True: projected ADAM over (w, beta) jointly, the beta-gradient
         scaled by 1e-5 (bcores.py:128-140).  The method the reference calls for the tangent space,

@@ -25,7 +25,7 @@ def _flatten(groups):
 class GreedyVICoreset(Coreset):
     def __init__(self, data, ll_projector, n_subsample_select=None, n_subsample_opt=None, opt_itrs=100,
                  step_sched=lambda i: 1. / (1. + i), mup=None, SigpInv=None, groups=None, selected_groups=None,
-                 initialized=False, comm=None, pin_data=True, **kw):
+                 initialized=False, comm=None, pin_data=True, fused_gradient=True, **kw):
         self.data = data
         self.ll_projector = ll_projector
         n = data.shape[0]
@@ -37,8 +37,9 @@ class GreedyVICoreset(Coreset):
         self.SigpInv = SigpInv
         self.groups = groups
         self.selected_groups = []
+        self.fused_gradient = bool(fused_gradient)     # False: every gradient materialises Phi (the general path)
         self.comm = comm if (comm is not None and comm.world > 1) else None
-        self._dev_data = None
+        self._dev_data = data if isinstance(data, DeviceData) else None      # rows already resident in HBM
         if self.comm is not None:
             if groups is not None or n_subsample_select is not None or n_subsample_opt is not None:
                 raise NotImplementedError('sharded rows support the full-data, ungrouped mode only')
@@ -200,10 +201,46 @@ class GreedyVICoreset(Coreset):
                 self._append(self.groups[f], self.data[self.groups[f], :])
 
     # -- bcores.py:141-150
+    def _fused_gradient(self, w, beta):
+        """The full-data, ungrouped gradient in one native call (bc_vi_gradient): the data rows go through the
+        store-free K1 (only `vecs.sum(axis=0)` is needed of them, bcores.py:144-145), the coreset rows and the M x S
+        algebra stay on the device, one host synchronisation.  None when this mode does not apply (black-box
+        projector, sub-sampling, groups, a transport without a native communicator, no coreset rows yet)."""
+        from .projector import _DeviceProjectorBase
+        if not self.fused_gradient or self.n_subsample_opt is not None or self.groups is not None \
+                or self.pts.size == 0 or not isinstance(self.ll_projector, _DeviceProjectorBase):
+            return None
+        nc = None
+        if self.comm is not None:
+            nc = self.comm.native_comm(self.ll_projector.ctx)
+            if nc is None:
+                return None
+        self.ll_projector.update(w, self.pts)
+        g = self.ll_projector.vi_gradient(self._dev_data if self._dev_data is not None else self.data, self.pts, w, 1.,
+                                          beta=self._fused_beta(beta), comm=nc)
+        if g is None:
+            raise RuntimeError('fused gradient not applicable after the sampler ran')      # guarded by the checks above
+        return g
+
+    def _fused_beta(self, beta):
+        return None      # SparseVI: plain log-likelihood; BetaCoreset overrides
+
+    def _fused_ok(self):
+        """The shape conditions of vi_gradient that do not depend on the sampler's output."""
+        if self.pts.size == 0:
+            return False
+        m, dz = np.atleast_2d(self.pts).shape
+        return self.ll_projector.projection_dimension <= 256 and m * (dz + 1) <= 60000
+
     def _optimize(self):
         beta = self._beta()
+        fused = self._fused_ok() if hasattr(self.ll_projector, 'vi_gradient') else False
 
         def grd(w):
+            if fused:
+                g = self._fused_gradient(w, beta)
+                if g is not None:
+                    return g
             vecs, sum_scaling, _, _, corevecs = self._tangent(self.n_subsample_opt, w, self.pts, beta)
             resid = sum_scaling * self._colsum(vecs) - w.dot(corevecs)
             return -corevecs.dot(resid) / corevecs.shape[1]

@@ -276,6 +276,63 @@ class _DeviceProjectorBase(Projector):
             raise
         return DevicePhi(h, self.ctx, release=self._pool.releaser(cap, S))
 
+    # -- the store-free paths of the gradient loop (bcores.py:141-146, sparsevi.py:129-134): of the N x S projection of
+    # the data rows only the S column sums are needed there, so K1 keeps its column partials and writes no Phi
+    def _ids(self, beta):
+        if beta is None:
+            return self.model.model_id, self.model.params()
+        return self.model.beta_model_id, self.model.params(beta=beta)
+
+    def _theta_checked(self, dd):
+        theta = self.model.theta_for_device(self.samples)
+        if dd.shape[1] != self.model.data_width(theta.shape[1]):
+            raise ValueError('data rows have %d columns, model expects %d for %d-dimensional samples'
+                             % (dd.shape[1], self.model.data_width(theta.shape[1]), theta.shape[1]))
+        return theta
+
+    def colsum(self, pts, beta=None, comm=None):
+        """`project(pts).sum(axis=0)` (beta None) / `project_f(pts, beta).sum(axis=0)` without materialising the
+        projection: bc_project_colsum, bit-identical to the column sums of the materialised Phi.  `comm`: a native
+        communicator handle (ShardComm.native_comm) -- the sum then runs over all ranks' shards.  Returns None when the
+        store-free kernel does not cover the request (S > 256); the caller projects and sums instead."""
+        dd, _ = self.device_data(pts)
+        theta = self._theta_checked(dd)
+        S = int(theta.shape[0])
+        if S > 256:
+            return None
+        model_id, params = self._ids(beta)
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        out = np.empty(S)
+        N.call('bc_project_colsum', self.ctx.h, dd.h, int(model_id), _ptr(theta), S, _ptr(params), int(params.shape[0]),
+               comm, _ptr(out))
+        return out
+
+    def vi_gradient(self, data, core_pts, w, sum_scaling=1., beta=None, comm=None, want_resid=False):
+        """One gradient of the greedy-VI weight optimisation in one native call (bc_vi_gradient): with the current
+        samples, -corevecs.dot(sum_scaling * vecs.sum(axis=0) - w.dot(corevecs)) / S for vecs = projection of `data`
+        (resident DeviceData, pinned array, or a live array that is uploaded for this call like project() does) and
+        corevecs = projection of `core_pts`.  None if not covered (S > 256, no coreset rows, or a coreset too large
+        for the staging area)."""
+        dd, _ = self.device_data(data)
+        core = np.ascontiguousarray(np.atleast_2d(core_pts), dtype=np.float64)
+        m = int(core.shape[0])
+        theta = self._theta_checked(dd)
+        S = int(theta.shape[0])
+        if S > 256 or m == 0 or m * (core.shape[1] + 1) > 60000:
+            return None
+        if core.shape[1] != dd.shape[1]:
+            raise ValueError('coreset rows have %d columns, data rows %d' % (core.shape[1], dd.shape[1]))
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        if w.shape != (m,):
+            raise ValueError('one weight per coreset row')
+        model_id, params = self._ids(beta)
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        grad = np.empty(m)
+        resid = np.empty(S) if want_resid else None
+        N.call('bc_vi_gradient', self.ctx.h, dd.h, _ptr(core), m, int(model_id), _ptr(theta), S, _ptr(params),
+               int(params.shape[0]), _ptr(w), float(sum_scaling), comm, _ptr(grad), _ptr(resid) if want_resid else None)
+        return (grad, resid) if want_resid else grad
+
 
 class DeviceProjector(_DeviceProjectorBase):
     """GPU counterpart of BlackBoxProjector: `project(pts)` returns a DevicePhi."""

@@ -159,6 +159,7 @@ extern "C" int bc_comm_info(const bc_comm* c, int32_t* rank, int32_t* world) {
 
 // enqueue on the context's stream; no host synchronisation
 int bc_comm_all_gather_dev(bc_comm* c, const double* send_dev, double* recv_dev, size_t count) {
+  if (!c->nccl) { bc_set_error("RCCL all-gather: the communicator was aborted"); return -1; }
   const int res = g_rccl.all_gather(send_dev, recv_dev, count, NCCL_FLOAT64, c->nccl, c->ctx->stream);
   if (res != NCCL_SUCCESS) return rccl_fail(res, "ncclAllGather");
   return BC_OK;
@@ -181,29 +182,62 @@ __global__ void k_sum_rank_order(const double* __restrict__ gathered, int world,
   }
 }
 
-extern "C" int bc_comm_sum_doubles(bc_comm* c, const double* in_dev, int64_t count, double* out_host) {
-  if (!c || !in_dev || !out_host || count <= 0) { bc_set_error("bc_comm_sum_doubles: bad argument"); return BC_INVALID_ARGUMENT; }
+// device-to-device part: all-gather + rank-order sum, enqueued on the context's stream; *result_dev stays valid until
+// the next sum through this communicator
+int bc_comm_sum_dev(bc_comm* c, const double* in_dev, int64_t count, const double** result_dev) {
+  if (!c || !in_dev || !result_dev || count <= 0) { bc_set_error("bc_comm_sum_dev: bad argument"); return BC_INVALID_ARGUMENT; }
   if (!c->nccl) { bc_set_error("bc_comm_sum_doubles: the communicator was aborted"); return -1; }
   bc_ctx* ctx = c->ctx;
   BC_HIP(hipSetDevice(ctx->device));
   if ((size_t)count > c->sum_cap) {
+    BC_HIP(hipStreamSynchronize(ctx->stream));
     if (c->sum_buf) (void)hipFree(c->sum_buf);
     c->sum_buf = nullptr;
     c->sum_cap = 0;
     BC_HIP(hipMalloc((void**)&c->sum_buf, (size_t)count * (c->world + 1) * sizeof(double)));
     c->sum_cap = (size_t)count;
   }
-  if ((size_t)count > ctx->pinned_doubles) { bc_set_error("bc_comm_sum_doubles: at most %zu doubles", ctx->pinned_doubles); return BC_INVALID_ARGUMENT; }
   double* gathered = c->sum_buf;
-  double* result = c->sum_buf + (size_t)count * c->world;
+  double* result = c->sum_buf + c->sum_cap * c->world;
   int rc = bc_comm_all_gather_dev(c, in_dev, gathered, (size_t)count);
   if (rc) return rc;
   const int blocks = (int)((count + 255) / 256 < 64 ? (count + 255) / 256 : 64);
   hipLaunchKernelGGL(k_sum_rank_order, dim3(blocks), dim3(256), 0, ctx->stream, gathered, c->world, (long long)count, result);
   BC_HIP(hipGetLastError());
+  *result_dev = result;
+  return BC_OK;
+}
+
+extern "C" int bc_comm_sum_doubles(bc_comm* c, const double* in_dev, int64_t count, double* out_host) {
+  if (!c || !in_dev || !out_host || count <= 0) { bc_set_error("bc_comm_sum_doubles: bad argument"); return BC_INVALID_ARGUMENT; }
+  bc_ctx* ctx = c->ctx;
+  if ((size_t)count > ctx->pinned_doubles) { bc_set_error("bc_comm_sum_doubles: at most %zu doubles", ctx->pinned_doubles); return BC_INVALID_ARGUMENT; }
+  const double* result = nullptr;
+  int rc = bc_comm_sum_dev(c, in_dev, count, &result);
+  if (rc) return rc;
   BC_HIP(hipMemcpyAsync(ctx->pinned, result, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   BC_HIP(hipStreamSynchronize(ctx->stream));
   memcpy(out_host, ctx->pinned, (size_t)count * sizeof(double));
+  return BC_OK;
+}
+
+// Test hook: the rank-order sum on a FABRICATED gathered buffer ([world][count], host), so that the [world][count]
+// indexing and the order of additions are checked for any world size on a single GPU, without a communicator.
+extern "C" int bc_comm_rank_order_sum_selftest(bc_ctx* ctx, const double* gathered_host, int32_t world, int64_t count, double* out_host) {
+  if (!ctx || !gathered_host || !out_host || world < 1 || count <= 0) { bc_set_error("bc_comm_rank_order_sum_selftest: bad argument"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  double* buf = nullptr;
+  BC_HIP(hipMalloc((void**)&buf, (size_t)count * (world + 1) * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(buf, gathered_host, (size_t)count * world * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    const int blocks = (int)((count + 255) / 256 < 64 ? (count + 255) / 256 : 64);
+    hipLaunchKernelGGL(k_sum_rank_order, dim3(blocks), dim3(256), 0, ctx->stream, buf, world, (long long)count, buf + (size_t)count * world);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, buf + (size_t)count * world, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return bc_hip_fail(e, "bc_comm_rank_order_sum_selftest", __FILE__, __LINE__);
   return BC_OK;
 }
 

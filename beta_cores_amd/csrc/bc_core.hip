@@ -45,6 +45,11 @@ extern "C" int bc_ctx_create(int device, void* stream, bc_ctx** out) {
   bc_ctx* c = new bc_ctx();
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
+  c->max_lds = (int)prop.sharedMemPerBlock;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) c->max_lds = v;
+  }
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -67,11 +72,33 @@ static void timer_free(bc_timer& t) {
   t.used = 0;
 }
 
+int bc_scratch_grow(bc_ctx* ctx, bc_scratch* s, size_t doubles) {
+  if (doubles <= s->cap) return BC_OK;
+  BC_HIP(hipStreamSynchronize(ctx->stream));       // an enqueued kernel may still read the old buffer
+  if (s->p) (void)hipFree(s->p);
+  s->p = nullptr;
+  s->cap = 0;
+  const size_t want = doubles + doubles / 2;
+  BC_HIP(hipMalloc((void**)&s->p, want * sizeof(double)));
+  s->cap = want;
+  return BC_OK;
+}
+
 extern "C" int bc_ctx_destroy(bc_ctx* ctx) {
   if (!ctx) return BC_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& t : ctx->timers) timer_free(t);
+  for (auto& ev : ctx->vi_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->colsum_phi) bc_phi_destroy(ctx->colsum_phi);
+  if (ctx->core_phi) bc_phi_destroy(ctx->core_phi);
+  if (ctx->core_data) bc_data_destroy(ctx->core_data);
+  bc_scratch* all[] = {&ctx->proj_theta, &ctx->proj_saux, &ctx->proj_rowaux, &ctx->proj_rowaux2, &ctx->proj_siginv, &ctx->gradx, &ctx->vi_buf,
+                       &ctx->gram[0], &ctx->gram[1], &ctx->gram[2], &ctx->gram[3], &ctx->gram[4]};
+  for (bc_scratch* sc : all)
+    if (sc->p) (void)hipFree(sc->p);
+  if (ctx->proj_pinned) (void)hipHostFree(ctx->proj_pinned);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -294,7 +321,7 @@ int bc_phi_set_rows(bc_phi* p, int64_t n_rows) {
 
 // ONE device allocation per Phi (tiles + all the small side arrays): creating / destroying a Phi is
 // one hipMalloc / hipFree, which matters when small projections are made thousands of times.
-int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out, int64_t cap_rows) {
+int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out, int64_t cap_rows, bool stats_only) {
   bc_phi* p = new bc_phi();
   p->ctx = ctx;
   p->s = s;
@@ -310,8 +337,8 @@ int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_
   const size_t nt = (size_t)p->cap_tiles;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_tiles = take(nt * s * BC_TILE * sizeof(double));
-  const size_t o_norms = take(nt * BC_TILE * sizeof(double));
+  const size_t o_tiles = take(stats_only ? 0 : nt * s * BC_TILE * sizeof(double));
+  const size_t o_norms = take(stats_only ? 0 : nt * BC_TILE * sizeof(double));
   const size_t o_colsum = take((size_t)s * sizeof(double));
   const size_t o_tpart = take(nt * s * sizeof(double));
   const size_t o_stats = take(4 * sizeof(double));
@@ -328,8 +355,8 @@ int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_
     return bc_hip_fail(e, "hipMalloc(phi)", __FILE__, __LINE__);
   }
   char* base = (char*)p->slab;
-  p->tiles = (double*)(base + o_tiles);
-  p->norms = (double*)(base + o_norms);
+  p->tiles = stats_only ? nullptr : (double*)(base + o_tiles);
+  p->norms = stats_only ? nullptr : (double*)(base + o_norms);
   p->colsum = (double*)(base + o_colsum);
   p->tile_part = (double*)(base + o_tpart);
   p->stats = (double*)(base + o_stats);
@@ -459,6 +486,7 @@ __global__ __launch_bounds__(256) void k_stats_stage1(const double* __restrict__
     if (g == 0 && k < s) part2[(size_t)blockIdx.x * s + k] = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
     __syncthreads();
   }
+  if (!norms) return;                 // store-free projection: column sums only (block-uniform)
   double ns = 0.0, nz = 0.0;
   long long r1 = t1 * BC_TILE;
   if (r1 > n_rows) r1 = n_rows;
@@ -499,6 +527,7 @@ __global__ __launch_bounds__(1024) void k_stats_stage2(const double* __restrict_
     }
     __syncthreads();
   }
+  if (!nstat) return;                 // store-free projection: no norm statistics
   // norm statistics: same split over the first 2 x G x ... threads
   double ns = 0.0, nz = 0.0;
   for (int b = threadIdx.x; b < nb; b += blockDim.x) {
@@ -522,6 +551,21 @@ __global__ __launch_bounds__(1024) void k_stats_stage2(const double* __restrict_
     for (int i = 0; i < m; ++i) t += part[i];
     stats[1] = t;
   }
+}
+
+// tile_part -> colsum with the very kernels, grid and order of additions of bc_phi_finish_stats (the column sums of a
+// store-free projection carry the bits the materialised one's would), minus the norm statistics and the host copy
+int bc_phi_reduce_colsum(bc_phi* p) {
+  bc_ctx* ctx = p->ctx;
+  const int nb = p->stat_blocks;
+  const long long chunk = (p->ntiles + nb - 1) / nb;
+  hipLaunchKernelGGL(k_stats_stage1, dim3(nb), dim3(256), 0, ctx->stream, p->tile_part, (long long)p->ntiles, p->s,
+                     (const double*)nullptr, (long long)p->n_rows, chunk > 0 ? chunk : 1, p->part2, p->nstat);
+  BC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_stats_stage2, dim3(1), dim3(1024), 0, ctx->stream, p->part2, (const double*)nullptr, nb, p->s, p->colsum,
+                     p->stats);
+  BC_HIP(hipGetLastError());
+  return BC_OK;
 }
 
 int bc_phi_finish_stats(bc_phi* p) {

@@ -76,12 +76,6 @@ __global__ __launch_bounds__(256) void k_grad_x(GradArgs a) {
   }
 }
 
-struct GradScratch {
-  double* dev = nullptr;
-  size_t cap = 0;
-};
-static GradScratch g_gs[16];
-
 extern "C" int bc_project_grad_x(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                                  const double* params, int32_t n_params, double* out) {
   if (!ctx || !data || !theta || !out || s <= 0 || (n_params > 0 && !params)) {
@@ -118,16 +112,9 @@ extern "C" int bc_project_grad_x(bc_ctx* ctx, const bc_data* data, int model, co
   const size_t n_th = (size_t)s * d, n_sg = siginv ? (size_t)d * d : 0, n_ts = siginv ? n_th : 0, n_xs = siginv ? (size_t)m * d : 0;
   const size_t n_out = (size_t)m * s * w;
   const size_t need = n_th + n_sg + n_ts + n_xs + n_out;
-  GradScratch& gs = g_gs[ctx->device & 15];
-  if (need > gs.cap) {
-    BC_HIP(hipStreamSynchronize(ctx->stream));
-    if (gs.dev) (void)hipFree(gs.dev);
-    gs.dev = nullptr;
-    gs.cap = 0;
-    BC_HIP(hipMalloc((void**)&gs.dev, need * sizeof(double)));
-    gs.cap = need;
-  }
-  double* d_th = gs.dev;
+  int rcs = bc_scratch_grow(ctx, &ctx->gradx, need);      // owned by the context, freed with it
+  if (rcs) return rcs;
+  double* d_th = ctx->gradx.p;
   double* d_sg = d_th + n_th;
   double* d_ts = d_sg + n_sg;
   double* d_xs = d_ts + n_ts;

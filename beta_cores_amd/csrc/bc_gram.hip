@@ -179,26 +179,12 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
   out[(size_t)c * dz + r] = acc;
 }
 
-// grow-only device scratch per GPU: the sampler calls weighted_post on <= M coreset rows thousands of
+// grow-only device scratch, owned by the context: the sampler calls weighted_post on <= M coreset rows thousands of
 // times (bcores.py:39 -> sampler -> weighted_post), a hipMalloc/hipFree pair per call would dominate
-struct GramScratch {
-  double* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // partial, partial_y, out, out_y, w
-  size_t cap[5] = {0, 0, 0, 0, 0};
-};
-static GramScratch g_gram[16];
-
 static int gram_buf(bc_ctx* ctx, int which, size_t doubles, double** out) {
-  GramScratch& sc = g_gram[ctx->device & 15];
-  if (doubles > sc.cap[which]) {
-    BC_HIP(hipStreamSynchronize(ctx->stream));
-    if (sc.buf[which]) (void)hipFree(sc.buf[which]);
-    sc.buf[which] = nullptr;
-    sc.cap[which] = 0;
-    const size_t want = doubles + doubles / 2;
-    BC_HIP(hipMalloc((void**)&sc.buf[which], want * sizeof(double)));
-    sc.cap[which] = want;
-  }
-  *out = sc.buf[which];
+  int rc = bc_scratch_grow(ctx, &ctx->gram[which], doubles);
+  if (rc) return rc;
+  *out = ctx->gram[which].p;
   return BC_OK;
 }
 

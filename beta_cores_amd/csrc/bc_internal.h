@@ -29,6 +29,16 @@ struct bc_timer {
   bool armed = false;      // the launch in progress is being timed
 };
 
+// grow-only device buffer owned by a context (freed in bc_ctx_destroy): scratch of calls that are made thousands of
+// times on coreset-sized inputs, where a hipMalloc / hipFree pair per call would dominate
+struct bc_scratch {
+  double* p = nullptr;
+  size_t cap = 0;                // doubles
+};
+
+// phases of bc_vi_gradient, timed with HIP events when the context's timing is on (bc_ctx_phase_times)
+#define BC_VI_PHASES 5           // upload (Theta, coreset rows, w) | K1 of the coreset rows | K1 over the data rows (store-free) |
+                                 // column-sum reduction (+ rank-order sum over ranks) | M x S algebra + download
 struct bc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -36,9 +46,25 @@ struct bc_ctx {
   int timing = 0;                // 0 = off, n >= 1: every n-th launch of each kernel class is timed
   bc_timer timers[3];
   int n_cu = 256;
+  int max_lds = 64 * 1024;       // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
   double* pinned = nullptr;      // small pinned staging area (host)
   size_t pinned_doubles = 0;
+  // K1 staging (bc_project.hip): zero-padded Theta, per-sample / per-row extras, Siginv; a pinned host mirror
+  bc_scratch proj_theta, proj_saux, proj_rowaux, proj_rowaux2, proj_siginv;
+  double* proj_pinned = nullptr;
+  size_t proj_pinned_cap = 0;
+  bc_scratch gradx;              // bc_project_grad_x
+  bc_scratch gram[5];            // K4: partial, partial_y, out, out_y, w
+  bc_phi* colsum_phi = nullptr;  // store-free K1: a Phi with the per-tile column partials but no tiles / norms
+  bc_phi* core_phi = nullptr;    // bc_vi_gradient: the projection of the <= M coreset rows
+  bc_data* core_data = nullptr;  //                 and their upload slot
+  bc_scratch vi_buf;             // bc_vi_gradient: w | resid | grad
+  hipEvent_t vi_ev[BC_VI_PHASES + 1] = {};
+  double vi_phase_ms[BC_VI_PHASES] = {};
+  int64_t vi_calls_timed = 0;
 };
+
+int bc_scratch_grow(bc_ctx* ctx, bc_scratch* s, size_t doubles);   // contents are NOT kept when it grows
 
 int bc_timer_begin(bc_ctx* ctx, int which);
 int bc_timer_end(bc_ctx* ctx, int which);
@@ -82,9 +108,11 @@ struct bc_phi {
   unsigned* sweep_counter = nullptr;   // arrival counter of the sweep's last-block reduction (kept at 0 between launches)
 };
 
-int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out, int64_t cap_rows = 0);
+int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_phi** out, int64_t cap_rows = 0,
+                 bool stats_only = false);   // stats_only: no tiles, no norms (store-free K1)
 int bc_phi_set_rows(bc_phi* phi, int64_t n_rows);   // 0 if n_rows fits the capacity (state updated), 1 otherwise
 int bc_phi_finish_stats(bc_phi* phi);   // tile_part -> colsum, norm stats (device), then host copy
+int bc_phi_reduce_colsum(bc_phi* phi);  // tile_part -> colsum on the device only: no norm statistics, no host copy, no sync
 int bc_sweep_grid(const bc_phi* phi);
 
 // ------------------------------------------------------------------ device helpers

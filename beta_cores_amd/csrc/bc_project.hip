@@ -42,7 +42,6 @@ __device__ __forceinline__ void bc_store2(double* p, double x, double y) { *rein
 struct ProjArgs {
   const double* z;        // [n_rows][dz]
   const double* theta;    // [nt*16][dk]  zero padded            (MFMA kernel)
-  const double* theta_v;  // [dk][4][SW]  zero padded            (vector-FMA kernel: d-major, one sample quarter per wave)
   const double* saux;     // [nt*16] per-sample extra (gauss: theta^T Siginv theta)
   const double* rowaux;   // [n_rows] per-row extra (gauss: x^T Siginv x) or null
   double* tiles;
@@ -176,9 +175,13 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
 // TL = 0 or 4 "tail" samples beyond the NT tiles (S <= 16*NT + TL): one sample QUAD contracted with
 // v_mfma_f64_4x4x4_4b_f64 (see the loop).  S = 100 (every BASELINE config) thus runs 6 tiles + 1 quad = exactly
 // 100 samples instead of 7 tiles with 12 padded ones.
-template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0>
+// STORE = false: the store-free mode of the gradient loop (bcores.py:141-146 needs `vecs.sum(axis=0)` only): the same
+// contraction, formula, centring and per-tile column partials -- bit for bit -- but neither the tile nor the row norms
+// are written; algorithmic traffic 8*128*Dz B per tile.
+template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0, bool STORE = true>
 __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2) void k_project(ProjArgs a) {
   static_assert(TL == 0 || (TL == 4 && !RAW), "tail: exactly one extra sample quad");
+  static_assert(STORE || !RAW, "the raw passes of S > 256 exist to be stored");
   constexpr int NTHR = 128 / (16 * JT) * 64;
   constexpr int NR = NT * 16 + TL;                // rows of (padded) Theta this kernel contracts with
   constexpr int LDZ = KC + 1;    // odd stride: rows (2j, 2j+1) of a lane pair hit distinct banks
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         tv[jt] = 0.;
         sq = 0.;
       }
-      if (g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
+      if (STORE && g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
     }
   } else {
 #pragma unroll
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     }
     sq += __shfl_xor(sq, 16, BC_WAVE);
     sq += __shfl_xor(sq, 32, BC_WAVE);
-    if (g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
+    if (STORE && g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
   }
   }
   KSTAMP(21);
@@ -538,10 +541,10 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   auto put = [&](int s0, double v0, double v1) __attribute__((always_inline)) {       // sample s0 + g of this lane's row(s)
     double cp;
     if (JT == 2) {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bc_u4v, (bc_d2v){v0, v1}), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
+      if (STORE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bc_u4v, (bc_d2v){v0, v1}), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
       cp = v0 + v1;
     } else {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bc_u2v, v0), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
+      if (STORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bc_u2v, v0), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
       cp = v0;
     }
     // per-tile column partial (K2): sum over the tile's rows.  JT == 2 kernels park each lane's pair sum in LDS
@@ -631,172 +634,6 @@ __global__ __launch_bounds__(256) void k_center_tiles(double* __restrict__ tiles
   if (tid < BC_TILE) norms[t * BC_TILE + tid] = sqrt(psum[tid] + psum[128 + tid]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1, vector-FMA formulation (S <= 100): measured on MI355X the fp64 vector pipe sustains ~56 TF in
-// this register blocking against ~47 TF for v_mfma_f64_16x16x4_f64 (tools/valu_f64_sgpr.hip,
-// tools/mfma_f64_peak.hip; both DVFS-limited), and it needs no padding of S to a multiple of 16.
-//   block = 256 rows (two Phi tiles), 4 waves; wave w owns the sample quarter [w*SW, (w+1)*SW);
-//   lane l owns rows 2l, 2l+1 (tile A) and 128+2l, 129+2l (tile B)  ->  acc[4][SW] in VGPRs;
-//   per feature d: 2 x ds_read_b128 fetch the lane's four x values from the LDS slab [KC][258],
-//   theta[d][quarter] is wave-uniform: s_load into SGPRs, used directly as the FMA's scalar operand.
-// The Z slab is staged with buffer loads (rows past N read as 0) and prefetched one slab ahead.
-template <int MODEL, int SW>
-__global__ __launch_bounds__(256, 2) void k_project_v(ProjArgs a) {
-  constexpr int KC = 8;
-  constexpr int LDR = 258;               // slab row length (256 rows + 2): keeps the 16-byte reads aligned
-  __shared__ double Zl[KC * LDR];
-  __shared__ double rs0[4 * 256];        // cross-wave row reductions: sum / sum of squares
-  __shared__ double rs1[4 * 256];        // min
-  __shared__ double rs2[4 * 256];        // max
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long blk = blockIdx.x;
-  const long long r0 = blk * 256;
-  const int S = a.s;
-
-  double acc[4][SW];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-    for (int j = 0; j < SW; ++j) acc[rr][j] = 0.;
-
-  const int zc = tid % KC, zrw = tid / KC;       // staging: thread -> (row zrw + 32*q, column zc)
-  const long long rows_left = a.n_rows - r0;
-  const long long rows_here = rows_left < 256 ? rows_left : 256;
-  const auto zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0,
-                                                       (int)(rows_here * a.dz * 8), 0x00020000);
-  double zr[KC];
-  auto load_chunk = [&](int d0) {
-    const int col = min(d0 + zc, a.d - 1);
-    const int voff = (zrw * a.dz + col) * 8;
-#pragma unroll
-    for (int q = 0; q < KC; ++q)
-      zr[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrsrc, voff, q * 32 * a.dz * 8, BC_K1_Z_AUX));
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int q = 0; q < KC; ++q) Zl[zc * LDR + zrw + 32 * q] = zr[q];
-  };
-
-  const int nchunks = a.dk / KC;
-  load_chunk(0);
-  for (int c = 0; c < nchunks; ++c) {
-    store_chunk();
-    __syncthreads();
-    if (c + 1 < nchunks) load_chunk((c + 1) * KC);
-    const double* __restrict__ th = a.theta_v + ((size_t)c * KC * 4 + w) * SW;   // wave-uniform
-#pragma unroll 1
-    for (int dd = 0; dd < KC; ++dd) {
-      const double2 xa = *reinterpret_cast<const double2*>(Zl + dd * LDR + 2 * lane);
-      const double2 xb = *reinterpret_cast<const double2*>(Zl + dd * LDR + 128 + 2 * lane);
-      const double* __restrict__ t = th + (size_t)dd * 4 * SW;
-#pragma unroll
-      for (int j = 0; j < SW; ++j) {
-        const double tv = t[j];
-        acc[0][j] = fma(xa.x, tv, acc[0][j]);
-        acc[1][j] = fma(xa.y, tv, acc[1][j]);
-        acc[2][j] = fma(xb.x, tv, acc[2][j]);
-        acc[3][j] = fma(xb.y, tv, acc[3][j]);
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue
-  const int lrow[4] = {2 * lane, 2 * lane + 1, 128 + 2 * lane, 129 + 2 * lane};
-  bool live[4];
-  double ra[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const long long gr = r0 + lrow[rr];
-    live[rr] = gr < a.n_rows;
-    ra[rr] = 0.;
-    if (live[rr]) {
-      if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra[rr] = a.z[(size_t)gr * a.dz + a.d];
-      else if (MODEL >= BC_MODEL_GAUSS_LL) ra[rr] = a.rowaux[gr];
-    }
-  }
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    double sum = 0., vmin = INFINITY, vmax = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < SW; ++j) {
-      const int sidx = w * SW + j;
-      double v = 0.;
-      if (sidx < S && live[rr]) {
-        v = bc_model_value<MODEL>(acc[rr][j], ra[rr], (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[sidx] : 0., a.c);
-        vmin = fmin(vmin, v);
-        vmax = fmax(vmax, v);
-      }
-      acc[rr][j] = v;
-      sum += v;
-    }
-    rs0[w * 256 + lrow[rr]] = sum;
-    rs1[w * 256 + lrow[rr]] = vmin;
-    rs2[w * 256 + lrow[rr]] = vmax;
-  }
-  __syncthreads();
-  double mean[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = lrow[rr];
-    const double tot = ((rs0[r] + rs0[256 + r]) + rs0[512 + r]) + rs0[768 + r];
-    const double mn = fmin(fmin(rs1[r], rs1[256 + r]), fmin(rs1[512 + r], rs1[768 + r]));
-    const double mx = fmax(fmax(rs2[r], rs2[256 + r]), fmax(rs2[512 + r], rs2[768 + r]));
-    mean[rr] = ((mn == mx) ? bc_np_sum_const_256(mx, S) : tot) / (double)S;      // constant row: NumPy's rounding of the mean
-  }
-  __syncthreads();
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    double sq = 0.;
-#pragma unroll
-    for (int j = 0; j < SW; ++j) {
-      const int sidx = w * SW + j;
-      double v = acc[rr][j];
-      v = (sidx < S && live[rr]) ? v - mean[rr] : 0.;
-      acc[rr][j] = v;
-      sq = fma(v, v, sq);
-    }
-    rs0[w * 256 + lrow[rr]] = sq;
-  }
-  __syncthreads();
-  const long long tileA = 2 * blk, tileB = 2 * blk + 1;
-  const bool hasB = tileB * BC_TILE < a.n_rows;
-  if (w == 0) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int r = lrow[rr];
-      if (rr < 2 || hasB) a.norms[r0 + r] = sqrt(((rs0[r] + rs0[256 + r]) + rs0[512 + r]) + rs0[768 + r]);
-    }
-  }
-  double* tA = a.tiles + (size_t)tileA * S * BC_TILE + 2 * lane;
-  double* tB = a.tiles + (size_t)tileB * S * BC_TILE + 2 * lane;
-#pragma unroll
-  for (int j = 0; j < SW; ++j) {
-    const int sidx = w * SW + j;
-    if (sidx < S) {
-      bc_store2(tA + (size_t)sidx * BC_TILE, acc[0][j], acc[1][j]);
-      if (hasB) bc_store2(tB + (size_t)sidx * BC_TILE, acc[2][j], acc[3][j]);
-    }
-    // column partials (K2): one per 128-row tile, summed over the wave's 64 lanes
-    double cpa = bc_wave_sum(acc[0][j] + acc[1][j]);
-    double cpb = bc_wave_sum(acc[2][j] + acc[3][j]);
-    if (lane == 0 && sidx < S) {
-      a.tile_part[(size_t)tileA * S + sidx] = cpa;
-      if (hasB) a.tile_part[(size_t)tileB * S + sidx] = cpb;
-    }
-  }
-}
-
-template <int MODEL>
-static int launch_project_v(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int sw) {
-  const unsigned grid = (unsigned)((ntiles + 1) / 2);
-  if (sw <= 16) hipLaunchKernelGGL((k_project_v<MODEL, 16>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_project_v<MODEL, 25>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  BC_HIP(hipGetLastError());
-  return BC_OK;
-}
-
 // x^T Siginv x per row, in the reference's order: (x * (x.dot(Siginv))).sum(axis=1)   (gaussian.py:10).
 // Siginv is staged in LDS when it fits (use_lds), otherwise read through the caches (wave-uniform loads).
 __global__ __launch_bounds__(256) void k_row_quadform(const double* __restrict__ z, long long n_rows, int d,
@@ -825,40 +662,14 @@ __global__ __launch_bounds__(256) void k_row_quadform(const double* __restrict__
 static int bc_project_wide(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                            const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
 
-struct ProjScratch {
-  double* theta = nullptr;
-  size_t theta_cap = 0;
-  double* saux = nullptr;
-  size_t saux_cap = 0;
-  double* theta_v = nullptr;
-  size_t theta_v_cap = 0;
-  double* rowaux = nullptr;
-  size_t rowaux_cap = 0;
-  double* siginv = nullptr;
-  size_t siginv_cap = 0;
-  double* pinned = nullptr;
-  size_t pinned_cap = 0;
-};
-
-static ProjScratch g_scr[16];   // per device
-
-static int grow_dev(double** p, size_t* cap, size_t need) {
-  if (need <= *cap) return BC_OK;
-  if (*p) (void)hipFree(*p);
-  *p = nullptr;
-  *cap = 0;
-  BC_HIP(hipMalloc((void**)p, need * sizeof(double)));
-  *cap = need;
-  return BC_OK;
-}
-
-static int grow_pinned(ProjScratch& sc, size_t need) {
-  if (need <= sc.pinned_cap) return BC_OK;
-  if (sc.pinned) (void)hipHostFree(sc.pinned);
-  sc.pinned = nullptr;
-  sc.pinned_cap = 0;
-  BC_HIP(hipHostMalloc((void**)&sc.pinned, need * sizeof(double), hipHostMallocDefault));
-  sc.pinned_cap = need;
+static int grow_pinned(bc_ctx* ctx, size_t need) {
+  if (need <= ctx->proj_pinned_cap) return BC_OK;
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->proj_pinned) (void)hipHostFree(ctx->proj_pinned);
+  ctx->proj_pinned = nullptr;
+  ctx->proj_pinned_cap = 0;
+  BC_HIP(hipHostMalloc((void**)&ctx->proj_pinned, need * sizeof(double), hipHostMallocDefault));
+  ctx->proj_pinned_cap = need;
   return BC_OK;
 }
 
@@ -919,55 +730,82 @@ static int model_constants(int model, const double* p, int np, int d, double* c,
   return BC_INVALID_ARGUMENT;
 }
 
-template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0>
+enum { PROJ_FULL = 0, PROJ_RAW = 1, PROJ_COLSUM = 2 };
+
+template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0, bool STORE = true>
 static int launch_project(bc_ctx* ctx, const ProjArgs& a, long long ntiles) {
   size_t lds = (size_t)(128 * (KC + 1) + (NT * 16 + TL) * (KC + 2)) * sizeof(double);
 #ifdef BC_K1_STAMPS
   if (getenv("BC_K1_EXTRA_LDS")) lds += (size_t)atoi(getenv("BC_K1_EXTRA_LDS"));   // diagnostic: fewer blocks per CU
 #endif
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT, RAW, TL>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+  if (lds > (size_t)ctx->max_lds) {
+    bc_set_error("bc_project: this instantiation stages %zu bytes of LDS per block, the device allows %d", lds, ctx->max_lds);
+    return BC_INVALID_ARGUMENT;
   }
-  hipLaunchKernelGGL((k_project<MODEL, NT, KC, JT, RAW, TL>), dim3((unsigned)ntiles), dim3(128 / (16 * JT) * 64), lds, ctx->stream, a);
+  static unsigned attr_done = 0;            // per instantiation, one bit per device ordinal
+  const unsigned bit = 1u << (ctx->device & 31);
+  if (!(attr_done & bit) && lds > 64 * 1024) {
+    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project<MODEL, NT, KC, JT, RAW, TL, STORE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done |= bit;
+  }
+  hipLaunchKernelGGL((k_project<MODEL, NT, KC, JT, RAW, TL, STORE>), dim3((unsigned)ntiles), dim3(128 / (16 * JT) * 64), lds, ctx->stream, a);
   BC_HIP(hipGetLastError());
   return BC_OK;
 }
 
-template <int MODEL>
+template <int MODEL, bool STORE>
 static int launch_project_nt(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int ntsel) {
   switch (ntsel) {
-    case 4: return launch_project<MODEL, 4, 32, 2>(ctx, a, ntiles);
-    case 6: return launch_project<MODEL, 6, 32, 2, false, 4>(ctx, a, ntiles);      // 96 < S <= 100: 6 tiles + 1 sample quad
-    case 7: {
-      static const int jt1 = getenv("BC_K1_JT1") ? atoi(getenv("BC_K1_JT1")) : 0;
-      if (jt1) return launch_project<MODEL, 7, 32, 1>(ctx, a, ntiles);
-      return launch_project<MODEL, 7, 32, 2>(ctx, a, ntiles);
-    }
-    case 13: return launch_project<MODEL, 13, 16, 1>(ctx, a, ntiles);
-    default: return launch_project<MODEL, 16, 16, 1>(ctx, a, ntiles);
+    case 4: return launch_project<MODEL, 4, 32, 2, false, 0, STORE>(ctx, a, ntiles);
+    case 6: return launch_project<MODEL, 6, 32, 2, false, 4, STORE>(ctx, a, ntiles);      // 96 < S <= 100: 6 tiles + 1 sample quad
+    case 7: return launch_project<MODEL, 7, 32, 2, false, 0, STORE>(ctx, a, ntiles);
+    case 13: return launch_project<MODEL, 13, 16, 1, false, 0, STORE>(ctx, a, ntiles);
+    default: return launch_project<MODEL, 16, 16, 1, false, 0, STORE>(ctx, a, ntiles);
   }
 }
 
-// One launch of the projection.  raw == false: the whole of Phi (s == s_total <= 256), centred, with
-// norms and column partials.  raw == true: samples [s_off, s_off + s) of s_total, un-centred.
-static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
-                        const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout,
-                        int32_t s_total, int32_t s_off, bool raw) {
-  if (!ctx || !data || !theta || !inout || s <= 0 || (n_params > 0 && !params)) {
-    bc_set_error("bc_project: bad argument");
-    return BC_INVALID_ARGUMENT;
+template <bool STORE>
+static int launch_project_model(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int model, int ntsel) {
+  switch (model) {
+    case BC_MODEL_LINREG_LL: return launch_project_nt<BC_MODEL_LINREG_LL, STORE>(ctx, a, ntiles, ntsel);
+    case BC_MODEL_LINREG_BETA: return launch_project_nt<BC_MODEL_LINREG_BETA, STORE>(ctx, a, ntiles, ntsel);
+    case BC_MODEL_LOGISTIC_LL: return launch_project_nt<BC_MODEL_LOGISTIC_LL, STORE>(ctx, a, ntiles, ntsel);
+    case BC_MODEL_LOGISTIC_BETA: return launch_project_nt<BC_MODEL_LOGISTIC_BETA, STORE>(ctx, a, ntiles, ntsel);
+    case BC_MODEL_GAUSS_LL: return launch_project_nt<BC_MODEL_GAUSS_LL, STORE>(ctx, a, ntiles, ntsel);
+    case BC_MODEL_GAUSS_BETA: return launch_project_nt<BC_MODEL_GAUSS_BETA, STORE>(ctx, a, ntiles, ntsel);
+    default: return launch_project_nt<BC_MODEL_GAUSS_BETA_GRAD, STORE>(ctx, a, ntiles, ntsel);
   }
-  if (data->ctx != ctx) { bc_set_error("bc_project: data belongs to another context"); return BC_INVALID_ARGUMENT; }
-  if (model < 0 || model > BC_MODEL_GAUSS_BETA_GRAD) { bc_set_error("bc_project: unknown model %d", model); return BC_INVALID_ARGUMENT; }
-  if (s > 256) { bc_set_error("bc_project: internal: a single pass handles at most 256 samples"); return BC_INVALID_ARGUMENT; }
-  const bool has_y = (model == BC_MODEL_LINREG_LL || model == BC_MODEL_LINREG_BETA);
-  const int d = data->dz - (has_y ? 1 : 0);
+}
+
+static int launch_project_raw(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int model) {
+  switch (model) {
+    case BC_MODEL_LINREG_LL: return launch_project<BC_MODEL_LINREG_LL, 16, 16, 1, true>(ctx, a, ntiles);
+    case BC_MODEL_LINREG_BETA: return launch_project<BC_MODEL_LINREG_BETA, 16, 16, 1, true>(ctx, a, ntiles);
+    case BC_MODEL_LOGISTIC_LL: return launch_project<BC_MODEL_LOGISTIC_LL, 16, 16, 1, true>(ctx, a, ntiles);
+    case BC_MODEL_LOGISTIC_BETA: return launch_project<BC_MODEL_LOGISTIC_BETA, 16, 16, 1, true>(ctx, a, ntiles);
+    case BC_MODEL_GAUSS_LL: return launch_project<BC_MODEL_GAUSS_LL, 16, 16, 1, true>(ctx, a, ntiles);
+    case BC_MODEL_GAUSS_BETA: return launch_project<BC_MODEL_GAUSS_BETA, 16, 16, 1, true>(ctx, a, ntiles);
+    default: return launch_project<BC_MODEL_GAUSS_BETA_GRAD, 16, 16, 1, true>(ctx, a, ntiles);
+  }
+}
+
+// ---- a projection in two steps: the plan (model constants, Theta zero-padded and uploaded: once per Theta) and the
+// launches that use it (one per set of rows: bc_vi_gradient projects the data rows and the coreset rows with one plan)
+struct ProjPlan {
+  ProjArgs a;             // constants, theta, saux, d, dk, s, model filled in; the per-launch fields are set by plan_launch
+  int model = 0, s = 0, d = 0, ntsel = 0;
+  bool raw = false, has_siginv = false;
+};
+
+static bool model_has_y(int model) { return model == BC_MODEL_LINREG_LL || model == BC_MODEL_LINREG_BETA; }
+
+static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, const double* params, int32_t n_params,
+                      int dz, bool raw, ProjPlan* pl) {
+  if (s <= 0 || s > 256) { bc_set_error("bc_project: internal: a single pass handles 1..256 samples"); return BC_INVALID_ARGUMENT; }
+  const int d = dz - (model_has_y(model) ? 1 : 0);
   if (d <= 0) { bc_set_error("bc_project: data rows too short for this model"); return BC_INVALID_ARGUMENT; }
-  BC_HIP(hipSetDevice(ctx->device));
-  ProjArgs a;
+  ProjArgs& a = pl->a;
   memset(&a, 0, sizeof(a));
 #ifdef BC_K1_STAMPS
   a.stamps = getenv("BC_K1_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("BC_K1_STAMP_PTR"), nullptr, 10) : nullptr;
@@ -977,46 +815,23 @@ static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const doubl
     bc_set_error("bc_project: model %d expects a different number of parameters than %d (d = %d)", model, n_params, d);
     return BC_INVALID_ARGUMENT;
   }
-  // output handle: reuse buffers when the shape matches
-  bc_phi* phi = *inout;
-  if (phi && (phi->ctx != ctx || phi->s != s_total || bc_phi_set_rows(phi, data->n_rows) != 0)) {
-    bc_set_error("bc_project: *inout has a different S or too little row capacity; pass NULL to allocate");
-    return BC_INVALID_ARGUMENT;
-  }
-  bool fresh = false;
-  if (!phi) {
-    int rc = bc_phi_alloc(ctx, data->n_rows, s_total, row_offset, &phi);
-    if (rc) return rc;
-    fresh = true;
-  }
-  phi->row_offset = row_offset;
-  phi->stats_valid = false;
-
   const int nt = (s + 15) / 16;
   static const int no_tail = getenv("BC_K1_NOTAIL") ? atoi(getenv("BC_K1_NOTAIL")) : 0;
-  const bool tail = !raw && s > 96 && s <= 100 && !no_tail;      // 6 MFMA tiles + 4 vector-pipe samples
+  const bool tail = !raw && s > 96 && s <= 100 && !no_tail;      // 6 MFMA tiles + one sample quad
   const int NTsel = raw ? 16 : tail ? 6 : nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 16;
   const int NRsel = NTsel * 16 + (tail ? 4 : 0);                 // rows of the zero-padded Theta / saux
-  // The vector-FMA kernel is parity-clean but measured SLOWER than the MFMA kernel in round 1
-  // (N=4M, D=128: 3.73 ms vs 3.11 ms; its scalar theta loads are not software-pipelined yet), so it is
-  // opt-in: BC_K1_VALU=1.
-  static const int want_valu = getenv("BC_K1_VALU") ? atoi(getenv("BC_K1_VALU")) : 0;
-  const bool use_valu = s <= 100 && want_valu && !raw;    // vector-FMA kernel: sample quarters of <= 25
-  const int SWv = s <= 64 ? 16 : 25;
-  const int KC = NTsel <= 7 ? 32 : 16;                    // dk is a multiple of 8 (the VALU kernel's chunk) either way
+  const int KC = NTsel <= 7 ? 32 : 16;
   const int dk = ((d + KC - 1) / KC) * KC;
-  ProjScratch& sc = g_scr[ctx->device & 15];
   const size_t th_n = (size_t)NRsel * dk, sa_n = (size_t)NRsel;
-  const size_t thv_n = use_valu ? (size_t)dk * 4 * SWv : 0;
-  int rc = grow_dev(&sc.theta, &sc.theta_cap, th_n);
-  if (!rc) rc = grow_dev(&sc.saux, &sc.saux_cap, sa_n);
-  if (!rc && use_valu) rc = grow_dev(&sc.theta_v, &sc.theta_v_cap, thv_n);
-  if (!rc) rc = grow_pinned(sc, th_n + sa_n + (siginv ? (size_t)d * d : 0) + thv_n);
-  if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
+  int rc = bc_scratch_grow(ctx, &ctx->proj_theta, th_n);
+  if (!rc) rc = bc_scratch_grow(ctx, &ctx->proj_saux, sa_n);
+  if (!rc && siginv) rc = bc_scratch_grow(ctx, &ctx->proj_siginv, (size_t)d * d);
+  if (!rc) rc = grow_pinned(ctx, th_n + sa_n + (siginv ? (size_t)d * d : 0));
+  if (rc) return rc;
   // make sure an earlier launch is no longer reading the pinned staging area
   BC_HIP(hipStreamSynchronize(ctx->stream));
-  double* hth = sc.pinned;
-  double* hsa = sc.pinned + th_n;
+  double* hth = ctx->proj_pinned;
+  double* hsa = ctx->proj_pinned + th_n;
   memset(hth, 0, (th_n + sa_n) * sizeof(double));
   if (siginv) {
     // Theta' = (Siginv . Theta^T)^T  so that the contraction yields x^T Siginv theta (gaussian.py:12),
@@ -1038,92 +853,102 @@ static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const doubl
   } else {
     for (int q = 0; q < s; ++q) memcpy(hth + (size_t)q * dk, theta + (size_t)q * d, (size_t)d * sizeof(double));
   }
-  hipError_t e = hipMemcpyAsync(sc.theta, hth, th_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(sc.saux, hsa, sa_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && use_valu) {
-    // d-major copy for the scalar loads of the vector-FMA kernel: [dk][4 quarters][SW], zero padded
-    double* hv = sc.pinned + th_n + sa_n + (siginv ? (size_t)d * d : 0);
-    memset(hv, 0, thv_n * sizeof(double));
-    for (int q = 0; q < s; ++q) {
-      const int wq = q / SWv, jq = q % SWv;
-      for (int aa = 0; aa < d; ++aa) hv[((size_t)aa * 4 + wq) * SWv + jq] = hth[(size_t)q * dk + aa];
-    }
-    e = hipMemcpyAsync(sc.theta_v, hv, thv_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  }
-  a.rowaux = nullptr;
-  if (e == hipSuccess && siginv && data->n_rows > 0) {
-    rc = grow_dev(&sc.rowaux, &sc.rowaux_cap, (size_t)data->n_rows);
-    if (!rc) rc = grow_dev(&sc.siginv, &sc.siginv_cap, (size_t)d * d);
-    if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
-    double* hsi = sc.pinned + th_n + sa_n;
+  BC_HIP(hipMemcpyAsync(ctx->proj_theta.p, hth, th_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  BC_HIP(hipMemcpyAsync(ctx->proj_saux.p, hsa, sa_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (siginv) {
+    double* hsi = ctx->proj_pinned + th_n + sa_n;
     memcpy(hsi, siginv, (size_t)d * d * sizeof(double));
-    e = hipMemcpyAsync(sc.siginv, hsi, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-      const int use_lds = (size_t)d * d * sizeof(double) <= 60 * 1024;
-      long long blocks = (data->n_rows + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(k_row_quadform, dim3((unsigned)blocks), dim3(256), use_lds ? (size_t)d * d * sizeof(double) : 0,
-                         ctx->stream, data->z, (long long)data->n_rows, d, sc.siginv, sc.rowaux, use_lds);
-      e = hipGetLastError();
-      a.rowaux = sc.rowaux;
-    }
+    BC_HIP(hipMemcpyAsync(ctx->proj_siginv.p, hsi, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
-  if (e != hipSuccess) { if (fresh) bc_phi_destroy(phi); return bc_hip_fail(e, "bc_project staging", __FILE__, __LINE__); }
+  a.theta = ctx->proj_theta.p;
+  a.saux = ctx->proj_saux.p;
+  a.d = d;
+  a.dk = dk;
+  a.s = s;
+  a.model = model;
+  pl->model = model;
+  pl->s = s;
+  pl->d = d;
+  pl->ntsel = NTsel;
+  pl->raw = raw;
+  pl->has_siginv = siginv != nullptr;
+  return BC_OK;
+}
 
+// One launch of a staged projection over `data`'s rows.  mode PROJ_FULL: the whole of Phi (s == s_total <= 256),
+// centred, with norms and column partials.  PROJ_RAW: samples [s_off, s_off + s) of s_total, un-centred.
+// PROJ_COLSUM: `phi` is a stats-only Phi: column partials only.  rowaux: the scratch that receives x^T Siginv x.
+static int plan_launch(bc_ctx* ctx, const ProjPlan& pl, const bc_data* data, bc_phi* phi, int mode, int32_t s_total,
+                       int32_t s_off, bc_scratch* rowaux) {
+  ProjArgs a = pl.a;
+  a.rowaux = nullptr;
+  if (pl.has_siginv && data->n_rows > 0) {
+    int rc = bc_scratch_grow(ctx, rowaux, (size_t)data->n_rows);
+    if (rc) return rc;
+    const int d = pl.d;
+    const int use_lds = (size_t)d * d * sizeof(double) <= 60 * 1024;
+    long long blocks = (data->n_rows + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_row_quadform, dim3((unsigned)blocks), dim3(256), use_lds ? (size_t)d * d * sizeof(double) : 0,
+                       ctx->stream, data->z, (long long)data->n_rows, d, ctx->proj_siginv.p, rowaux->p, use_lds);
+    BC_HIP(hipGetLastError());
+    a.rowaux = rowaux->p;
+  }
   a.z = data->z;
-  a.theta = sc.theta;
-  a.theta_v = sc.theta_v;
-  a.saux = sc.saux;
   a.tiles = phi->tiles;
   a.norms = phi->norms;
   a.tile_part = phi->tile_part;
   a.n_rows = data->n_rows;
   a.dz = data->dz;
-  a.d = d;
-  a.dk = dk;
-  a.s = s;
   a.s_total = s_total;
   a.s_off = s_off;
-  a.model = model;
-  rc = BC_OK;
-  if (phi->ntiles > 0) {
-    rc = bc_timer_begin(ctx, 1);
-    if (!rc && raw) {
-      switch (model) {
-        case BC_MODEL_LINREG_LL: rc = launch_project<BC_MODEL_LINREG_LL, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
-        case BC_MODEL_LINREG_BETA: rc = launch_project<BC_MODEL_LINREG_BETA, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
-        case BC_MODEL_LOGISTIC_LL: rc = launch_project<BC_MODEL_LOGISTIC_LL, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
-        case BC_MODEL_LOGISTIC_BETA: rc = launch_project<BC_MODEL_LOGISTIC_BETA, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
-        case BC_MODEL_GAUSS_LL: rc = launch_project<BC_MODEL_GAUSS_LL, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
-        case BC_MODEL_GAUSS_BETA: rc = launch_project<BC_MODEL_GAUSS_BETA, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
-        default: rc = launch_project<BC_MODEL_GAUSS_BETA_GRAD, 16, 16, 1, true>(ctx, a, phi->ntiles); break;
-      }
-    } else if (!rc && use_valu) {
-      switch (model) {
-        case BC_MODEL_LINREG_LL: rc = launch_project_v<BC_MODEL_LINREG_LL>(ctx, a, phi->ntiles, SWv); break;
-        case BC_MODEL_LINREG_BETA: rc = launch_project_v<BC_MODEL_LINREG_BETA>(ctx, a, phi->ntiles, SWv); break;
-        case BC_MODEL_LOGISTIC_LL: rc = launch_project_v<BC_MODEL_LOGISTIC_LL>(ctx, a, phi->ntiles, SWv); break;
-        case BC_MODEL_LOGISTIC_BETA: rc = launch_project_v<BC_MODEL_LOGISTIC_BETA>(ctx, a, phi->ntiles, SWv); break;
-        case BC_MODEL_GAUSS_LL: rc = launch_project_v<BC_MODEL_GAUSS_LL>(ctx, a, phi->ntiles, SWv); break;
-        case BC_MODEL_GAUSS_BETA: rc = launch_project_v<BC_MODEL_GAUSS_BETA>(ctx, a, phi->ntiles, SWv); break;
-        default: rc = launch_project_v<BC_MODEL_GAUSS_BETA_GRAD>(ctx, a, phi->ntiles, SWv); break;
-      }
-    } else if (!rc) {
-      switch (model) {
-        case BC_MODEL_LINREG_LL: rc = launch_project_nt<BC_MODEL_LINREG_LL>(ctx, a, phi->ntiles, NTsel); break;
-        case BC_MODEL_LINREG_BETA: rc = launch_project_nt<BC_MODEL_LINREG_BETA>(ctx, a, phi->ntiles, NTsel); break;
-        case BC_MODEL_LOGISTIC_LL: rc = launch_project_nt<BC_MODEL_LOGISTIC_LL>(ctx, a, phi->ntiles, NTsel); break;
-        case BC_MODEL_LOGISTIC_BETA: rc = launch_project_nt<BC_MODEL_LOGISTIC_BETA>(ctx, a, phi->ntiles, NTsel); break;
-        case BC_MODEL_GAUSS_LL: rc = launch_project_nt<BC_MODEL_GAUSS_LL>(ctx, a, phi->ntiles, NTsel); break;
-        case BC_MODEL_GAUSS_BETA: rc = launch_project_nt<BC_MODEL_GAUSS_BETA>(ctx, a, phi->ntiles, NTsel); break;
-        default: rc = launch_project_nt<BC_MODEL_GAUSS_BETA_GRAD>(ctx, a, phi->ntiles, NTsel); break;
-      }
-    }
-    if (!rc) rc = bc_timer_end(ctx, 1);
-  } else {
-    e = hipMemsetAsync(phi->norms, 0, BC_TILE * sizeof(double), ctx->stream);
-    if (e != hipSuccess) rc = bc_hip_fail(e, "memset", __FILE__, __LINE__);
+  if (phi->ntiles <= 0) {
+    if (phi->norms) BC_HIP(hipMemsetAsync(phi->norms, 0, BC_TILE * sizeof(double), ctx->stream));
+    return BC_OK;
   }
+  int rc = bc_timer_begin(ctx, 1);
+  if (rc) return rc;
+  if (mode == PROJ_RAW) rc = launch_project_raw(ctx, a, phi->ntiles, pl.model);
+  else if (mode == PROJ_COLSUM) rc = launch_project_model<false>(ctx, a, phi->ntiles, pl.model, pl.ntsel);
+  else rc = launch_project_model<true>(ctx, a, phi->ntiles, pl.model, pl.ntsel);
+  if (!rc) rc = bc_timer_end(ctx, 1);
+  return rc;
+}
+
+static int project_check(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                         const double* params, int32_t n_params, const char* who) {
+  if (!ctx || !data || !theta || s <= 0 || (n_params > 0 && !params)) { bc_set_error("%s: bad argument", who); return BC_INVALID_ARGUMENT; }
+  if (data->ctx != ctx) { bc_set_error("%s: data belongs to another context", who); return BC_INVALID_ARGUMENT; }
+  if (model < 0 || model > BC_MODEL_GAUSS_BETA_GRAD) { bc_set_error("%s: unknown model %d", who, model); return BC_INVALID_ARGUMENT; }
+  return BC_OK;
+}
+
+// raw == false: the whole of Phi (s == s_total <= 256).  raw == true: samples [s_off, s_off + s) of s_total, un-centred.
+static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                        const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout,
+                        int32_t s_total, int32_t s_off, bool raw) {
+  int rc = project_check(ctx, data, model, theta, s, params, n_params, "bc_project");
+  if (rc) return rc;
+  if (!inout) { bc_set_error("bc_project: bad argument"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  ProjPlan pl;
+  rc = plan_stage(ctx, model, theta, s, params, n_params, data->dz, raw, &pl);
+  if (rc) return rc;
+  // output handle: reuse buffers when the shape matches
+  bc_phi* phi = *inout;
+  if (phi && (phi->ctx != ctx || phi->s != s_total || !phi->tiles || bc_phi_set_rows(phi, data->n_rows) != 0)) {
+    bc_set_error("bc_project: *inout has a different S or too little row capacity; pass NULL to allocate");
+    return BC_INVALID_ARGUMENT;
+  }
+  bool fresh = false;
+  if (!phi) {
+    rc = bc_phi_alloc(ctx, data->n_rows, s_total, row_offset, &phi);
+    if (rc) return rc;
+    fresh = true;
+  }
+  phi->row_offset = row_offset;
+  phi->stats_valid = false;
+  rc = plan_launch(ctx, pl, data, phi, raw ? PROJ_RAW : PROJ_FULL, s_total, s_off, &ctx->proj_rowaux);
   if (!rc && !raw) rc = bc_phi_finish_stats(phi);
   if (rc) { if (fresh) bc_phi_destroy(phi); return rc; }
   *inout = phi;
@@ -1133,8 +958,7 @@ static int project_impl(bc_ctx* ctx, const bc_data* data, int model, const doubl
 // S > 256: passes of <= 256 samples write un-centred values, then one centring pass over Phi.
 static int bc_project_wide(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                            const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout) {
-  const bool has_y = (model == BC_MODEL_LINREG_LL || model == BC_MODEL_LINREG_BETA);
-  const int d = data->dz - (has_y ? 1 : 0);
+  const int d = data->dz - (model_has_y(model) ? 1 : 0);
   bc_phi* phi = *inout;
   const bool fresh = phi == nullptr;
   for (int s_off = 0; s_off < s; s_off += 256) {
@@ -1156,12 +980,204 @@ static int bc_project_wide(bc_ctx* ctx, const bc_data* data, int model, const do
 
 extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                           const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout) {
-  if (!ctx || !data || !theta || !inout || s <= 0 || (n_params > 0 && !params)) {
-    bc_set_error("bc_project: bad argument");
-    return BC_INVALID_ARGUMENT;
-  }
-  if (data->ctx != ctx) { bc_set_error("bc_project: data belongs to another context"); return BC_INVALID_ARGUMENT; }
-  if (model < 0 || model > BC_MODEL_GAUSS_BETA_GRAD) { bc_set_error("bc_project: unknown model %d", model); return BC_INVALID_ARGUMENT; }
+  int rc = project_check(ctx, data, model, theta, s, params, n_params, "bc_project");
+  if (rc) return rc;
+  if (!inout) { bc_set_error("bc_project: bad argument"); return BC_INVALID_ARGUMENT; }
   if (s > 256) return bc_project_wide(ctx, data, model, theta, s, params, n_params, row_offset, inout);
   return project_impl(ctx, data, model, theta, s, params, n_params, row_offset, inout, s, 0, false);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Store-free projection and the fused gradient of the greedy-VI weight optimisation.
+//
+// bcores.py:141-146 / sparsevi.py:129-134: every one of the opt_itrs ADAM steps of every build step evaluates
+//     vecs = project_f(data, beta) ; resid = sum_scaling * vecs.sum(axis=0) - w.dot(corevecs) ; grad = -corevecs.dot(resid) / S
+// i.e. of the N x S projection only its S column sums are used.  The materialising path writes 8*N*S bytes to read S
+// numbers back; here K1 keeps its per-tile column partials and stores nothing else (k_project<..., STORE = false>).
+int bc_comm_sum_dev(bc_comm* c, const double* in_dev, int64_t count, const double** result_dev);   // bc_comm.hip
+
+// the context's stats-only Phi, sized for n_rows x s
+static int colsum_phi_for(bc_ctx* ctx, int64_t n_rows, int32_t s, bc_phi** out) {
+  bc_phi* p = ctx->colsum_phi;
+  if (p && (p->s != s || bc_phi_set_rows(p, n_rows) != 0)) {
+    BC_HIP(hipStreamSynchronize(ctx->stream));
+    bc_phi_destroy(p);
+    ctx->colsum_phi = p = nullptr;
+  }
+  if (!p) {
+    int rc = bc_phi_alloc(ctx, n_rows, s, 0, &p, 0, true);
+    if (rc) return rc;
+    ctx->colsum_phi = p;
+  }
+  p->stats_valid = false;
+  *out = p;
+  return BC_OK;
+}
+
+extern "C" int bc_project_colsum(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                                 const double* params, int32_t n_params, bc_comm* comm, double* out_s) {
+  int rc = project_check(ctx, data, model, theta, s, params, n_params, "bc_project_colsum");
+  if (rc) return rc;
+  if (!out_s) { bc_set_error("bc_project_colsum: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (s > 256) { bc_set_error("bc_project_colsum: at most 256 samples (S = %d): project and take bc_phi_colsum", s); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  ProjPlan pl;
+  rc = plan_stage(ctx, model, theta, s, params, n_params, data->dz, false, &pl);
+  if (rc) return rc;
+  bc_phi* phi = nullptr;
+  rc = colsum_phi_for(ctx, data->n_rows, s, &phi);
+  if (!rc) rc = plan_launch(ctx, pl, data, phi, PROJ_COLSUM, s, 0, &ctx->proj_rowaux);
+  if (!rc) rc = bc_phi_reduce_colsum(phi);
+  if (rc) return rc;
+  const double* res = phi->colsum;
+  if (comm) {
+    rc = bc_comm_sum_dev(comm, phi->colsum, s, &res);
+    if (rc) return rc;
+  }
+  BC_HIP(hipMemcpyAsync(ctx->pinned, res, (size_t)s * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(out_s, ctx->pinned, (size_t)s * sizeof(double));
+  return BC_OK;
+}
+
+// resid[k] = scale * colsum[k] - sum_i w[i] * C[i, k]   (bcores.py:145: sum_scaling*vecs.sum(axis=0) - w.dot(corevecs))
+// grad[i]  = -(sum_k C[i, k] * resid[k]) / S            (bcores.py:146: -corevecs.dot(resid)/corevecs.shape[1])
+// C = the projected coreset rows in the tiled layout (row i, sample k at bc_tile_off(i, k, S)): neighbouring threads
+// read neighbouring rows, so both passes are coalesced.  One block; m is the coreset size (tens to a few thousand).
+__global__ __launch_bounds__(256) void k_vi_gradient(const double* __restrict__ colsum, const double* __restrict__ core,
+                                                    const double* __restrict__ w, int m, int s, double scale,
+                                                    double* __restrict__ resid_out, double* __restrict__ grad_out) {
+  extern __shared__ double rs[];      // [s]
+  for (int k = threadIdx.x; k < s; k += blockDim.x) {
+    double acc = 0.;
+    for (int i = 0; i < m; ++i) acc = fma(w[i], core[bc_tile_off(i, k, s)], acc);
+    const double r = scale * colsum[k] - acc;
+    rs[k] = r;
+    resid_out[k] = r;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    double acc = 0.;
+    for (int k = 0; k < s; ++k) acc = fma(core[bc_tile_off(i, k, s)], rs[k], acc);
+    grad_out[i] = -acc / (double)s;
+  }
+}
+
+extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* core_rows, int64_t m, int model,
+                              const double* theta, int32_t s, const double* params, int32_t n_params, const double* w,
+                              double sum_scaling, bc_comm* comm, double* out_grad, double* out_resid) {
+  int rc = project_check(ctx, data, model, theta, s, params, n_params, "bc_vi_gradient");
+  if (rc) return rc;
+  if (m <= 0 || !core_rows || !w || !out_grad) { bc_set_error("bc_vi_gradient: needs a non-empty coreset (m = %lld)", (long long)m); return BC_INVALID_ARGUMENT; }
+  if (s > 256) { bc_set_error("bc_vi_gradient: at most 256 samples (S = %d)", s); return BC_INVALID_ARGUMENT; }
+  const int dz = data->dz;
+  const size_t n_core = (size_t)m * dz, n_up = n_core + (size_t)m, n_down = (size_t)m + (size_t)s;
+  if (n_up > ctx->pinned_doubles || n_down > ctx->pinned_doubles) {
+    bc_set_error("bc_vi_gradient: coreset of %lld rows x %d exceeds the staging area", (long long)m, dz);
+    return BC_INVALID_ARGUMENT;
+  }
+  BC_HIP(hipSetDevice(ctx->device));
+  const bool timed = ctx->timing != 0;
+  if (timed)
+    for (auto& ev : ctx->vi_ev)
+      if (!ev) BC_HIP(hipEventCreate(&ev));
+  auto mark = [&](int i) -> int {
+    if (timed) BC_HIP(hipEventRecord(ctx->vi_ev[i], ctx->stream));
+    return BC_OK;
+  };
+  // --- stage Theta (synchronises with the stream: the pinned areas are free afterwards), the coreset rows and w
+  ProjPlan pl;
+  rc = mark(0);
+  if (!rc) rc = plan_stage(ctx, model, theta, s, params, n_params, dz, false, &pl);
+  if (rc) return rc;
+  if (!ctx->core_data) {
+    rc = bc_data_create(ctx, 256, dz, &ctx->core_data);
+    if (rc) return rc;
+  }
+  bc_data* cd = ctx->core_data;
+  if (cd->dz != dz || cd->cap_rows < m) {
+    BC_HIP(hipStreamSynchronize(ctx->stream));
+    bc_data_destroy(cd);
+    ctx->core_data = nullptr;
+    int64_t cap = 256;
+    while (cap < m) cap *= 2;
+    rc = bc_data_create(ctx, cap, dz, &ctx->core_data);
+    if (rc) return rc;
+    cd = ctx->core_data;
+  }
+  cd->n_rows = m;
+  rc = bc_scratch_grow(ctx, &ctx->vi_buf, (size_t)m * 2 + (size_t)s);
+  if (rc) return rc;
+  double* d_w = ctx->vi_buf.p;
+  double* d_grad = d_w + m;
+  double* d_resid = d_grad + m;
+  memcpy(ctx->pinned, core_rows, n_core * sizeof(double));
+  memcpy(ctx->pinned + n_core, w, (size_t)m * sizeof(double));
+  BC_HIP(hipMemcpyAsync(cd->z, ctx->pinned, n_core * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  BC_HIP(hipMemcpyAsync(d_w, ctx->pinned + n_core, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rc = mark(1);
+  if (rc) return rc;
+  // --- the <= M coreset rows (materialised: the M x S algebra below reads them), then the data rows (store-free)
+  bc_phi* cphi = ctx->core_phi;
+  if (cphi && (cphi->s != s || bc_phi_set_rows(cphi, m) != 0)) {
+    BC_HIP(hipStreamSynchronize(ctx->stream));
+    bc_phi_destroy(cphi);
+    ctx->core_phi = cphi = nullptr;
+  }
+  if (!cphi) {
+    int64_t cap = 256;
+    while (cap < m) cap *= 2;
+    rc = bc_phi_alloc(ctx, m, s, 0, &cphi, cap);
+    if (rc) return rc;
+    ctx->core_phi = cphi;
+  }
+  cphi->stats_valid = false;
+  const int saved_timing = ctx->timing;
+  ctx->timing = 0;                      // the coreset rows' launch is not a K1 sample of the kernel timer
+  rc = plan_launch(ctx, pl, cd, cphi, PROJ_FULL, s, 0, &ctx->proj_rowaux);
+  ctx->timing = saved_timing;
+  if (!rc) rc = mark(2);
+  bc_phi* phi = nullptr;
+  if (!rc) rc = colsum_phi_for(ctx, data->n_rows, s, &phi);
+  // (x^T Siginv x of the data rows, Gaussian models, goes to a scratch of its own: the coreset rows' is still in use)
+  if (!rc) rc = plan_launch(ctx, pl, data, phi, PROJ_COLSUM, s, 0, &ctx->proj_rowaux2);
+  if (!rc) rc = mark(3);
+  if (!rc) rc = bc_phi_reduce_colsum(phi);
+  if (rc) return rc;
+  const double* colsum = phi->colsum;
+  if (comm) {
+    rc = bc_comm_sum_dev(comm, phi->colsum, s, &colsum);
+    if (rc) return rc;
+  }
+  rc = mark(4);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_vi_gradient, dim3(1), dim3(256), (size_t)s * sizeof(double), ctx->stream, colsum, cphi->tiles, d_w,
+                     (int)m, s, sum_scaling, d_resid, d_grad);
+  BC_HIP(hipGetLastError());
+  BC_HIP(hipMemcpyAsync(ctx->pinned, d_grad, n_down * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  rc = mark(5);
+  if (rc) return rc;
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(out_grad, ctx->pinned, (size_t)m * sizeof(double));
+  if (out_resid) memcpy(out_resid, ctx->pinned + m, (size_t)s * sizeof(double));
+  if (timed) {
+    for (int i = 0; i < BC_VI_PHASES; ++i) {
+      float ms = 0.f;
+      BC_HIP(hipEventElapsedTime(&ms, ctx->vi_ev[i], ctx->vi_ev[i + 1]));
+      ctx->vi_phase_ms[i] += ms;
+    }
+    ctx->vi_calls_timed++;
+  }
+  return BC_OK;
+}
+
+extern "C" int bc_ctx_phase_times(bc_ctx* ctx, double* out_ms, int32_t n, int64_t* calls, int reset) {
+  if (!ctx || (n > 0 && !out_ms)) { bc_set_error("bc_ctx_phase_times: bad argument"); return BC_INVALID_ARGUMENT; }
+  for (int i = 0; i < n; ++i) out_ms[i] = i < BC_VI_PHASES ? ctx->vi_phase_ms[i] : 0.;
+  if (calls) *calls = ctx->vi_calls_timed;
+  if (reset) {
+    for (auto& v : ctx->vi_phase_ms) v = 0.;
+    ctx->vi_calls_timed = 0;
+  }
+  return BC_OK;
 }

@@ -59,6 +59,15 @@ class Context:
     def kernel_time_reset(self):
         N.call('bc_ctx_kernel_time_reset', self.h)
 
+    VI_PHASES = ('upload', 'k1_core_rows', 'k1_data_rows', 'colsum_reduce', 'algebra_download')
+
+    def phase_times(self, reset=True):
+        """({phase: total GPU ms}, timed calls) of the bc_vi_gradient calls made while timing was on."""
+        out = np.zeros(len(self.VI_PHASES))
+        n = C.c_int64()
+        N.call('bc_ctx_phase_times', self.h, _ptr(out), len(self.VI_PHASES), C.byref(n), 1 if reset else 0)
+        return dict(zip(self.VI_PHASES, out.tolist())), n.value
+
 
 def default_context():
     global _default_ctx

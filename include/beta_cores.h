@@ -86,6 +86,10 @@ int bc_ctx_sync(bc_ctx* ctx);
 int bc_ctx_kernel_time(bc_ctx* ctx, int which, double* total_ms, int64_t* launches);
 int bc_ctx_kernel_time_reset(bc_ctx* ctx);
 int bc_ctx_enable_timing(bc_ctx* ctx, int on);
+/* accumulated GPU time (HIP events, ms) of the BC_VI_PHASES = 5 phases of the bc_vi_gradient calls made while timing
+ * was on: upload (Theta, coreset rows, w) | K1 of the coreset rows | store-free K1 over the data rows | column-sum
+ * reduction (+ rank-order sum over ranks) | M x S algebra + download; *calls = number of timed calls; reset != 0 clears. */
+int bc_ctx_phase_times(bc_ctx* ctx, double* out_ms, int32_t n, int64_t* calls, int reset);
 
 /* ---- native candidate exchange (RCCL on the context's stream) ---------- */
 /* the one data-path collective of the sharded greedy loop is an all-gather of an (S+4)-double
@@ -113,6 +117,9 @@ int bc_comm_abort(bc_comm* c);
 /* sum of `count` doubles over ranks, added IN RANK ORDER on the device (bit-stable), result on the host:
  * replaces vecs.sum(axis=0) of a row-sharded projection (hilbert.py:17, bcores.py:77) */
 int bc_comm_sum_doubles(bc_comm* c, const double* in_dev, int64_t count, double* out_host);
+/* test hook: the device kernel behind bc_comm_sum_doubles on a fabricated gathered buffer (host, [world][count]), so
+ * that its indexing and order of additions can be checked for any world size on one GPU, without a communicator */
+int bc_comm_rank_order_sum_selftest(bc_ctx* ctx, const double* gathered_host, int32_t world, int64_t count, double* out_host);
 
 /* ---- data rows (Z) resident on the device ----------------------------- */
 /* replaces the `data`/`pts` ndarray argument of Projector.project (projector.py:23,51) */
@@ -141,6 +148,24 @@ int bc_phi_create(bc_ctx* ctx, int64_t cap_rows, int32_t s, bc_phi** out);
  * re-projects every gradient call, bcores.py:141-146). Fuses row norms and column sums (K2). */
 int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
+/* K1 WITHOUT materialising Phi: only b = Phi^T 1 of the projection of `data`'s rows, S <= 256 doubles to the host.
+ * What every gradient of the greedy-VI weight optimisation needs of the N x S projection (bcores.py:141-146,
+ * sparsevi.py:129-134: `vecs.sum(axis=0)` inside grd).  Same contraction, formula, centring, per-tile column partials
+ * and reduction order as bc_project + bc_phi_colsum -- the result is bit-identical to theirs -- but neither the tiles
+ * nor the row norms are written: 8*N*Dz bytes of HBM traffic instead of 8*N*(Dz + S).  comm != NULL: the sum over all
+ * ranks' row shards (rank order, as bc_phi_colsum_all). */
+int bc_project_colsum(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
+                      const double* params, int32_t n_params, bc_comm* comm, double* out_s);
+/* One gradient of the greedy-VI weight optimisation in ONE call and ONE host synchronisation (bcores.py:141-146,
+ * sparsevi.py:129-134, full-data tangent space):
+ *     vecs = project(data) ; corevecs = project(core_rows)
+ *     resid = sum_scaling * vecs.sum(axis=0) - w.dot(corevecs) ; grad = -corevecs.dot(resid) / S
+ * core_rows: host, m x dz row-major (the coreset's points, m >= 1); w: host, m weights; theta / params as bc_project;
+ * out_grad: m doubles; out_resid: S doubles or NULL.  The data rows go through the store-free K1, the m coreset rows
+ * through the materialising one, the M x S algebra runs on the device; comm as in bc_project_colsum. */
+int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* core_rows, int64_t m, int model,
+                   const double* theta, int32_t s, const double* params, int32_t n_params, const double* w,
+                   double sum_scaling, bc_comm* comm, double* out_grad, double* out_resid);
 /* x-gradients of the log-likelihood at `data`'s rows (the coreset's pseudo-points), centred over the coordinate axis:
  * what BlackBoxProjector.project(pts, grad=True) returns next to the projection (projector.py:27-32) and
  * BatchPSVICoreset moves its points with (bpsvi.py:39-57).  model: BC_MODEL_LINREG_LL (model_linreg.py:12-17,

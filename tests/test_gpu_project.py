@@ -331,32 +331,6 @@ def test_constant_rows_wide_projection_and_other_models(bc):
             assert const_row_ok(host[r], raw[r, 0], S), (S, r)
 
 
-def test_vector_fma_variant_matches(bc):
-    """The opt-in vector-FMA formulation of K1 (BC_K1_VALU=1, S <= 100) produces the same Phi as the
-    MFMA kernel up to summation order; run in a child process because the choice is read once."""
-    import os, subprocess, sys, textwrap
-    code = textwrap.dedent("""
-        import sys, numpy as np
-        sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
-        import beta_cores_amd as bc
-        from oracle import models_ref as M
-        rng = np.random.RandomState(5)
-        for (n, d, s) in [(1000, 64, 100), (300, 33, 50), (129, 7, 64), (2, 3, 16), (700, 128, 97)]:
-            Z = rng.randn(n, d + 1); th = rng.randn(s, d) * 0.5
-            prj = bc.DeviceBetaProjector(lambda k, w, p: th, s, bc.likelihoods.LinearRegression(1.3))
-            for got, raw in ((prj.project(Z), M.linreg_loglik(Z, th, 1.3)), (prj.project_f(Z, 0.3), M.linreg_beta_lik(Z, th, 0.3, 1.3))):
-                ref = raw - raw.mean(axis=1)[:, None]
-                g = np.asarray(got)
-                assert np.abs(g - ref).max() <= 1e-11 * (1 + np.abs(raw).max()), (n, d, s)
-                assert np.allclose(got.colsum(), g.sum(axis=0), rtol=1e-10, atol=1e-9 * (1 + np.abs(raw).max()))
-                assert np.allclose(got.norms(), np.sqrt((g ** 2).sum(axis=1)), rtol=1e-12)
-        print('ok')
-    """) % (ROOT, ROOT)
-    env = dict(os.environ, BC_K1_VALU='1')
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and 'ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
-
-
 def test_group_sum_matches_numpy_bits(bc):
     """bc_phi_group_sum: per-group sums of Phi rows, accumulated in member order -- bit-identical to
     np.array([phi[g].sum(axis=0) for g in groups]) (bcores.py:46-50), for contiguous, scattered, repeated-member,
