@@ -96,6 +96,7 @@ _SIGNATURES = {
     'bc_snnls_set_flags': [vp, C.c_int],
     'bc_snnls_trace': [vp, C.c_int64, vp, vp, vp, c_i64p],
     'bc_weighted_gram': [vp, vp, vp, vp, vp],
+    'bc_weighted_gram_host': [vp, vp, C.c_int64, C.c_int32, vp, vp, vp],
 }
 EXPORTS = sorted(list(_SIGNATURES) + ['bc_version', 'bc_last_error'])
 

@@ -53,6 +53,10 @@ class BatchPSVICoreset(Coreset):
             rows, scale = (self._resident if self._resident is not None else self.data), 1.
         else:
             rows, scale = self.data[np.random.randint(self.data.shape[0], size=m)], self.data.shape[0] / m
+        if hasattr(self.ll_projector, 'colsum'):        # device projector: store-free K1, the bits of project().sum(axis=0)
+            b = self.ll_projector.colsum(rows)
+            if b is not None:
+                return scale * b
         vecs = self.ll_projector.project(rows)
         if not isinstance(vecs, DevicePhi):            # black-box projector: a host array, reduced on the device
             ctx = getattr(self.ll_projector, 'ctx', None)

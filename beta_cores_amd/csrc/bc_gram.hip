@@ -236,6 +236,53 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   return rc;
 }
 
+// Coreset-sized inputs straight from host memory (the samplers call weighted_post on the <= M coreset rows once per
+// gradient, bcores.py:39 -> sampler -> model_linreg.py:25-34): rows and weights travel in ONE transfer from the pinned
+// staging area, both results come back in ONE, one synchronisation in all -- the per-call latency is what counts here.
+extern "C" int bc_weighted_gram_host(bc_ctx* ctx, const double* z_rowmajor, int64_t n_rows, int32_t dz, const double* w,
+                                     double* out_xtwx, double* out_xtwy) {
+  if (!ctx || !out_xtwx || !out_xtwy || n_rows < 0 || dz < 2 || (n_rows > 0 && !z_rowmajor)) {
+    bc_set_error("bc_weighted_gram_host: bad argument (rows must be [x (D >= 1), y])");
+    return BC_INVALID_ARGUMENT;
+  }
+  const int d = dz - 1;
+  const size_t n_z = (size_t)n_rows * dz, n_in = n_z + (w ? (size_t)n_rows : 0), n_out = (size_t)d * d + (size_t)d;
+  if (n_in > ctx->pinned_doubles || n_out > ctx->pinned_doubles) {
+    bc_set_error("bc_weighted_gram_host: meant for coreset-sized inputs (%lld rows x %d); upload larger ones with bc_data_from_host",
+                 (long long)n_rows, dz);
+    return BC_INVALID_ARGUMENT;
+  }
+  if (n_rows == 0) {
+    memset(out_xtwx, 0, (size_t)d * d * sizeof(double));
+    memset(out_xtwy, 0, (size_t)d * sizeof(double));
+    return BC_OK;
+  }
+  BC_HIP(hipSetDevice(ctx->device));
+  double* in_dev = nullptr;
+  double* out_dev = nullptr;
+  int rc = gram_buf(ctx, 4, n_in, &in_dev);
+  if (!rc) rc = gram_buf(ctx, 2, n_out, &out_dev);
+  if (rc) return rc;
+  BC_HIP(hipStreamSynchronize(ctx->stream));            // nothing enqueued may still use the staging area
+  memcpy(ctx->pinned, z_rowmajor, n_z * sizeof(double));
+  if (w) memcpy(ctx->pinned + n_z, w, (size_t)n_rows * sizeof(double));
+  BC_HIP(hipMemcpyAsync(in_dev, ctx->pinned, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  bc_data view;
+  view.ctx = ctx;
+  view.n_rows = n_rows;
+  view.dz = dz;
+  view.z = in_dev;
+  view.owned = false;
+  const double* w_dev = w ? in_dev + n_z : nullptr;
+  rc = d > 64 ? run_gram<128>(ctx, &view, w_dev, out_dev, out_dev + (size_t)d * d) : run_gram<64>(ctx, &view, w_dev, out_dev, out_dev + (size_t)d * d);
+  if (rc) return rc;
+  BC_HIP(hipMemcpyAsync(ctx->pinned, out_dev, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(out_xtwx, ctx->pinned, (size_t)d * d * sizeof(double));
+  memcpy(out_xtwy, ctx->pinned + (size_t)d * d, (size_t)d * sizeof(double));
+  return BC_OK;
+}
+
 extern "C" int bc_weighted_gram(bc_ctx* ctx, const bc_data* data, const double* w, double* out_xtwx, double* out_xtwy) {
   if (!ctx || !data || !out_xtwx || !out_xtwy) { bc_set_error("bc_weighted_gram: bad argument"); return BC_INVALID_ARGUMENT; }
   if (data->ctx != ctx) { bc_set_error("bc_weighted_gram: data belongs to another context"); return BC_INVALID_ARGUMENT; }

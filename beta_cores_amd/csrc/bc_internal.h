@@ -50,15 +50,14 @@ struct bc_ctx {
   double* pinned = nullptr;      // small pinned staging area (host)
   size_t pinned_doubles = 0;
   // K1 staging (bc_project.hip): zero-padded Theta, per-sample / per-row extras, Siginv; a pinned host mirror
-  bc_scratch proj_theta, proj_saux, proj_rowaux, proj_rowaux2, proj_siginv;
+  bc_scratch proj_theta, proj_rowaux, proj_rowaux2;      // proj_theta: Theta | saux | Siginv | extras, one transfer
   double* proj_pinned = nullptr;
   size_t proj_pinned_cap = 0;
   bc_scratch gradx;              // bc_project_grad_x
   bc_scratch gram[5];            // K4: partial, partial_y, out, out_y, w
   bc_phi* colsum_phi = nullptr;  // store-free K1: a Phi with the per-tile column partials but no tiles / norms
   bc_phi* core_phi = nullptr;    // bc_vi_gradient: the projection of the <= M coreset rows
-  bc_data* core_data = nullptr;  //                 and their upload slot
-  bc_scratch vi_buf;             // bc_vi_gradient: w | resid | grad
+  bc_scratch vi_buf;             // bc_vi_gradient: grad | resid
   hipEvent_t vi_ev[BC_VI_PHASES + 1] = {};
   double vi_phase_ms[BC_VI_PHASES] = {};
   int64_t vi_calls_timed = 0;

@@ -795,13 +795,18 @@ static int launch_project_raw(bc_ctx* ctx, const ProjArgs& a, long long ntiles, 
 struct ProjPlan {
   ProjArgs a;             // constants, theta, saux, d, dk, s, model filled in; the per-launch fields are set by plan_launch
   int model = 0, s = 0, d = 0, ntsel = 0;
-  bool raw = false, has_siginv = false;
+  bool raw = false;
+  const double* siginv_dev = nullptr;      // Gaussian models: Siginv [d][d] on the device
 };
 
 static bool model_has_y(int model) { return model == BC_MODEL_LINREG_LL || model == BC_MODEL_LINREG_BETA; }
 
+// `extra` (optional): further host arrays shipped in the same transfer (bc_vi_gradient: the coreset rows and their
+// weights); extra_dev[i] receives the device address of extra_src[i].  ONE pinned staging area, ONE device buffer, ONE
+// hipMemcpyAsync per plan: a copy call costs ~5 us of host time, a gradient step of the 1M-row configuration 350.
 static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, const double* params, int32_t n_params,
-                      int dz, bool raw, ProjPlan* pl) {
+                      int dz, bool raw, ProjPlan* pl, int n_extra = 0, const double* const* extra_src = nullptr,
+                      const size_t* extra_n = nullptr, double** extra_dev = nullptr) {
   if (s <= 0 || s > 256) { bc_set_error("bc_project: internal: a single pass handles 1..256 samples"); return BC_INVALID_ARGUMENT; }
   const int d = dz - (model_has_y(model) ? 1 : 0);
   if (d <= 0) { bc_set_error("bc_project: data rows too short for this model"); return BC_INVALID_ARGUMENT; }
@@ -822,11 +827,12 @@ static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, co
   const int NRsel = NTsel * 16 + (tail ? 4 : 0);                 // rows of the zero-padded Theta / saux
   const int KC = NTsel <= 7 ? 32 : 16;
   const int dk = ((d + KC - 1) / KC) * KC;
-  const size_t th_n = (size_t)NRsel * dk, sa_n = (size_t)NRsel;
-  int rc = bc_scratch_grow(ctx, &ctx->proj_theta, th_n);
-  if (!rc) rc = bc_scratch_grow(ctx, &ctx->proj_saux, sa_n);
-  if (!rc && siginv) rc = bc_scratch_grow(ctx, &ctx->proj_siginv, (size_t)d * d);
-  if (!rc) rc = grow_pinned(ctx, th_n + sa_n + (siginv ? (size_t)d * d : 0));
+  const size_t th_n = (size_t)NRsel * dk, sa_n = (size_t)NRsel, sg_n = siginv ? (size_t)d * d : 0;
+  const size_t head_n = (th_n + sa_n + sg_n + 1) & ~(size_t)1;
+  size_t total = head_n;
+  for (int i = 0; i < n_extra; ++i) total += (extra_n[i] + 1) & ~(size_t)1;      // 16-byte aligned pieces
+  int rc = bc_scratch_grow(ctx, &ctx->proj_theta, total);
+  if (!rc) rc = grow_pinned(ctx, total);
   if (rc) return rc;
   // make sure an earlier launch is no longer reading the pinned staging area
   BC_HIP(hipStreamSynchronize(ctx->stream));
@@ -850,18 +856,19 @@ static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, co
       }
       hsa[q] = tst;
     }
+    memcpy(ctx->proj_pinned + th_n + sa_n, siginv, sg_n * sizeof(double));
   } else {
     for (int q = 0; q < s; ++q) memcpy(hth + (size_t)q * dk, theta + (size_t)q * d, (size_t)d * sizeof(double));
   }
-  BC_HIP(hipMemcpyAsync(ctx->proj_theta.p, hth, th_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  BC_HIP(hipMemcpyAsync(ctx->proj_saux.p, hsa, sa_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (siginv) {
-    double* hsi = ctx->proj_pinned + th_n + sa_n;
-    memcpy(hsi, siginv, (size_t)d * d * sizeof(double));
-    BC_HIP(hipMemcpyAsync(ctx->proj_siginv.p, hsi, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  size_t off = head_n;
+  for (int i = 0; i < n_extra; ++i) {
+    memcpy(ctx->proj_pinned + off, extra_src[i], extra_n[i] * sizeof(double));
+    extra_dev[i] = ctx->proj_theta.p + off;
+    off += (extra_n[i] + 1) & ~(size_t)1;
   }
+  BC_HIP(hipMemcpyAsync(ctx->proj_theta.p, ctx->proj_pinned, total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   a.theta = ctx->proj_theta.p;
-  a.saux = ctx->proj_saux.p;
+  a.saux = ctx->proj_theta.p + th_n;
   a.d = d;
   a.dk = dk;
   a.s = s;
@@ -871,7 +878,7 @@ static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, co
   pl->d = d;
   pl->ntsel = NTsel;
   pl->raw = raw;
-  pl->has_siginv = siginv != nullptr;
+  pl->siginv_dev = siginv ? ctx->proj_theta.p + th_n + sa_n : nullptr;
   return BC_OK;
 }
 
@@ -882,7 +889,7 @@ static int plan_launch(bc_ctx* ctx, const ProjPlan& pl, const bc_data* data, bc_
                        int32_t s_off, bc_scratch* rowaux) {
   ProjArgs a = pl.a;
   a.rowaux = nullptr;
-  if (pl.has_siginv && data->n_rows > 0) {
+  if (pl.siginv_dev && data->n_rows > 0) {
     int rc = bc_scratch_grow(ctx, rowaux, (size_t)data->n_rows);
     if (rc) return rc;
     const int d = pl.d;
@@ -890,7 +897,7 @@ static int plan_launch(bc_ctx* ctx, const ProjPlan& pl, const bc_data* data, bc_
     long long blocks = (data->n_rows + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_row_quadform, dim3((unsigned)blocks), dim3(256), use_lds ? (size_t)d * d * sizeof(double) : 0,
-                       ctx->stream, data->z, (long long)data->n_rows, d, ctx->proj_siginv.p, rowaux->p, use_lds);
+                       ctx->stream, data->z, (long long)data->n_rows, d, pl.siginv_dev, rowaux->p, use_lds);
     BC_HIP(hipGetLastError());
     a.rowaux = rowaux->p;
   }
@@ -1071,8 +1078,8 @@ extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* co
   if (m <= 0 || !core_rows || !w || !out_grad) { bc_set_error("bc_vi_gradient: needs a non-empty coreset (m = %lld)", (long long)m); return BC_INVALID_ARGUMENT; }
   if (s > 256) { bc_set_error("bc_vi_gradient: at most 256 samples (S = %d)", s); return BC_INVALID_ARGUMENT; }
   const int dz = data->dz;
-  const size_t n_core = (size_t)m * dz, n_up = n_core + (size_t)m, n_down = (size_t)m + (size_t)s;
-  if (n_up > ctx->pinned_doubles || n_down > ctx->pinned_doubles) {
+  const size_t n_core = (size_t)m * dz, n_down = (size_t)m + (size_t)s;
+  if (n_down > ctx->pinned_doubles) {
     bc_set_error("bc_vi_gradient: coreset of %lld rows x %d exceeds the staging area", (long long)m, dz);
     return BC_INVALID_ARGUMENT;
   }
@@ -1085,36 +1092,27 @@ extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* co
     if (timed) BC_HIP(hipEventRecord(ctx->vi_ev[i], ctx->stream));
     return BC_OK;
   };
-  // --- stage Theta (synchronises with the stream: the pinned areas are free afterwards), the coreset rows and w
+  // --- stage Theta, the coreset rows and w: one pinned area, one transfer (plan_stage synchronises with the stream first)
   ProjPlan pl;
   rc = mark(0);
-  if (!rc) rc = plan_stage(ctx, model, theta, s, params, n_params, dz, false, &pl);
   if (rc) return rc;
-  if (!ctx->core_data) {
-    rc = bc_data_create(ctx, 256, dz, &ctx->core_data);
-    if (rc) return rc;
-  }
-  bc_data* cd = ctx->core_data;
-  if (cd->dz != dz || cd->cap_rows < m) {
-    BC_HIP(hipStreamSynchronize(ctx->stream));
-    bc_data_destroy(cd);
-    ctx->core_data = nullptr;
-    int64_t cap = 256;
-    while (cap < m) cap *= 2;
-    rc = bc_data_create(ctx, cap, dz, &ctx->core_data);
-    if (rc) return rc;
-    cd = ctx->core_data;
-  }
-  cd->n_rows = m;
-  rc = bc_scratch_grow(ctx, &ctx->vi_buf, (size_t)m * 2 + (size_t)s);
+  const double* esrc[2] = {core_rows, w};
+  const size_t en[2] = {n_core, (size_t)m};
+  double* edev[2] = {nullptr, nullptr};
+  rc = plan_stage(ctx, model, theta, s, params, n_params, dz, false, &pl, 2, esrc, en, edev);
   if (rc) return rc;
-  double* d_w = ctx->vi_buf.p;
-  double* d_grad = d_w + m;
+  bc_data core_view;                     // the coreset rows where the transfer put them (borrowed)
+  core_view.ctx = ctx;
+  core_view.n_rows = m;
+  core_view.dz = dz;
+  core_view.z = edev[0];
+  core_view.owned = false;
+  bc_data* cd = &core_view;
+  const double* d_w = edev[1];
+  rc = bc_scratch_grow(ctx, &ctx->vi_buf, (size_t)m + (size_t)s);
+  if (rc) return rc;
+  double* d_grad = ctx->vi_buf.p;
   double* d_resid = d_grad + m;
-  memcpy(ctx->pinned, core_rows, n_core * sizeof(double));
-  memcpy(ctx->pinned + n_core, w, (size_t)m * sizeof(double));
-  BC_HIP(hipMemcpyAsync(cd->z, ctx->pinned, n_core * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  BC_HIP(hipMemcpyAsync(d_w, ctx->pinned + n_core, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   rc = mark(1);
   if (rc) return rc;
   // --- the <= M coreset rows (materialised: the M x S algebra below reads them), then the data rows (store-free)

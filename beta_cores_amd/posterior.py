@@ -40,33 +40,35 @@ def _small_lapack(d):
     return _controller.limit(limits=1, user_api='blas')
 
 
-_slots = {}
-
-
 def weighted_gram(z, w=None, ctx=None, comm=None):
     """(X^T diag(w) X, X^T (w*y)) for rows z = [x, y]; `z` may be an ndarray or a DeviceData.
     With `comm` the rows are this rank's shard and the two results are summed over ranks."""
     ctx = ctx or default_context()
-    if isinstance(z, DeviceData):
-        data = z
+    if w is not None:
+        w = np.ascontiguousarray(w, dtype=np.float64)
+    if not isinstance(z, DeviceData):
+        z = np.ascontiguousarray(np.atleast_2d(z), dtype=np.float64)
+        if w is not None and w.shape != (z.shape[0],):
+            raise ValueError('w must have one weight per row')
+        if z.shape[0] * (z.shape[1] + 1) <= 60000 and z.shape[1] * z.shape[1] <= 60000:
+            # coreset-sized call (the samplers, once per gradient): rows, weights and results in one native call
+            d = z.shape[1] - 1
+            G, v = np.empty((max(d, 0), max(d, 0))), np.empty(max(d, 0))
+            N.call('bc_weighted_gram_host', ctx.h, _ptr(z), int(z.shape[0]), int(z.shape[1]), _ptr(w) if w is not None else None,
+                   _ptr(G), _ptr(v))
+            if comm is not None and comm.world > 1:
+                G = comm.sum_in_rank_order(G)
+                v = comm.sum_in_rank_order(v)
+            return G, v
+        data = DeviceData(z, ctx=ctx)
     else:
-        z = np.atleast_2d(z)
-        if z.shape[0] < 4096:           # coreset-sized call (the samplers): re-used upload slot
-            key = (id(ctx), z.shape[1])
-            slot = _slots.get(key)
-            if slot is None:
-                slot = _slots[key] = DeviceData.slot(z.shape[1], cap_rows=256, ctx=ctx)
-            data = slot.update(z)
-        else:
-            data = DeviceData(z, ctx=ctx)
+        data = z
     n, dz = data.shape
     d = dz - 1
     G = np.empty((d, d))
     v = np.empty(d)
-    if w is not None:
-        w = np.ascontiguousarray(w, dtype=np.float64)
-        if w.shape != (n,):
-            raise ValueError('w must have one weight per row')
+    if w is not None and w.shape != (n,):
+        raise ValueError('w must have one weight per row')
     N.call('bc_weighted_gram', data.ctx.h, data.h, _ptr(w) if w is not None else None, _ptr(G), _ptr(v))
     if comm is not None and comm.world > 1:
         G = comm.sum_in_rank_order(G)

@@ -281,6 +281,10 @@ int bc_snnls_trace(bc_snnls* h, int64_t cap, int64_t* f, int32_t* status, double
 /* data rows are [x(D), y]; w: host, n_rows doubles (NULL = all ones).
  * out_xtwx: D x D row-major, out_xtwy: D.  Local rows only; the host sums over ranks. */
 int bc_weighted_gram(bc_ctx* ctx, const bc_data* data, const double* w, double* out_xtwx, double* out_xtwy);
+/* the same for coreset-sized rows in HOST memory (what the samplers pass, bcores.py:39 -> sampler -> weighted_post on the
+ * <= M coreset points, once per gradient): one transfer in, one out, one synchronisation.  z: n_rows x dz row-major. */
+int bc_weighted_gram_host(bc_ctx* ctx, const double* z_rowmajor, int64_t n_rows, int32_t dz, const double* w,
+                          double* out_xtwx, double* out_xtwy);
 
 #ifdef __cplusplus
 }
