@@ -15,6 +15,7 @@
 // Formula sources (expression order kept, -ffp-contract=off):
 //   model_linreg.py:4-10 / model_neurlinr.py:90-97,102-110 / model_lr.py:72-86 / gaussian.py:7-15,34-62
 #include "bc_internal.h"
+#include "bc_np_exp.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -167,6 +168,57 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
       return ((t1 - t2) - t3) - c[6];
     }
   }
+}
+
+// exp() carrying NumPy's bits on AVX-512 hosts (bc_np_exp.h) where that routine covers the argument, the ordinary one
+// in the far tails (|x| >= 707.7: the results there are below the last bit of anything they are added to)
+__device__ __forceinline__ double bc_exp_like_numpy(double x) {
+  int covered;
+  const double e = bc_np_exp(x, &covered);
+  return covered ? e : exp(x);
+}
+
+// The model value of a CONSTANT row (all S values equal: a data row with all-zero features) with the reference's bits:
+// which of these rows the reference's centring leaves exactly 0 depends on the last bit of the constant (section 7 of
+// DESIGN.md, golden F13), so their np.exp() is restated exactly; the formulas without a transcendental are already
+// bit-identical, and the two logistic ones are left to bc_model_value (log1p(exp(0)) = log 2 matches; the
+// beta-likelihood's np.power is not restated).
+template <int MODEL>
+__device__ __forceinline__ double bc_model_value_np(double p, double ra, double sa, const double* c) {
+  switch (MODEL) {
+    case BC_MODEL_LINREG_BETA: {
+      const double q = (ra * ra - p * (2. * ra)) + p * p;
+      return c[0] * (c[1] * bc_exp_like_numpy(c[2] * q) + c[3]);
+    }
+    case BC_MODEL_GAUSS_BETA: {
+      const double q = (ra + sa) - 2. * p;
+      return c[0] * bc_exp_like_numpy(c[1] * q) - c[2];
+    }
+    case BC_MODEL_GAUSS_BETA_GRAD: {
+      const double q = (ra + sa) - 2. * p;
+      const double gq = bc_exp_like_numpy(c[1] * q);
+      const double t1 = c[3] * (c[0] * gq - c[2]);
+      const double t2 = c[4] * gq;
+      const double t3 = c[5] * q * gq;
+      return ((t1 - t2) - t3) - c[6];
+    }
+    default:
+      return bc_model_value<MODEL>(p, ra, sa, c);
+  }
+}
+template <int MODEL>
+constexpr bool bc_model_has_np_exp() { return MODEL == BC_MODEL_LINREG_BETA || MODEL == BC_MODEL_GAUSS_BETA || MODEL == BC_MODEL_GAUSS_BETA_GRAD; }
+
+// the constant of a constant row from the contraction value `p` of the lane's first sample: every lane of the row
+// evaluates its own (they agree up to the last bit), the lane with g == 0 decides
+template <int MODEL>
+__device__ __forceinline__ double bc_const_row_value(double devval, double p, double ra, double sa, const double* c, int lane) {
+  if (!bc_model_has_np_exp<MODEL>()) return devval;
+  double v = bc_model_value_np<MODEL>(p, ra, sa, c);
+  v = __shfl(v, lane & 15, BC_WAVE);
+  // the restated value is the same number as the device's own up to the last bits; anything else means the row is
+  // constant for another reason than equal arguments (it then keeps the device's value)
+  return (fabs(v - devval) <= 1e-13 * fabs(devval)) ? v : devval;
 }
 
 // NT = number of 16-sample accumulator tiles, KC = D-chunk staged per LDS pass,
@@ -333,7 +385,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         for (int reg = 0; reg < 4; ++reg) {
           const int s = 16 * st + g + 4 * reg;
           if (s < S) {
-            const double v = live ? bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c) : 0.;
+            const double v = live ? bc_model_value_np<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c) : 0.;
             rbase[(size_t)(a.s_off + s) * BC_TILE + jt] = v;
           }
         }
@@ -353,6 +405,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
       const double ra = ra_pf[jt];
+      const double p00 = acc[jt][0][0];          // the contraction value of the lane's first sample (constant rows, below)
       double sum = 0.;
 #pragma unroll
       for (int st = 0; st < NT; ++st)
@@ -411,7 +464,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         ok &= (d0 == __shfl_xor(d0, 32, BC_WAVE)) ? 1 : 0;
         ok &= __shfl_xor(ok, 32, BC_WAVE);
         if (ok) {                                    // the four lanes of a constant row take this together
-          const double cval = mean + d0;
+          const double cval = bc_const_row_value<MODEL>(mean + d0, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
           mean = bc_np_sum_const_256(cval, S) / (double)S;
           const double v = cval - mean;
           sq = 0.;
@@ -447,6 +500,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     const long long gr = r0 + row_base + jt;
     const bool live = gr < a.n_rows;
     const double ra = ra_pf[jt];
+    const double p00 = acc[jt][0][0];            // the contraction value of the lane's first sample (constant rows, below)
     double sum = 0., vmin = INFINITY, vmax = -INFINITY;
     // TL > 0 kernels (96 < S <= 100): every sample of the NT tiles is a real one and every lane holds some, so the
     // `s < S` predicates vanish and "all S values equal" is tracked with compares against the lane's first value
@@ -506,6 +560,17 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny constant
     // residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The tree-order sum
     // above would round differently and flip that zero / non-zero status, so such rows use NumPy's order.
+    if (bc_model_has_np_exp<MODEL>() && __builtin_amdgcn_ballot_w64(constant_row && live) != 0ull) {
+      const double cnp = bc_const_row_value<MODEL>(cval, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
+      if (constant_row && live) {                // the reference's bits for the constant: every element of the row IS it
+        cval = cnp;
+#pragma unroll
+        for (int st = 0; st < NT; ++st)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[jt][st][reg] = cnp;
+        if (TL > 0) tv[jt] = cnp;
+      }
+    }
     const double mean = (constant_row ? bc_np_sum_const_256(cval, S) : sum) / (double)S;   // lls.mean(axis=1)
     double sq = 0.;
 #pragma unroll

@@ -6,8 +6,12 @@ consistency of the device reductions): nnz <= m, size() == nnz, w >= 0, error mo
 ||sum_i w_i Phi_i - sum_i Phi_i|| recomputed from gathered rows, b == Phi^T 1 via an independent device
 matvec, K4 == torch fp64 GEMM, determinism (two builds give identical bits), and a 200k-row prefix of
 the same data reproduces the oracle's selections exactly."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -218,3 +222,44 @@ def test_config4_headline_size(env, shard):
     del phi, data, Z, h
     prj.forget()
     torch.cuda.empty_cache()
+
+
+def test_config1_stated_size_giga_vs_oracle():
+    """BASELINE configs[0] at its stated size: the examples/zellner_gaussian recipe (main.py:33-54: N = 10 000 clean rows,
+    d = 8, three outlier clusters of N/50, N/50, N/10 rows, S = 200 samples from the exact posterior = `prj_optimal`,
+    main.py:71,106), GIGA via HilbertCoreset, 50 greedy steps -- device (K1 Gaussian log-likelihood + fused greedy loop)
+    against the oracle fed with the same RNG stream: selections bit-exact after every step, weights within 1e-5, the
+    projection within 1e-11."""
+    import importlib.util
+    import beta_cores_amd as bc
+    path = os.path.join(ROOT, 'examples', 'zellner_gaussian.py')
+    spec = importlib.util.spec_from_file_location('zellner_gaussian_example_full', path)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    N, d, S, steps, tr = 10_000, 8, 200, 50, 3
+    res = ex.run('GIGAO', tr, N=N, d=d, M=steps, proj_dim=S, verbose=False)
+    # the oracle side: the script's statements in the script's order (same seed -> same data, same Theta)
+    np.random.seed(tr)
+    mu0, Sig0 = np.zeros(d), np.eye(d)
+    Sig = 500 * np.eye(d)
+    th = np.zeros(d)
+    Sig0inv, Siginv = np.linalg.inv(Sig0), np.linalg.inv(Sig)
+    logdetSig = np.linalg.slogdet(Sig)[1]
+    X = np.random.multivariate_normal(th, Sig, N)
+    mup, LSigp, _ = M.gauss_weighted_post(mu0, Sig0inv, Siginv, X, np.ones(X.shape[0]))
+    Xc = np.concatenate((X, np.random.multivariate_normal(th + 200, 0.5 * Sig, int(N / 50.)),
+                         np.random.multivariate_normal(th + 150, 0.1 * Sig, int(N / 50.)),
+                         np.random.multivariate_normal(th, 10 * Sig, int(N / 10.))))
+    assert Xc.shape == (11_400, d) and np.array_equal(res['Xc'], Xc)
+    theta = mup + np.random.randn(S, mup.shape[0]).dot(LSigp.T)          # prj_optimal's constructor draw (projector.py:18)
+    ll = lambda x, t: M.gauss_loglik(x, t, Siginv, logdetSig)
+    ref = C.RefHilbert(Xc, ll, theta)
+    assert ref.vecs.shape[0] == Xc.shape[0]                              # no all-zero rows: indices are data rows
+    dev_phi = np.asarray(bc.DeviceProjector(lambda n, w, p: theta, S, bc.likelihoods.GaussianLocation(Siginv, logdetSig)).project(Xc))
+    assert np.abs(dev_phi - ref.vecs).max() <= 1e-11 * (1. + np.abs(ref.vecs).max())
+    for m in range(1, steps + 1):
+        ref.build(1, m)
+        np.testing.assert_array_equal(res['idcs'][m], ref.idcs)
+        np.testing.assert_allclose(res['w'][m], ref.wts, rtol=1e-5)
+    assert len(res['idcs'][steps]) > 10
+    assert res['rkl'][steps] < res['rkl'][1]                              # the coreset posterior approaches the exact one
