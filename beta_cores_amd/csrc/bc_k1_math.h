@@ -1,0 +1,79 @@
+// The transcendental bodies of the K1 epilogue: exp(x) and log1p(exp(-a)), table-driven, division-free.
+//
+// Why not libm: the logistic projections evaluate one log1p(exp(.)) (and the beta-likelihood three more exp) per
+// element of Phi, 10^8 times per million rows, on the vector pipe that the fp64 matrix cores keep busy (K1's time is
+// the SUM of its MFMA time and its other vector work).  Round 2's written-out bodies (Cody-Waite +
+// degree-12 polynomial, 2 atanh series, TWO fp64 divisions) cost ~106 vector instructions per element of the
+// logistic log-likelihood (SQ_INSTS_VALU, profiles/r03_k1_pmc_logistic.csv); these cost ~36:
+//
+//   exp(x):  x = (64 e + j) ln2/64 + r, |r| <= ln2/128;  exp(x) = 2^e * T[j] * (1 + r + r^2/2 + ... + r^5/120)
+//            (T[j] = 2^(j/64) from LDS; truncation r^6/720 <= 3.5e-17)
+//   log1p(exp(-a)), a >= 0:  u = exp(-a), f = 1 + u in (1, 2];  i = round(256 (f - 1)), c_i = 1 + i/256;
+//            ln f = lc_i + log1p(t),  t = f*rc_i - 1 (one fma, |t| <= 2^-9),  rc_i = RN(1/c_i), lc_i = RN(-ln rc_i)
+//            (the log of the ROUNDED reciprocal: the identity is exact), log1p(t) to degree 6 (t^7/7 <= 8e-18 t), plus
+//            the first-order term (u - (f - 1)) * rc_i for the rounding of 1 + u.  Entry 0 is {1, 0}: for small u the
+//            result keeps u's relative accuracy; entry 256 is {1/2, RN(ln 2)}: a = 0 gives exactly RN(ln 2).
+//
+// Measured against 80-bit arithmetic (tests/test_k1_math_cpu.py, two million arguments each): exp <= 1.0 ulp,
+// log1p(exp(-a)) <= 1.6 ulp.  Parity bar of the projections: 1e-11 * (1 + max|f|) against the reference (golden F2).
+//
+// `tab` points at BC_K1_TAB_DOUBLES doubles laid out as bc_k1_tables.h says (in LDS inside K1).
+// Plain C99 / C++: compiled by hipcc for the device and by gcc for the host-side accuracy test.
+#ifndef BC_K1_MATH_H
+#define BC_K1_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "bc_k1_tables.h"
+
+#if defined(__HIPCC__)
+#define BC_KM __host__ __device__ __forceinline__
+#else
+#define BC_KM static inline
+#endif
+
+// exp(x) for |x| <= 2e4 (beyond 745 / 709 the result is 0 / +inf through ldexp); a NaN gives a NaN.  No clamps: the
+// callers bound their arguments once per element instead of twice per exp (a compare-and-select pair on doubles is
+// four instructions).
+BC_KM double bc_exp_tab_core(double x, const double* tab) {
+  const double kd = rint(x * 92.33248261689366);       // 64 / ln 2
+  double r = fma(-kd, 0.010830424695086549, x);        // ln2/64, high 32 bits: kd * hi is exact for |kd| < 2^21
+  r = fma(-kd, 1.162596423439437e-12, r);              // ln2/64, low part
+  const int ki = (int)kd;
+  const int j = ki & 63, e = ki >> 6;                  // ki = 64 e + j, j in 0..63 (arithmetic shift)
+  double p = fma(r, 1. / 120., 1. / 24.);
+  p = fma(p, r, 1. / 6.);
+  p = fma(p, r, 0.5);
+  p = fma(p, r * r, r);                                // exp(r) - 1
+  const double t = tab[j];
+  return ldexp(fma(t, p, t), e);
+}
+
+// exp(x) for any x (NaN in, NaN out)
+BC_KM double bc_exp_tab(double x, const double* tab) {
+  const double xc = fmin(fmax(x, -800.), 800.);        // (fmax / fmin drop a NaN: restored below)
+  const double r = bc_exp_tab_core(xc, tab);
+  return (x != x) ? x : r;
+}
+
+// log(1 + exp(-a)) for 0 <= a <= 2e4 (a NaN gives a NaN)
+BC_KM double bc_log1p_exp_neg_tab(double a, const double* tab) {
+  const double u = bc_exp_tab_core(-a, tab);
+  const double f = 1. + u;
+  const double fm1 = f - 1.;                           // exact
+  int i = (int)fma(fm1, 256., 0.5);                    // nearest c_i = 1 + i/256, i in 0..256
+  i = (i < 0) ? 0 : ((i > 256) ? 256 : i);             // (a NaN converts to an arbitrary int: keep the index in range)
+  const double rc = tab[BC_K1_EXP_N + 2 * i], lc = tab[BC_K1_EXP_N + 2 * i + 1];
+  const double t = fma(f, rc, -1.);
+  double q = fma(t, -1. / 6., 1. / 5.);
+  q = fma(q, t, -1. / 4.);
+  q = fma(q, t, 1. / 3.);
+  q = fma(q, t, -1. / 2.);
+  q = q * t;
+  const double s = fma(q, t, t);                       // log1p(t)
+  const double c = (u - fm1) * rc;                     // d/df ln f * (rounding error of 1 + u)
+  return lc + (s + c);
+}
+
+#endif  // BC_K1_MATH_H

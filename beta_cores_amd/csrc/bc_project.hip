@@ -16,6 +16,7 @@
 //   model_linreg.py:4-10 / model_neurlinr.py:90-97,102-110 / model_lr.py:72-86 / gaussian.py:7-15,34-62
 #include "bc_internal.h"
 #include "bc_np_exp.h"
+#include "bc_k1_math.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -63,55 +64,14 @@ struct ProjArgs {
 #define KSTAMP(i) do { } while (0)
 #endif
 
-// ---- the two transcendental building blocks of the logistic models, written out (the libm versions are general-purpose:
-// ~150-200 instructions per log1p(exp(m)); these are ~55, which is what the logistic projections are bound by).
-// exp(x) for x <= 0: Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, degree-12 Taylor polynomial in Horner form
-// (next term r^13/13! <= 1.7e-16), v_ldexp.  x below -745 gives 0 like exp().
-__device__ __forceinline__ double bc_exp_nonpos(double x) {
-  x = (x < -800.) ? -800. : x;                       // (a NaN stays a NaN: the result is NaN like exp()'s)
-  const double k = rint(x * 1.4426950408889634);
-  double r = fma(-k, 6.93147180369123816490e-01, x);
-  r = fma(-k, 1.90821492927058770002e-10, r);
-  double p = 1. / 479001600.;
-  p = fma(p, r, 1. / 39916800.);
-  p = fma(p, r, 1. / 3628800.);
-  p = fma(p, r, 1. / 362880.);
-  p = fma(p, r, 1. / 40320.);
-  p = fma(p, r, 1. / 5040.);
-  p = fma(p, r, 1. / 720.);
-  p = fma(p, r, 1. / 120.);
-  p = fma(p, r, 1. / 24.);
-  p = fma(p, r, 1. / 6.);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.);
-  p = fma(p, r, 1.);
-  return ldexp(p, (int)k);
-}
+// ---- lookup tables of the epilogue's exp / log1p(exp(-a)) bodies (bc_k1_math.h): 578 doubles in global memory, copied
+// into LDS by every block of a model that needs them (behind the staging buffers; ~4.6 KB next to the 61 KB those take)
+__device__ const unsigned long long g_k1_tab_bits[BC_K1_TAB_DOUBLES] = BC_K1_TABLE_INIT;
 
-// log1p(exp(-a)) for a >= 0 (NaN in, NaN out): u = exp(-a) in (0, 1], f = 1 + u in (1, 2] halved above sqrt(2),
-// log f' = 2 atanh(t), t = (f' - 1) / (f' + 1), |t| <= 0.172 (odd series to t^21), plus the first-order correction for
-// the rounding of 1 + u.  Measured against 80-bit arithmetic over m in [-800, 100): at most 4.4 ulp, 0.4 on average
-// (log1p(exp(m)) of glibc: 1.6 / 0.25); exactly log 2 at a = 0.
-__device__ __forceinline__ double bc_log1p_exp_neg(double a) {
-  const double u = bc_exp_nonpos(-a);
-  const double f = 1. + u;
-  const bool hi = f > 1.4142135623730951;
-  const double fp = hi ? 0.5 * f : f;
-  const double t = (fp - 1.) / (fp + 1.);
-  const double t2 = t * t;
-  double q = 2. / 21.;
-  q = fma(q, t2, 2. / 19.);
-  q = fma(q, t2, 2. / 17.);
-  q = fma(q, t2, 2. / 15.);
-  q = fma(q, t2, 2. / 13.);
-  q = fma(q, t2, 2. / 11.);
-  q = fma(q, t2, 2. / 9.);
-  q = fma(q, t2, 2. / 7.);
-  q = fma(q, t2, 2. / 5.);
-  q = fma(q, t2, 2. / 3.);
-  q = fma(q, t2, 2.);
-  const double c = (u - (f - 1.)) / f;
-  return fma(q, t, hi ? 0.6931471805599453 : 0.) + c;
+template <int MODEL>
+constexpr bool bc_model_uses_tables() {
+  return MODEL == BC_MODEL_LINREG_BETA || MODEL == BC_MODEL_LOGISTIC_LL || MODEL == BC_MODEL_LOGISTIC_BETA ||
+         MODEL == BC_MODEL_GAUSS_BETA || MODEL == BC_MODEL_GAUSS_BETA_GRAD;
 }
 
 // model_lr.py:81-86 evaluates two exp and three pow per element; here the powers go through
@@ -120,20 +80,25 @@ __device__ __forceinline__ double bc_log1p_exp_neg(double a) {
 // i.e. one log1p(exp) and three exp.  Same saturation as the reference's IEEE overflow semantics (m -> +inf: +1,
 // m -> -inf: -1/b); where the reference flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the
 // 1e-11 of the parity tolerance.
-// (With the general libm bodies -- one log1p, four exp -- inlined, the epilogue's fully unrolled loops over the
-// accumulators exceeded the unroller's budget, stayed rolled, indexed the accumulator array dynamically and so pushed it
-// into scratch memory: 438 scratch stores inside the contraction loop of the S = 100 kernel, 4.9 ms per 1M rows.  With
-// the short bodies above the loops unroll again: 0.92 ms.)
-__device__ __forceinline__ double bc_logistic_beta_value(double m, double c0, double c1, double c2) {
-  const double am = fabs(m);
-  const double Ls = bc_log1p_exp_neg(am);            // log(1 + e^-|m|)
+// BC_K1_GROUP (build-time): how many elements of a row the epilogue lets the scheduler interleave (see the S = 100
+// epilogue); the beta-logistic element is four transcendental bodies by itself
+#ifndef BC_K1_GROUP
+#define BC_K1_GROUP 2
+#endif
+__device__ __forceinline__ double bc_logistic_beta_value(double m, double c0, double c1, double c2, const double* tab) {
+  const double am = fmin(fabs(m), 800.);              // beyond that every term has saturated (fmin drops a NaN: restored below)
+  const double Ls = bc_log1p_exp_neg_tab(am, tab);    // log(1 + e^-|m|)
   const double Ll = Ls + am;                          // log(1 + e^+|m|)
   const double L1 = (m <= 0.) ? Ls : Ll, L2 = (m <= 0.) ? Ll : Ls;
-  return -((c0 * bc_exp_nonpos(c1 * L1)) - (bc_exp_nonpos(c2 * L1) + bc_exp_nonpos(c2 * L2)));
+  const double e1 = bc_exp_tab_core(c1 * L1, tab);    // arguments in [-(b+1) * 801, 0]
+  const double e2 = bc_exp_tab_core(c2 * L1, tab);
+  const double e3 = bc_exp_tab_core(c2 * L2, tab);
+  const double v = -((c0 * e1) - (e2 + e3));
+  return (m != m) ? m : v;
 }
 
 template <int MODEL>
-__device__ __forceinline__ double bc_model_value(double p, double ra, double sa, const double* c) {
+__device__ __forceinline__ double bc_model_value(double p, double ra, double sa, const double* c, const double* tab) {
   switch (MODEL) {
     // (2p)*y is evaluated as p*(2y): doubling is exact, so the product rounds to the same double, and 2y -- like y*y --
     // is a per-row value that stays out of the per-sample code
@@ -143,25 +108,26 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
     }
     case BC_MODEL_LINREG_BETA: {          // k0*(k1*exp(k2*q) + k3)
       const double q = (ra * ra - p * (2. * ra)) + p * p;
-      return c[0] * (c[1] * exp(c[2] * q) + c[3]);
+      return c[0] * (c[1] * bc_exp_tab(c[2] * q, tab) + c[3]);
     }
     case BC_MODEL_LOGISTIC_LL: {          // m = -z.th ; m < 100 ? -log1p(exp(m)) : -m ;  log1p(e^m) = max(m, 0) + log1p(e^-|m|)
       const double m = -p;
-      return (m < 100.) ? -(fmax(m, 0.) + bc_log1p_exp_neg(fabs(m))) : -m;
+      // (|m| is bounded for the body: past 800 it returns 0 either way; fmin drops a NaN, which the other branch keeps)
+      return (m < 100.) ? -(fmax(m, 0.) + bc_log1p_exp_neg_tab(fmin(fabs(m), 800.), tab)) : -m;
     }
     case BC_MODEL_LOGISTIC_BETA:          // -( (b+1)/b*(1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) ), out of line (below)
-      return bc_logistic_beta_value(-p, c[0], c[1], c[2]);
+      return bc_logistic_beta_value(-p, c[0], c[1], c[2], tab);
     case BC_MODEL_GAUSS_LL: {             // cc - 1/2*(xSx + tSt - 2*xSt)
       const double q = (ra + sa) - 2. * p;
       return c[0] - 1. / 2. * q;
     }
     case BC_MODEL_GAUSS_BETA: {           // 1/b*exp(-.5*b*q) - (1+b)^(-.5d-1)
       const double q = (ra + sa) - 2. * p;
-      return c[0] * exp(c[1] * q) - c[2];
+      return c[0] * bc_exp_tab(c[1] * q, tab) - c[2];
     }
     default: {                            // BC_MODEL_GAUSS_BETA_GRAD, gaussian.py:46-62
       const double q = (ra + sa) - 2. * p;
-      const double gq = exp(c[1] * q);
+      const double gq = bc_exp_tab(c[1] * q, tab);
       const double t1 = c[3] * (c[0] * gq - c[2]);
       const double t2 = c[4] * gq;
       const double t3 = c[5] * q * gq;
@@ -184,7 +150,7 @@ __device__ __forceinline__ double bc_exp_like_numpy(double x) {
 // bit-identical, and the two logistic ones are left to bc_model_value (log1p(exp(0)) = log 2 matches; the
 // beta-likelihood's np.power is not restated).
 template <int MODEL>
-__device__ __forceinline__ double bc_model_value_np(double p, double ra, double sa, const double* c) {
+__device__ __forceinline__ double bc_model_value_np(double p, double ra, double sa, const double* c, const double* tab) {
   switch (MODEL) {
     case BC_MODEL_LINREG_BETA: {
       const double q = (ra * ra - p * (2. * ra)) + p * p;
@@ -203,7 +169,7 @@ __device__ __forceinline__ double bc_model_value_np(double p, double ra, double 
       return ((t1 - t2) - t3) - c[6];
     }
     default:
-      return bc_model_value<MODEL>(p, ra, sa, c);
+      return bc_model_value<MODEL>(p, ra, sa, c, tab);
   }
 }
 template <int MODEL>
@@ -214,7 +180,7 @@ constexpr bool bc_model_has_np_exp() { return MODEL == BC_MODEL_LINREG_BETA || M
 template <int MODEL>
 __device__ __forceinline__ double bc_const_row_value(double devval, double p, double ra, double sa, const double* c, int lane) {
   if (!bc_model_has_np_exp<MODEL>()) return devval;
-  double v = bc_model_value_np<MODEL>(p, ra, sa, c);
+  double v = bc_model_value_np<MODEL>(p, ra, sa, c, nullptr);
   v = __shfl(v, lane & 15, BC_WAVE);
   // the restated value is the same number as the device's own up to the last bits; anything else means the row is
   // constant for another reason than equal arguments (it then keeps the device's value)
@@ -244,6 +210,10 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   extern __shared__ double lds[];
   double* Zl = lds;                    // [128][LDZ]
   double* Tl = lds + 128 * LDZ;        // [NR][LDT]   (reused for the column partials after the loop)
+  double* tabl = lds + 128 * LDZ + NR * LDT;      // lookup tables of the epilogue's exp / log bodies (models that have one)
+  if (bc_model_uses_tables<MODEL>()) {
+    for (int i = threadIdx.x; i < BC_K1_TAB_DOUBLES; i += NTHR) tabl[i] = __builtin_bit_cast(double, g_k1_tab_bits[i]);
+  }                                               // visible after the first barrier of the contraction loop
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -385,7 +355,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         for (int reg = 0; reg < 4; ++reg) {
           const int s = 16 * st + g + 4 * reg;
           if (s < S) {
-            const double v = live ? bc_model_value_np<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c) : 0.;
+            const double v = live ? bc_model_value_np<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c, tabl) : 0.;
             rbase[(size_t)(a.s_off + s) * BC_TILE + jt] = v;
           }
         }
@@ -408,15 +378,21 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
       const double p00 = acc[jt][0][0];          // the contraction value of the lane's first sample (constant rows, below)
       double sum = 0.;
 #pragma unroll
-      for (int st = 0; st < NT; ++st)
+      for (int st = 0; st < NT; ++st) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const double v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[16 * st + g + 4 * reg] : 0., a.c);
+          const double v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[16 * st + g + 4 * reg] : 0., a.c, tabl);
           acc[jt][st][reg] = v;
           sum += v;
+          // Pin every BC_K1_GROUP elements: left to itself the compiler splits the table-driven bodies in two stages -- index
+          // and LDS read of all 25 elements of the row first, polynomials afterwards -- keeps every intermediate alive in
+          // between and spills ~900 VGPRs (the beta-logistic instantiation).  The empty asm consumes the finished values
+          // (ordering the arithmetic) and its memory clobber keeps the next group's table reads behind it.
+          if (bc_model_uses_tables<MODEL>() && ((4 * st + reg + 1) % BC_K1_GROUP) == 0) asm volatile("" : "+v"(acc[jt][st][reg]), "+v"(sum) :: "memory");
         }
+      }
       {
-        const double v = (s_tail < S) ? bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c) : 0.;
+        const double v = (s_tail < S) ? bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c, tabl) : 0.;
         tv[jt] = v;
         sum += v;
       }
@@ -515,22 +491,23 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
         const int s = 16 * st + g + 4 * reg;
         double v = 0.;
         if (TL > 0) {
-          if (live) v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c);
+          if (live) v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c, tabl);
           if (st == 0 && reg == 0) vref = v;
           differs |= (v != vref);
         } else if (s < S && live) {
-          v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c);
+          v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c, tabl);
           vmin = fmin(vmin, v);
           vmax = fmax(vmax, v);
         }
         acc[jt][st][reg] = v;
         sum += v;
       }
+      if (bc_model_uses_tables<MODEL>()) asm volatile("" : "+v"(sum) :: "memory");     // see the S = 100 path above
     }
     if (TL > 0) {
       double v = 0.;
       if (s_tail < S && live) {
-        v = bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c);
+        v = bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c, tabl);
         differs |= (v != vref);
       }
       tv[jt] = v;
@@ -800,6 +777,7 @@ enum { PROJ_FULL = 0, PROJ_RAW = 1, PROJ_COLSUM = 2 };
 template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0, bool STORE = true>
 static int launch_project(bc_ctx* ctx, const ProjArgs& a, long long ntiles) {
   size_t lds = (size_t)(128 * (KC + 1) + (NT * 16 + TL) * (KC + 2)) * sizeof(double);
+  if (bc_model_uses_tables<MODEL>()) lds += (size_t)BC_K1_TAB_DOUBLES * sizeof(double);
 #ifdef BC_K1_STAMPS
   if (getenv("BC_K1_EXTRA_LDS")) lds += (size_t)atoi(getenv("BC_K1_EXTRA_LDS"));   // diagnostic: fewer blocks per CU
 #endif

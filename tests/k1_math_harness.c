@@ -1,0 +1,60 @@
+/* Host-side accuracy check of beta_cores_amd/csrc/bc_k1_math.h (the K1 epilogue's exp and log1p(exp(-a))) against
+ * 80-bit long double arithmetic: prints the maximum and mean error in ulp over n pseudo-random arguments.
+ * Built and driven by tests/test_k1_math_cpu.py. */
+#include <stdio.h>
+#include <stdlib.h>
+#include "bc_k1_math.h"
+
+static double ulp_of(double v) {
+  if (v == 0.0) return 4.9406564584124654e-324;
+  double a = fabs(v);
+  return nextafter(a, INFINITY) - a;
+}
+
+static unsigned long long s = 88172645463325252ull;
+static double rnd(void) {      /* xorshift64, uniform in [0, 1) */
+  s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+  return (double)(s >> 11) * (1.0 / 9007199254740992.0);
+}
+
+int main(int argc, char** argv) {
+  const long n = argc > 1 ? atol(argv[1]) : 1000000;
+  const unsigned long long tabbits[BC_K1_TAB_DOUBLES] = BC_K1_TABLE_INIT;
+  double tab[BC_K1_TAB_DOUBLES];
+  memcpy(tab, tabbits, sizeof(tab));
+  double emax = 0, esum = 0, lmax = 0, lsum = 0, xe = 0, xl = 0;
+  for (long k = 0; k < n; ++k) {
+    /* exp: arguments over the whole range the projections produce, dense near 0 */
+    double x = (k & 1) ? -700.0 * rnd() : -40.0 * rnd() * rnd() * rnd();
+    if ((k & 7) == 7) x = 700.0 * rnd();
+    const long double we = expl((long double)x);
+    const double ge = bc_exp_tab(x, tab);
+    const double ee = (double)(fabsl((long double)ge - we) / (long double)ulp_of((double)we));
+    if (ee > emax) { emax = ee; xe = x; }
+    esum += ee;
+    /* log1p(exp(-a)) */
+    double a = (k & 1) ? 40.0 * rnd() : 8.0 * rnd() * rnd();
+    if ((k & 15) == 15) a = 700.0 * rnd();
+    const long double wl = log1pl(expl(-(long double)a));
+    const double gl = bc_log1p_exp_neg_tab(a, tab);
+    const double el = (double)(fabsl((long double)gl - wl) / (long double)ulp_of((double)wl));
+    if (el > lmax) { lmax = el; xl = a; }
+    lsum += el;
+  }
+  const double l0 = bc_log1p_exp_neg_tab(0.0, tab);
+  printf("exp: max %.3f ulp (at %.17g) mean %.3f | log1p_exp_neg: max %.3f ulp (at %.17g) mean %.3f | at0 %s\n", emax, xe, esum / n, lmax, xl,
+         lsum / n, l0 == 0.6931471805599453 ? "exact-ln2" : "NOT-ln2");
+  /* special values */
+  int ok = 1;
+  ok &= bc_exp_tab(0.0, tab) == 1.0;
+  ok &= bc_exp_tab(-1000.0, tab) == 0.0;
+  ok &= isinf(bc_exp_tab(1000.0, tab));
+  ok &= isnan(bc_exp_tab(NAN, tab));
+  ok &= isnan(bc_log1p_exp_neg_tab(NAN, tab));
+  ok &= bc_log1p_exp_neg_tab(800.0, tab) == 0.0;
+  ok &= bc_log1p_exp_neg_tab(20000.0, tab) == 0.0;
+  ok &= bc_exp_tab(-1e300, tab) == 0.0 && isinf(bc_exp_tab(1e300, tab)) && bc_exp_tab(-INFINITY, tab) == 0.0;
+  ok &= bc_log1p_exp_neg_tab(50.0, tab) == exp(-50.0) || fabs(bc_log1p_exp_neg_tab(50.0, tab) / exp(-50.0) - 1.0) < 4e-16;
+  printf("special %s\n", ok ? "ok" : "BAD");
+  return ok ? 0 : 1;
+}
