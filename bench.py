@@ -131,6 +131,23 @@ def fp64_sweep_leg(bc, ctx, alg, cls, barrier, n_local, S, args):
             'same_selections_as_prefiltered_run': bool(np.array_equal(a[:m], b[:m])), 'compared_steps': int(m)}
 
 
+def k4_entry(n, d, ms):
+    """K4 numbers that cannot exceed 1: the kernel computes the upper-triangular BT x BT tiles only (bc_gram.hip), so the
+    matrix pipe executes  tiles * 2*N*BT^2  flop, not the 2*N*(D+1)^2 of the full Gram matrix; `ms` covers the Gram kernel
+    AND its two-level split-order reduction (bc_timer brackets all three launches)."""
+    bt = 128 if d > 64 else 64
+    nt = -(-d // bt)
+    ntri = nt * (nt + 1) // 2
+    executed = 2.0 * n * ntri * bt * bt
+    full = 2.0 * n * (d + 1) * (d + 1)
+    return {'kernel_ms (gram + reduce)': ms, 'tile': bt, 'tiles_computed': ntri, 'tiles_full_square': nt * nt,
+            'executed_tflops': executed / (ms * 1e-3) / 1e12,
+            'frac_of_fp64_mfma_peak': executed / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
+            'symmetry_factor': full / executed,
+            'effective_tflops_of_full_gram': full / (ms * 1e-3) / 1e12,
+            'bytes_per_launch': 8.0 * n * (d + 1), 'hbm_frac': 8.0 * n * (d + 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def _time_k1(ctx, call, barrier, reps=4, warm=2):
     for _ in range(warm):
         call()
@@ -224,8 +241,7 @@ def other_configs(torch, bc, ctx, dev, barrier, no_cpu=False):
         barrier()
         ms4, n4 = ctx.kernel_time(2)
         ms4 /= max(n4, 1)
-        k4[nm] = {'kernel_ms': ms4, 'tflops': 2.0 * n * (d + 1) * (d + 1) / (ms4 * 1e-3) / 1e12,
-                  'frac_of_fp64_mfma_peak': 2.0 * n * (d + 1) * (d + 1) / (ms4 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}
+        k4[nm] = k4_entry(n, d, ms4)
     mu, L, _ = bc.weighted_post(np.zeros(d), np.eye(d), 1.0, data, None)
     theta = mu + np.random.default_rng(51).standard_normal((S, d)).dot(L.T)
     prj = bc.DeviceBetaProjector(lambda k, ww_, p: theta, S, bc.likelihoods.LinearRegression(1.0), ctx=ctx)
@@ -236,6 +252,45 @@ def other_configs(torch, bc, ctx, dev, barrier, no_cpu=False):
     del prj, data, Z
     torch.cuda.empty_cache()
     return res, beta_legs
+
+
+class NativeCallTimer:
+    """Wall time per C entry point while active (patches beta_cores_amd._native.call): the breakdown of solver_init."""
+
+    def __init__(self, bc):
+        import beta_cores_amd._native as N
+        self.N = N
+        self.acc = {}
+
+    def __enter__(self):
+        import beta_cores_amd.device as dv
+        import beta_cores_amd.coreset.projector as pj
+        import beta_cores_amd.snnls.engine as en
+        self.mods = [m for m in (self.N, dv.N, pj.N, en.N) if m is not None]
+        self.orig = self.N.call
+        acc, orig = self.acc, self.orig
+
+        def timed(name, *a):
+            t0 = time.perf_counter()
+            try:
+                return orig(name, *a)
+            finally:
+                acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0)
+        self.N.call = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.N.call = self.orig
+        return False
+
+    def ms(self, name):
+        return 1e3 * self.acc.get(name, 0.0)
+
+    def total_ms(self):
+        return 1e3 * sum(self.acc.values())
+
+    def other_ms(self, names):
+        return 1e3 * sum(v for k, v in self.acc.items() if k not in names)
 
 
 def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, opt_seed=7, oracle_rows=None, Z_host=None):
@@ -472,10 +527,22 @@ def main():
 
     # ---------------- solver construction (b, norms already fused into K1)
     cls = bc.snnls.GIGA if args.alg == 'giga' else bc.snnls.FrankWolfe
-    t0 = time.perf_counter()
-    alg = bc.HilbertCoreset(data, prj, snnls=cls, comm=comm)
-    barrier()
-    t_init = time.perf_counter() - t0
+    phi = None                             # hand the 8 GB Phi of the projection runs back to the projector's pool: the coreset's
+    barrier()                              # own projection reuses it instead of hipMalloc'ing a second one inside the timed init
+    ctx.enable_timing(True)
+    ctx.kernel_time_reset()
+    with NativeCallTimer(bc) as nct:
+        t0 = time.perf_counter()
+        alg = bc.HilbertCoreset(data, prj, snnls=cls, comm=comm)
+        barrier()
+        t_init = time.perf_counter() - t0
+    k1i_ms, k1i_n = ctx.kernel_time(1)
+    init_parts = {'phi_alloc (bc_phi_create)': nct.ms('bc_phi_create'),
+                  'K1 kernel (HIP events)': k1i_ms,
+                  'bc_project host side + column-sum / norm statistics (two small kernels, one sync)': max(0.0, nct.ms('bc_project') - k1i_ms),
+                  'solver create: mirror allocation + k_build_i8 + state (bc_snnls_create)': nct.ms('bc_snnls_create'),
+                  'other native calls': nct.other_ms(('bc_phi_create', 'bc_project', 'bc_snnls_create')),
+                  'python / collectives': max(0.0, 1e3 * t_init - nct.total_ms())}
     total = args.warmup + args.steps
 
     # ---------------- greedy iterations: W untimed, then exactly K timed
@@ -559,11 +626,10 @@ def main():
                            'roofline_fp64_mfma': {'achieved': k1_flops / (k1_ms_per * 1e-3) / 1e12,
                                                   'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
                                                   'frac': k1_flops / (k1_ms_per * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}},
-            'posterior_gram': {'kernel_ms': k4_ms / max(k4_n, 1), 'wall_ms': 1e3 * t_post,
-                               'tflops': 2.0 * n_local * (D + 1) * (D + 1) / max(k4_ms / max(k4_n, 1), 1e-9) / 1e9,
-                               'note': 'K4 X^T W X on fp64 MFMA, all local rows, w = 1 (sampler set-up, untimed)'},
+            'posterior_gram': dict(k4_entry(n_local, D, max(k4_ms / max(k4_n, 1), 1e-9)), wall_ms=1e3 * t_post,
+                                   note='K4 X^T W X on fp64 MFMA, all local rows, w = 1 (sampler set-up, cold first launch)'),
             'prefilter': dict(zip(('sweeps', 'candidates_rescored', 'fp64_fallbacks'), alg.snnls._eng.prefilter_stats())),
-            'solver_init_ms': 1e3 * t_init, 'setup_s': t_setup,
+            'solver_init_ms': 1e3 * t_init, 'solver_init': init_parts, 'setup_s': t_setup,
             'coreset': {'size': int(len(idcs)), 'error': err, 'failed_steps': int(st_tr.sum())},
         }
 

@@ -10,6 +10,7 @@
 // split order by a second kernel, so the result is run-to-run deterministic.
 #include "bc_internal.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -22,6 +23,7 @@ struct GramArgs {
   double* partial_y;      // [splits][nt*BT]   X^T (w*y), accumulated by the diagonal-tile blocks
   long long n_rows;
   long long rows_per_split;   // multiple of KR
+  long long splits;
   int dz, d, nt;          // d = number of x columns (y is column d), nt = number of BT-wide column tiles over d
   int ntri;               // nt*(nt+1)/2
 };
@@ -38,9 +40,15 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int wa = wv >> 1, wb = wv & 1;   // wave position inside the block tile
-  // blockIdx.x = split * ntri + tri  (tiles of one split are neighbours => they share rows in L2)
-  const int tri = blockIdx.x % a.ntri;
-  const long long split = blockIdx.x / a.ntri;
+  // XCD-aware block -> (split, tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+  // one, each XCD has its own L2), and the ntri tiles of one row split all read the same rows: they are given block
+  // numbers that are equal modulo 8 and adjacent in that XCD's queue, so the rows are fetched from HBM once per split
+  // instead of once per tile (D = 512: ten tiles per split; with the tiles of a split on neighbouring block numbers,
+  // i.e. on ten different XCDs, the kernel moved 5x its algorithmic bytes and ran 13.5-19.8 ms instead of ~11).
+  const long long q = blockIdx.x >> 3;
+  const int tri = (int)(q % a.ntri);
+  const long long split = (q / a.ntri) * 8 + (blockIdx.x & 7);
+  if (split >= a.splits) return;
   int ta = 0, rem = tri;                 // tri -> (ta <= tb)
   while (rem >= a.nt - ta) { rem -= a.nt - ta; ++ta; }
   const int tb = ta + rem;
@@ -142,13 +150,38 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       }
 }
 
-// sum the per-split partial tiles in split order and scatter them (and their mirror images)
-// into the dense dz x dz matrix
-__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ partial,
-                                                    const double* __restrict__ partial_y, long long splits, int ntri,
-                                                    int nt, int bt, int dz, double* __restrict__ out,
-                                                    double* __restrict__ out_y) {
-  // grid = (ntri, bt*bt/256): one output element per thread, partials summed in split order
+// Sum of the per-split partial tiles IN SPLIT ORDER, in two levels so that it is parallel: level 1 adds runs of SEG
+// consecutive splits (one thread per element and run, eight loads in flight), level 2 adds the run sums in run order
+// and scatters the tile (and its mirror image) into the dense d x d matrix.  The association is fixed by (splits, SEG):
+// run-to-run deterministic.  (One level with one thread per element walked 2 048 splits serially: 0.81 ms at N = 10M,
+// D = 128, 13 % on top of the Gram kernel itself.)
+#define BC_GRAM_SEG 16
+__global__ __launch_bounds__(256) void k_gram_reduce1(const double* __restrict__ partial, long long splits, long long nruns,
+                                                     size_t tile_elems /* ntri*bt*bt */, double* __restrict__ part2) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long run = blockIdx.y;
+  if (e >= tile_elems) return;
+  const long long s0 = run * BC_GRAM_SEG;
+  long long s1 = s0 + BC_GRAM_SEG;
+  if (s1 > splits) s1 = splits;
+  const double* p = partial + e;
+  double acc = 0.0;
+  long long sp = s0;
+  for (; sp + 8 <= s1; sp += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sp + u) * tile_elems];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; sp < s1; ++sp) acc += p[(size_t)sp * tile_elems];
+  part2[(size_t)run * tile_elems + e] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_gram_reduce2(const double* __restrict__ part2, const double* __restrict__ partial_y,
+                                                     long long splits, long long nruns, int ntri, int nt, int bt, int dz,
+                                                     double* __restrict__ out, double* __restrict__ out_y) {
+  // grid = (ntri, bt*bt/256): one output element per thread
   const int tri = blockIdx.x;
   if (tri == 0 && blockIdx.y == 0)
     for (int c = threadIdx.x; c < dz; c += blockDim.x) {
@@ -163,18 +196,10 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
   if (e >= bt * bt) return;
   const int r = ta * bt + e / bt, c = tb * bt + e % bt;
   if (r >= dz || c >= dz || (ta == tb && r > c)) return;
+  const size_t tile_elems = (size_t)ntri * bt * bt;
+  const double* p = part2 + (size_t)tri * bt * bt + e;
   double acc = 0.0;
-  const double* p = partial + (size_t)tri * bt * bt + e;
-  const size_t stride = (size_t)ntri * bt * bt;
-  long long sp = 0;
-  for (; sp + 8 <= splits; sp += 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sp + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
-  }
-  for (; sp < splits; ++sp) acc += p[(size_t)sp * stride];
+  for (long long run = 0; run < nruns; ++run) acc += p[(size_t)run * tile_elems];
   out[(size_t)r * dz + c] = acc;
   out[(size_t)c * dz + r] = acc;
 }
@@ -194,8 +219,14 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   const int nt = (d + BT - 1) / BT;
   const int ntri = nt * (nt + 1) / 2;
   const int KR = 16;
-  // enough blocks for ~8 per CU, at least 2 slabs per split
-  long long want_splits = ((long long)ctx->n_cu * 8 + ntri - 1) / ntri;
+  // Row splits, in units of the 2 * n_cu resident block slots (BC_GRAM_WAVES overrides), at least 2 slabs per split.
+  // One tile (D <= 128): exactly one block per slot -- every further split writes, and the reduction reads back, another
+  // 128 KB tile (8 per slot were 268 MB of partials at N = 10M, D = 128: 6.06 ms with one, 7.76 ms with eight).  Several
+  // tiles (D = 512: ten): short blocks, eight rounds -- with one round the two blocks of a CU run in lock-step (both staging,
+  // then both on the matrix pipe) and the kernel takes 18.6 ms instead of 12.9 (profiles/r03_notes.md).
+  static const int waves_env = getenv("BC_GRAM_WAVES") ? atoi(getenv("BC_GRAM_WAVES")) : 0;
+  const int waves = waves_env > 0 ? waves_env : (ntri == 1 ? 1 : 8);
+  long long want_splits = ((long long)ctx->n_cu * 2 * (waves > 0 ? waves : 1) + ntri - 1) / ntri;
   long long max_splits = (data->n_rows + 2 * KR - 1) / (2 * KR);
   long long splits = want_splits < max_splits ? want_splits : max_splits;
   if (splits < 1) splits = 1;
@@ -204,9 +235,12 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   if (rps < KR) rps = KR;
   splits = (data->n_rows + rps - 1) / rps;
   if (splits < 1) splits = 1;
+  const long long nruns = (splits + BC_GRAM_SEG - 1) / BC_GRAM_SEG;
+  const size_t tile_elems = (size_t)ntri * BT * BT;
   double* partial = nullptr;
   double* partial_y = nullptr;
-  int rcb = gram_buf(ctx, 0, (size_t)splits * ntri * BT * BT, &partial);
+  // [splits] partial tiles, then [nruns] run sums behind them
+  int rcb = gram_buf(ctx, 0, (size_t)(splits + nruns) * tile_elems, &partial);
   if (!rcb) rcb = gram_buf(ctx, 1, (size_t)splits * nt * BT, &partial_y);
   if (rcb) return rcb;
   hipError_t e = hipSuccess;
@@ -217,21 +251,25 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   a.partial_y = partial_y;
   a.n_rows = data->n_rows;
   a.rows_per_split = rps;
+  a.splits = splits;
   a.dz = dz;
   a.d = d;
   a.nt = nt;
   a.ntri = ntri;
   int rc = bc_timer_begin(ctx, 2);
   if (!rc) {
-    hipLaunchKernelGGL(k_gram<BT>, dim3((unsigned)(splits * ntri)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_gram<BT>, dim3((unsigned)(((splits + 7) / 8) * 8 * ntri)), dim3(256), 0, ctx->stream, a);
     e = hipGetLastError();
   }
-  if (!rc && e == hipSuccess) rc = bc_timer_end(ctx, 2);
   if (!rc && e == hipSuccess) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3(ntri, (BT * BT + 255) / 256), dim3(256), 0, ctx->stream, partial, partial_y, splits, ntri, nt, BT, d,
-                       out_dev, outy_dev);
+    double* part2 = partial + (size_t)splits * tile_elems;
+    hipLaunchKernelGGL(k_gram_reduce1, dim3((unsigned)((tile_elems + 255) / 256), (unsigned)nruns), dim3(256), 0, ctx->stream, partial, splits,
+                       nruns, tile_elems, part2);
+    hipLaunchKernelGGL(k_gram_reduce2, dim3(ntri, (BT * BT + 255) / 256), dim3(256), 0, ctx->stream, part2, partial_y, splits, nruns, ntri,
+                       nt, BT, d, out_dev, outy_dev);
     e = hipGetLastError();
   }
+  if (!rc && e == hipSuccess) rc = bc_timer_end(ctx, 2);      // the timed region is the whole K4: Gram kernel + both reduction levels
   if (e != hipSuccess) return bc_hip_fail(e, "bc_weighted_gram", __FILE__, __LINE__);
   return rc;
 }

@@ -6,6 +6,8 @@ j = json.load(open(sys.argv[1]))
 print('it/s %.0f  ms/step %.4f  K3 frac %.3f  init %.1f ms  K1 %.3f ms (%.3f hbm)' % (
     j['value'], j['ms_per_step'], j['roofline']['frac'], j['solver_init_ms'], j['projection']['kernel_ms'],
     j['projection']['roofline_hbm']['frac']))
+print('init', json.dumps(j.get('solver_init')))
+print('K4 main', json.dumps(j.get('posterior_gram')))
 for e in j.get('beta_coreset', []):
     if 'cpu_baseline' in e:
         print('cpu', e['cpu_baseline'])
