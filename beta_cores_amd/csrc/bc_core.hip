@@ -314,6 +314,7 @@ int bc_phi_set_rows(bc_phi* p, int64_t n_rows) {
   p->ntiles = nt;
   p->sweep_blocks = bc_sweep_grid(p);
   p->stat_blocks = stat_blocks_for(nt);
+  p->part_rows = nt;
   p->stats_valid = false;
   return 0;
 }
@@ -468,13 +469,15 @@ __global__ __launch_bounds__(256) void k_layout_to_rowmajor(const double* __rest
 __global__ __launch_bounds__(256) void k_stats_stage1(const double* __restrict__ tile_part, long long ntiles, int s,
                                                      const double* __restrict__ norms, long long n_rows,
                                                      long long chunk, double* __restrict__ part2,
-                                                     double* __restrict__ nstat) {
+                                                     double* __restrict__ nstat, long long part_rows, long long pchunk) {
   __shared__ double red[32];
   __shared__ double part[256];
   const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63;
-  const long long t0 = (long long)blockIdx.x * chunk;
-  long long t1 = t0 + chunk;
-  if (t1 > ntiles) t1 = ntiles;
+  // column partials: block b owns rows [b * pchunk, (b + 1) * pchunk) of tile_part (one row per tile, or per wave of
+  // the Theta-resident K1); row norms: tiles [b * chunk, (b + 1) * chunk)
+  long long t0 = (long long)blockIdx.x * pchunk;
+  long long t1 = t0 + pchunk;
+  if (t1 > part_rows) t1 = part_rows;
   for (int k0 = 0; k0 < s; k0 += 64) {
     const int k = k0 + lane;
     double acc = 0.0;
@@ -497,6 +500,9 @@ __global__ __launch_bounds__(256) void k_stats_stage1(const double* __restrict__
     __syncthreads();
   }
   if (!norms) return;                 // store-free projection: column sums only (block-uniform)
+  t0 = (long long)blockIdx.x * chunk;
+  t1 = t0 + chunk;
+  if (t1 > ntiles) t1 = ntiles;
   double ns = 0.0, nz = 0.0;
   long long r1 = t1 * BC_TILE;
   if (r1 > n_rows) r1 = n_rows;
@@ -569,8 +575,10 @@ int bc_phi_reduce_colsum(bc_phi* p) {
   bc_ctx* ctx = p->ctx;
   const int nb = p->stat_blocks;
   const long long chunk = (p->ntiles + nb - 1) / nb;
+  const long long prow = p->part_rows > 0 ? p->part_rows : p->ntiles, pchunk = (prow + nb - 1) / nb;
   hipLaunchKernelGGL(k_stats_stage1, dim3(nb), dim3(256), 0, ctx->stream, p->tile_part, (long long)p->ntiles, p->s,
-                     (const double*)nullptr, (long long)p->n_rows, chunk > 0 ? chunk : 1, p->part2, p->nstat);
+                     (const double*)nullptr, (long long)p->n_rows, chunk > 0 ? chunk : 1, p->part2, p->nstat, prow,
+                     pchunk > 0 ? pchunk : 1);
   BC_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_stats_stage2, dim3(1), dim3(1024), 0, ctx->stream, p->part2, (const double*)nullptr, nb, p->s, p->colsum,
                      p->stats);
@@ -582,8 +590,10 @@ int bc_phi_finish_stats(bc_phi* p) {
   bc_ctx* ctx = p->ctx;
   const int nb = p->stat_blocks;
   const long long chunk = (p->ntiles + nb - 1) / nb;
+  const long long prow = p->part_rows > 0 ? p->part_rows : p->ntiles, pchunk = (prow + nb - 1) / nb;
   hipLaunchKernelGGL(k_stats_stage1, dim3(nb), dim3(256), 0, ctx->stream, p->tile_part, (long long)p->ntiles, p->s,
-                     p->norms, (long long)p->n_rows, chunk > 0 ? chunk : 1, p->part2, p->nstat);
+                     p->norms, (long long)p->n_rows, chunk > 0 ? chunk : 1, p->part2, p->nstat, prow,
+                     pchunk > 0 ? pchunk : 1);
   BC_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_stats_stage2, dim3(1), dim3(1024), 0, ctx->stream, p->part2, p->nstat, nb, p->s, p->colsum,
                      p->stats);

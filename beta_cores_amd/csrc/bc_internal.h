@@ -91,6 +91,7 @@ struct bc_phi {
   double* norms = nullptr;       // [ntiles*128]
   double* colsum = nullptr;      // [s]   (valid when stats_valid)
   double* tile_part = nullptr;   // [ntiles][s] per-tile column partial sums (scratch)
+  int64_t part_rows = 0;         // rows of tile_part the last producer filled: ntiles, or one per wave (k_project_r)
   double* stats = nullptr;       // device: {norm_sum, zero_rows}
   double* part2 = nullptr;       // [stat_blocks][s] second-level column partials
   double* nstat = nullptr;       // [stat_blocks][2]

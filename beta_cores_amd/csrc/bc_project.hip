@@ -52,6 +52,7 @@ struct ProjArgs {
   long long n_rows;
   int dz, d, dk, s, model;
   int s_total, s_off;     // RAW passes (S > 256): this launch fills samples [s_off, s_off + s) of s_total, un-centred
+  long long ngroups;      // k_project_r: 32-row groups of this launch
   double c[8];            // model constants, see model_constants()
 #ifdef BC_K1_STAMPS       // diagnostic build: s_memtime of wave 0 at phase boundaries, 32 slots per tile
   unsigned long long* stamps;
@@ -185,6 +186,222 @@ __device__ __forceinline__ double bc_const_row_value(double devval, double p, do
   // the restated value is the same number as the device's own up to the last bits; anything else means the row is
   // constant for another reason than equal arguments (it then keeps the device's value)
   return (fabs(v - devval) <= 1e-13 * fabs(devval)) ? v : devval;
+}
+
+// Row statistics of one wave's accumulators, shared by the staged kernel (k_project) and the Theta-resident one
+// (k_project_r): on entry acc / tv hold the contraction values p of the lane's JT data rows (row0 + jt; samples
+// 16*st + g + 4*reg, tail sample 16*NT + g); on exit the centred model values.  Writes the row norms (STORE).
+// full_tile: every row of the tile is a real one (no masking).
+template <int MODEL, int NT, int JT, int TL, bool STORE>
+__device__ __forceinline__ void k1_row_stats(double4_t (&acc)[JT][NT], double (&tv)[JT], const double (&ra_pf)[JT], const ProjArgs& a,
+                                             const int S, const int lane, const int g, const double* tabl, const long long row0,
+                                             const bool full_tile) {
+  const int s_tail = NT * 16 + g;
+  if (TL > 0) {
+    // 96 < S <= 100 (every BASELINE config): all samples of the NT tiles are real ones and every lane holds some, so
+    // the `s < S` predicates vanish.  Rows past the end of the shard (last tile only) read as zeros, give finite
+    // model values, and are zeroed after the fact under a block-uniform branch instead of a select per element.
+    // "All S values of the row are equal" is not tracked per element either: such a row shows up afterwards as a
+    // centred row with a vanishing norm and is then examined exactly (below).
+    #pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      const double ra = ra_pf[jt];
+      const double p00 = acc[jt][0][0];          // the contraction value of the lane's first sample (constant rows, below)
+      double sum = 0.;
+#pragma unroll
+      for (int st = 0; st < NT; ++st) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const double v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[16 * st + g + 4 * reg] : 0., a.c, tabl);
+          acc[jt][st][reg] = v;
+          sum += v;
+          // Pin every BC_K1_GROUP elements: left to itself the compiler splits the table-driven bodies in two stages -- index
+          // and LDS read of all 25 elements of the row first, polynomials afterwards -- keeps every intermediate alive in
+          // between and spills ~900 VGPRs (the beta-logistic instantiation).  The empty asm consumes the finished values
+          // (ordering the arithmetic) and its memory clobber keeps the next group's table reads behind it.
+          if (bc_model_uses_tables<MODEL>() && ((4 * st + reg + 1) % BC_K1_GROUP) == 0) asm volatile("" : "+v"(acc[jt][st][reg]), "+v"(sum) :: "memory");
+        }
+      }
+      {
+        const double v = (s_tail < S) ? bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c, tabl) : 0.;
+        tv[jt] = v;
+        sum += v;
+      }
+      sum += __shfl_xor(sum, 16, BC_WAVE);
+      sum += __shfl_xor(sum, 32, BC_WAVE);
+      double mean = sum / (double)S;                 // lls.mean(axis=1), tree order
+      double sq = 0.;
+#pragma unroll
+      for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const double v = acc[jt][st][reg] - mean;
+          acc[jt][st][reg] = v;
+          sq = fma(v, v, sq);
+        }
+      {
+        const double v = (s_tail < S) ? tv[jt] - mean : 0.;
+        tv[jt] = v;
+        sq = fma(v, v, sq);
+      }
+      sq += __shfl_xor(sq, 16, BC_WAVE);
+      sq += __shfl_xor(sq, 32, BC_WAVE);
+      // A row whose S values are all the same number c (a data row with all-zero features): the reference subtracts
+      // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny
+      // constant residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The
+      // tree-order sum above rounds differently and would flip that zero / non-zero status, so such rows are
+      // re-centred with NumPy's order.  Every constant row lands here: its centred values are a few ulp of c, i.e.
+      // sq <= S*(8 eps c)^2, a thousand times inside the bound below (and NaN rows never do: they stay NaN as in the
+      // reference).  Inside the bound each v was within 1e-11 of the mean, so v - mean was exact (Sterbenz) and
+      // mean + (v - mean) gives v back exactly: "all v equal" is decided, exactly, on the centred values.
+      const double tiny = 1e-12 * mean;
+      const bool suspect = sq <= (double)S * (tiny * tiny);
+      if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) {
+        double d0 = acc[jt][0][0];
+        asm volatile("" : "+v"(d0));                 // keeps the 25 compares below out of the straight-line code
+        bool same = suspect;
+#pragma unroll
+        for (int st = 0; st < NT; ++st)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) same &= (acc[jt][st][reg] == d0);
+        if (s_tail < S) same &= (tv[jt] == d0);
+        int ok = same ? 1 : 0;
+        ok &= (d0 == __shfl_xor(d0, 16, BC_WAVE)) ? 1 : 0;
+        ok &= __shfl_xor(ok, 16, BC_WAVE);
+        ok &= (d0 == __shfl_xor(d0, 32, BC_WAVE)) ? 1 : 0;
+        ok &= __shfl_xor(ok, 32, BC_WAVE);
+        if (ok) {                                    // the four lanes of a constant row take this together
+          const double cval = bc_const_row_value<MODEL>(mean + d0, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
+          mean = bc_np_sum_const_256(cval, S) / (double)S;
+          const double v = cval - mean;
+          sq = 0.;
+#pragma unroll
+          for (int st = 0; st < NT; ++st)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              acc[jt][st][reg] = v;
+              sq = fma(v, v, sq);
+            }
+          const double vt = (s_tail < S) ? v : 0.;
+          tv[jt] = vt;
+          sq = fma(vt, vt, sq);
+        }
+        // the four lanes of a row agree on `ok`: a recomputed row adds up its four new partial sums, every other
+        // row keeps the total it had
+        double sq2 = ok ? sq : 0.;
+        sq2 += __shfl_xor(sq2, 16, BC_WAVE);
+        sq2 += __shfl_xor(sq2, 32, BC_WAVE);
+        if (ok) sq = sq2;
+      }
+      if (!full_tile && !(row0 + jt < a.n_rows)) {
+#pragma unroll
+        for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
+        tv[jt] = 0.;
+        sq = 0.;
+      }
+      if (STORE && g == 0) a.norms[row0 + jt] = sqrt(sq);
+    }
+  } else {
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+    const long long gr = row0 + jt;
+    const bool live = gr < a.n_rows;
+    const double ra = ra_pf[jt];
+    const double p00 = acc[jt][0][0];            // the contraction value of the lane's first sample (constant rows, below)
+    double sum = 0., vmin = INFINITY, vmax = -INFINITY;
+    // TL > 0 kernels (96 < S <= 100): every sample of the NT tiles is a real one and every lane holds some, so the
+    // `s < S` predicates vanish and "all S values equal" is tracked with compares against the lane's first value
+    // (fmin / fmax cost three instructions each with their canonicalisation; a NaN makes the row non-constant,
+    // as in the reference, where a NaN row stays NaN).
+    double vref = 0.;
+    bool differs = false;
+#pragma unroll
+    for (int st = 0; st < NT; ++st) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int s = 16 * st + g + 4 * reg;
+        double v = 0.;
+        if (TL > 0) {
+          if (live) v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c, tabl);
+          if (st == 0 && reg == 0) vref = v;
+          differs |= (v != vref);
+        } else if (s < S && live) {
+          v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c, tabl);
+          vmin = fmin(vmin, v);
+          vmax = fmax(vmax, v);
+        }
+        acc[jt][st][reg] = v;
+        sum += v;
+      }
+      if (bc_model_uses_tables<MODEL>()) asm volatile("" : "+v"(sum) :: "memory");     // see the S = 100 path above
+    }
+    if (TL > 0) {
+      double v = 0.;
+      if (s_tail < S && live) {
+        v = bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c, tabl);
+        differs |= (v != vref);
+      }
+      tv[jt] = v;
+      sum += v;
+    }
+    sum += __shfl_xor(sum, 16, BC_WAVE);
+    sum += __shfl_xor(sum, 32, BC_WAVE);
+    bool constant_row;
+    double cval;
+    if (TL > 0) {
+      int df = differs ? 1 : 0;
+      df |= (vref != __shfl_xor(vref, 16, BC_WAVE)) ? 1 : 0;
+      df |= __shfl_xor(df, 16, BC_WAVE);
+      df |= (vref != __shfl_xor(vref, 32, BC_WAVE)) ? 1 : 0;
+      df |= __shfl_xor(df, 32, BC_WAVE);
+      constant_row = df == 0;
+      cval = vref;
+    } else {
+      vmin = fmin(vmin, __shfl_xor(vmin, 16, BC_WAVE));
+      vmin = fmin(vmin, __shfl_xor(vmin, 32, BC_WAVE));
+      vmax = fmax(vmax, __shfl_xor(vmax, 16, BC_WAVE));
+      vmax = fmax(vmax, __shfl_xor(vmax, 32, BC_WAVE));
+      constant_row = vmin == vmax;
+      cval = vmax;
+    }
+    // a row whose S values are all the same number c (a data row with all-zero features): the reference subtracts
+    // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny constant
+    // residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The tree-order sum
+    // above would round differently and flip that zero / non-zero status, so such rows use NumPy's order.
+    if (bc_model_has_np_exp<MODEL>() && __builtin_amdgcn_ballot_w64(constant_row && live) != 0ull) {
+      const double cnp = bc_const_row_value<MODEL>(cval, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
+      if (constant_row && live) {                // the reference's bits for the constant: every element of the row IS it
+        cval = cnp;
+#pragma unroll
+        for (int st = 0; st < NT; ++st)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[jt][st][reg] = cnp;
+        if (TL > 0) tv[jt] = cnp;
+      }
+    }
+    const double mean = (constant_row ? bc_np_sum_const_256(cval, S) : sum) / (double)S;   // lls.mean(axis=1)
+    double sq = 0.;
+#pragma unroll
+    for (int st = 0; st < NT; ++st) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int s = 16 * st + g + 4 * reg;
+        double v = acc[jt][st][reg];
+        v = ((TL > 0 || s < S) && live) ? v - mean : 0.;
+        acc[jt][st][reg] = v;
+        sq = fma(v, v, sq);
+      }
+    }
+    if (TL > 0) {
+      const double v = (s_tail < S && live) ? tv[jt] - mean : 0.;
+      tv[jt] = v;
+      sq = fma(v, v, sq);
+    }
+    sq += __shfl_xor(sq, 16, BC_WAVE);
+    sq += __shfl_xor(sq, 32, BC_WAVE);
+    if (STORE && g == 0) a.norms[row0 + jt] = sqrt(sq);
+  }
+  }
 }
 
 // NT = number of 16-sample accumulator tiles, KC = D-chunk staged per LDS pass,
@@ -338,7 +555,6 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     __syncthreads();
     KSTAMP(5 + 5 * c);
   }
-  const int s_tail = NT * 16 + g;
 
   // ---- epilogue: lane holds, for data rows (row_base + jt), samples s = 16*st + g + 4*reg
   if (RAW) {
@@ -365,212 +581,7 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   // column partials reuse the staging LDS (all of it: Zl and Tl are dead after the loop)
   constexpr bool LDSCP = (JT == 2) && (NTHR / 64) * NR * 17 <= 128 * LDZ + NR * LDT;
   double* colpart = LDSCP ? lds : Tl;   // LDSCP: [waves][NR][17], else [waves][NR]
-  if (TL > 0) {
-    // 96 < S <= 100 (every BASELINE config): all samples of the NT tiles are real ones and every lane holds some, so
-    // the `s < S` predicates vanish.  Rows past the end of the shard (last tile only) read as zeros, give finite
-    // model values, and are zeroed after the fact under a block-uniform branch instead of a select per element.
-    // "All S values of the row are equal" is not tracked per element either: such a row shows up afterwards as a
-    // centred row with a vanishing norm and is then examined exactly (below).
-    const bool full_tile = rows_here == BC_TILE;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-      const double ra = ra_pf[jt];
-      const double p00 = acc[jt][0][0];          // the contraction value of the lane's first sample (constant rows, below)
-      double sum = 0.;
-#pragma unroll
-      for (int st = 0; st < NT; ++st) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const double v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[16 * st + g + 4 * reg] : 0., a.c, tabl);
-          acc[jt][st][reg] = v;
-          sum += v;
-          // Pin every BC_K1_GROUP elements: left to itself the compiler splits the table-driven bodies in two stages -- index
-          // and LDS read of all 25 elements of the row first, polynomials afterwards -- keeps every intermediate alive in
-          // between and spills ~900 VGPRs (the beta-logistic instantiation).  The empty asm consumes the finished values
-          // (ordering the arithmetic) and its memory clobber keeps the next group's table reads behind it.
-          if (bc_model_uses_tables<MODEL>() && ((4 * st + reg + 1) % BC_K1_GROUP) == 0) asm volatile("" : "+v"(acc[jt][st][reg]), "+v"(sum) :: "memory");
-        }
-      }
-      {
-        const double v = (s_tail < S) ? bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c, tabl) : 0.;
-        tv[jt] = v;
-        sum += v;
-      }
-      sum += __shfl_xor(sum, 16, BC_WAVE);
-      sum += __shfl_xor(sum, 32, BC_WAVE);
-      double mean = sum / (double)S;                 // lls.mean(axis=1), tree order
-      double sq = 0.;
-#pragma unroll
-      for (int st = 0; st < NT; ++st)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const double v = acc[jt][st][reg] - mean;
-          acc[jt][st][reg] = v;
-          sq = fma(v, v, sq);
-        }
-      {
-        const double v = (s_tail < S) ? tv[jt] - mean : 0.;
-        tv[jt] = v;
-        sq = fma(v, v, sq);
-      }
-      sq += __shfl_xor(sq, 16, BC_WAVE);
-      sq += __shfl_xor(sq, 32, BC_WAVE);
-      // A row whose S values are all the same number c (a data row with all-zero features): the reference subtracts
-      // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny
-      // constant residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The
-      // tree-order sum above rounds differently and would flip that zero / non-zero status, so such rows are
-      // re-centred with NumPy's order.  Every constant row lands here: its centred values are a few ulp of c, i.e.
-      // sq <= S*(8 eps c)^2, a thousand times inside the bound below (and NaN rows never do: they stay NaN as in the
-      // reference).  Inside the bound each v was within 1e-11 of the mean, so v - mean was exact (Sterbenz) and
-      // mean + (v - mean) gives v back exactly: "all v equal" is decided, exactly, on the centred values.
-      const double tiny = 1e-12 * mean;
-      const bool suspect = sq <= (double)S * (tiny * tiny);
-      if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) {
-        double d0 = acc[jt][0][0];
-        asm volatile("" : "+v"(d0));                 // keeps the 25 compares below out of the straight-line code
-        bool same = suspect;
-#pragma unroll
-        for (int st = 0; st < NT; ++st)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) same &= (acc[jt][st][reg] == d0);
-        if (s_tail < S) same &= (tv[jt] == d0);
-        int ok = same ? 1 : 0;
-        ok &= (d0 == __shfl_xor(d0, 16, BC_WAVE)) ? 1 : 0;
-        ok &= __shfl_xor(ok, 16, BC_WAVE);
-        ok &= (d0 == __shfl_xor(d0, 32, BC_WAVE)) ? 1 : 0;
-        ok &= __shfl_xor(ok, 32, BC_WAVE);
-        if (ok) {                                    // the four lanes of a constant row take this together
-          const double cval = bc_const_row_value<MODEL>(mean + d0, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
-          mean = bc_np_sum_const_256(cval, S) / (double)S;
-          const double v = cval - mean;
-          sq = 0.;
-#pragma unroll
-          for (int st = 0; st < NT; ++st)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              acc[jt][st][reg] = v;
-              sq = fma(v, v, sq);
-            }
-          const double vt = (s_tail < S) ? v : 0.;
-          tv[jt] = vt;
-          sq = fma(vt, vt, sq);
-        }
-        // the four lanes of a row agree on `ok`: a recomputed row adds up its four new partial sums, every other
-        // row keeps the total it had
-        double sq2 = ok ? sq : 0.;
-        sq2 += __shfl_xor(sq2, 16, BC_WAVE);
-        sq2 += __shfl_xor(sq2, 32, BC_WAVE);
-        if (ok) sq = sq2;
-      }
-      if (!full_tile && !(r0 + row_base + jt < a.n_rows)) {
-#pragma unroll
-        for (int st = 0; st < NT; ++st) acc[jt][st] = (double4_t){0., 0., 0., 0.};
-        tv[jt] = 0.;
-        sq = 0.;
-      }
-      if (STORE && g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
-    }
-  } else {
-#pragma unroll
-  for (int jt = 0; jt < JT; ++jt) {
-    const long long gr = r0 + row_base + jt;
-    const bool live = gr < a.n_rows;
-    const double ra = ra_pf[jt];
-    const double p00 = acc[jt][0][0];            // the contraction value of the lane's first sample (constant rows, below)
-    double sum = 0., vmin = INFINITY, vmax = -INFINITY;
-    // TL > 0 kernels (96 < S <= 100): every sample of the NT tiles is a real one and every lane holds some, so the
-    // `s < S` predicates vanish and "all S values equal" is tracked with compares against the lane's first value
-    // (fmin / fmax cost three instructions each with their canonicalisation; a NaN makes the row non-constant,
-    // as in the reference, where a NaN row stays NaN).
-    double vref = 0.;
-    bool differs = false;
-#pragma unroll
-    for (int st = 0; st < NT; ++st) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int s = 16 * st + g + 4 * reg;
-        double v = 0.;
-        if (TL > 0) {
-          if (live) v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c, tabl);
-          if (st == 0 && reg == 0) vref = v;
-          differs |= (v != vref);
-        } else if (s < S && live) {
-          v = bc_model_value<MODEL>(acc[jt][st][reg], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s] : 0., a.c, tabl);
-          vmin = fmin(vmin, v);
-          vmax = fmax(vmax, v);
-        }
-        acc[jt][st][reg] = v;
-        sum += v;
-      }
-      if (bc_model_uses_tables<MODEL>()) asm volatile("" : "+v"(sum) :: "memory");     // see the S = 100 path above
-    }
-    if (TL > 0) {
-      double v = 0.;
-      if (s_tail < S && live) {
-        v = bc_model_value<MODEL>(tv[jt], ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[s_tail] : 0., a.c, tabl);
-        differs |= (v != vref);
-      }
-      tv[jt] = v;
-      sum += v;
-    }
-    sum += __shfl_xor(sum, 16, BC_WAVE);
-    sum += __shfl_xor(sum, 32, BC_WAVE);
-    bool constant_row;
-    double cval;
-    if (TL > 0) {
-      int df = differs ? 1 : 0;
-      df |= (vref != __shfl_xor(vref, 16, BC_WAVE)) ? 1 : 0;
-      df |= __shfl_xor(df, 16, BC_WAVE);
-      df |= (vref != __shfl_xor(vref, 32, BC_WAVE)) ? 1 : 0;
-      df |= __shfl_xor(df, 32, BC_WAVE);
-      constant_row = df == 0;
-      cval = vref;
-    } else {
-      vmin = fmin(vmin, __shfl_xor(vmin, 16, BC_WAVE));
-      vmin = fmin(vmin, __shfl_xor(vmin, 32, BC_WAVE));
-      vmax = fmax(vmax, __shfl_xor(vmax, 16, BC_WAVE));
-      vmax = fmax(vmax, __shfl_xor(vmax, 32, BC_WAVE));
-      constant_row = vmin == vmax;
-      cval = vmax;
-    }
-    // a row whose S values are all the same number c (a data row with all-zero features): the reference subtracts
-    // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny constant
-    // residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The tree-order sum
-    // above would round differently and flip that zero / non-zero status, so such rows use NumPy's order.
-    if (bc_model_has_np_exp<MODEL>() && __builtin_amdgcn_ballot_w64(constant_row && live) != 0ull) {
-      const double cnp = bc_const_row_value<MODEL>(cval, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
-      if (constant_row && live) {                // the reference's bits for the constant: every element of the row IS it
-        cval = cnp;
-#pragma unroll
-        for (int st = 0; st < NT; ++st)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) acc[jt][st][reg] = cnp;
-        if (TL > 0) tv[jt] = cnp;
-      }
-    }
-    const double mean = (constant_row ? bc_np_sum_const_256(cval, S) : sum) / (double)S;   // lls.mean(axis=1)
-    double sq = 0.;
-#pragma unroll
-    for (int st = 0; st < NT; ++st) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int s = 16 * st + g + 4 * reg;
-        double v = acc[jt][st][reg];
-        v = ((TL > 0 || s < S) && live) ? v - mean : 0.;
-        acc[jt][st][reg] = v;
-        sq = fma(v, v, sq);
-      }
-    }
-    if (TL > 0) {
-      const double v = (s_tail < S && live) ? tv[jt] - mean : 0.;
-      tv[jt] = v;
-      sq = fma(v, v, sq);
-    }
-    sq += __shfl_xor(sq, 16, BC_WAVE);
-    sq += __shfl_xor(sq, 32, BC_WAVE);
-    if (STORE && g == 0) a.norms[r0 + row_base + jt] = sqrt(sq);
-  }
-  }
+  k1_row_stats<MODEL, NT, JT, TL, STORE>(acc, tv, ra_pf, a, S, lane, g, tabl, r0 + row_base, rows_here == BC_TILE);
   KSTAMP(21);
   // store the tile (JT == 2: two adjacent rows per lane -> 16-byte stores, 256 B contiguous per 16 lanes) through a
   // buffer descriptor of exactly this tile's S*128 doubles: one per-lane byte offset for all stores, the sample's
@@ -628,6 +639,211 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
     a.tile_part[(size_t)tile * S + s] = t;
   }
   KSTAMP(24);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, Theta-RESIDENT formulation (large shards, D <= ~160 at S = 100).
+//
+// What the staged kernel above pays per 128-row tile besides its MFMAs: the whole of Theta (S x D, 102 KB at the
+// headline shape) is re-staged through registers into LDS for EVERY tile, the Z tile is staged the same way, and four
+// waves meet at two barriers per D-chunk (profiles/r02_notes.md: staging writes 3.4k, first-chunk wait up to 7.7k of a
+// tile's ~38k cycles).  Here:
+//   * one 512-thread block per CU keeps Theta in LDS for the whole launch (100 x 130 doubles = 104 KB at D = 128),
+//     permuted so that the A-operand reads stay conflict-free (below);
+//   * the B operand never touches LDS: lane (j, g) of a wave reads 32 contiguous bytes of ITS data row straight from
+//     global memory (two dwordx4 per 16 columns; the four lanes of a row cover one 128-byte line), one 16-column stage
+//     ahead of the MFMAs that consume it -- the k index of a 16x16x4 step is lane-group g, so "which column is k" is a free
+//     choice as long as Theta uses the same one: k-step (c, t) contracts columns {16c + 4g + t}, and Theta[., 16c + 4g + t]
+//     sits at LDS position 16c + 4t + g;
+//   * waves are independent: a wave owns 32-row groups (wave id + 8 * gridDim * i), no barrier after the set-up, the
+//     next group's first stage and y values are requested before the epilogue of the current one;
+//   * column partials (K2) are accumulated per WAVE over all its groups in LDS (one S-vector per wave, written once at
+//     the end: tile_part holds gridDim * 8 rows instead of one per tile); assignment of groups to waves is static, so the
+//     sums are run-to-run deterministic.
+// Same accumulator layout, row statistics (k1_row_stats), Phi layout and norms as the staged kernel.
+template <int MODEL, int NT, int TL, bool STORE>
+__global__ __launch_bounds__(512, 2) void k_project_r(ProjArgs a) {
+  constexpr int JT = 2;
+  constexpr int NR = NT * 16 + TL;
+  constexpr int TRS = 5 * 4 * 17;             // transposition scratch of one wave: 5 values x 4 lane groups x (16 + 1)
+  extern __shared__ double lds[];
+  const int S = a.s;
+  const int dk = a.dk;                        // multiple of 32: an even number of 16-column stages
+  const int ldt = dk + 2;
+  double* Tl = lds;                           // [NR][ldt], columns permuted inside every block of 16
+  double* csum = Tl + NR * ldt;               // [8][NR] per-wave column partials
+  double* trs = csum + 8 * NR;                // [8][TRS]
+  double* tabl = trs + 8 * TRS;               // lookup tables of the transcendental bodies (models that have one)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+
+  // ---- set-up: Theta -> LDS (wave w takes rows w, w + 8, ...), zero the accumulators, tables
+  for (int i = w; i < NR; i += 8)
+    for (int col = lane; col < dk; col += 64) Tl[i * ldt + (col & ~15) + 4 * (col & 3) + ((col >> 2) & 3)] = a.theta[(size_t)i * dk + col];
+  for (int i = tid; i < 8 * NR; i += 512) csum[i] = 0.;
+  if (bc_model_uses_tables<MODEL>())
+    for (int i = tid; i < BC_K1_TAB_DOUBLES; i += 512) tabl[i] = __builtin_bit_cast(double, g_k1_tab_bits[i]);
+  __syncthreads();
+
+  const double* trow = Tl + j * ldt + g;
+  const double* tquad = Tl + (NT * 16 + (j & 3)) * ldt + g;
+  double* mycs = csum + w * NR;
+  double* mytr = trs + w * TRS;
+  const long long wstride = (long long)gridDim.x * 8;
+  const int nstage = dk >> 4;
+  const bool colmask = (a.d & 31) != 0;       // columns in [d, dk) exist: their Z values are zeroed (Theta's are zero already)
+  const int voff0 = ((2 * j) * a.dz + 4 * g) * 8;
+
+  auto rsrc_of = [&](long long grp) __attribute__((always_inline)) {
+    const long long row0 = grp * 32;
+    long long rows = a.n_rows - row0;
+    rows = rows > 32 ? 32 : rows;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)row0 * a.dz), 0, (int)(rows * a.dz * 8), 0x00020000);
+  };
+  // one 16-column stage of the lane's two rows: b[jt][t] = Z[row0 + 2j + jt][16c + 4g + t]   (rows past N read as 0)
+  auto issue = [&](auto rs, int c, double (&b)[JT][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      const bc_d2v lo = __builtin_bit_cast(bc_d2v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff0 + jt * a.dz * 8, c * 128, BC_K1_Z_AUX));
+      const bc_d2v hi = __builtin_bit_cast(bc_d2v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff0 + jt * a.dz * 8 + 16, c * 128, BC_K1_Z_AUX));
+      b[jt][0] = lo[0]; b[jt][1] = lo[1]; b[jt][2] = hi[0]; b[jt][3] = hi[1];
+    }
+  };
+  auto load_ra = [&](long long grp, double (&ra)[JT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      const long long gr = grp * 32 + 2 * j + jt;
+      ra[jt] = 0.;
+      if (gr < a.n_rows) {
+        if (MODEL == BC_MODEL_LINREG_LL || MODEL == BC_MODEL_LINREG_BETA) ra[jt] = a.z[(size_t)gr * a.dz + a.d];
+        else if (MODEL >= BC_MODEL_GAUSS_LL) ra[jt] = a.rowaux[gr];
+      }
+    }
+  };
+
+  double4_t acc[JT][NT];
+  double tv[JT];
+  const double4_t zero4 = {0., 0., 0., 0.};
+  // the four k-steps of stage c; FIRST: the accumulators start from the instruction's inline-constant 0
+  auto kstage = [&](int c, double (&b)[JT][4], auto first) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first)::value;
+    if (colmask && 16 * c + 16 > a.d) {       // wave-uniform: only the last stages of a D that is not a multiple of 32
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[jt][t] = (16 * c + 4 * g + t < a.d) ? b[jt][t] : 0.;
+    }
+    const double* tr0 = trow + 16 * c;
+    const double* tq0 = tquad + 16 * c;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int st = 0; st < NT; ++st) {
+        const double at = tr0[st * 16 * ldt + 4 * t];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+          acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, b[jt][t], (FIRST && t == 0) ? zero4 : acc[jt][st], 0, 0, 0);
+      }
+      if (TL > 0) {
+        const double at = tq0[4 * t];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) tv[jt] = __builtin_amdgcn_mfma_f64_4x4x4f64(at, b[jt][t], (FIRST && t == 0) ? 0. : tv[jt], 0, 0, 0);
+      }
+    }
+  };
+
+#ifdef BC_K1_STAMPS
+  unsigned long long ph[4] = {0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime(), tstart = tprev;
+#define RSTAMP(i) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[i] += tn - tprev; tprev = tn; } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
+  long long grp = (long long)blockIdx.x * 8 + w;
+  double bA[JT][4], bB[JT][4], ra_next[JT] = {0., 0.};
+  if (grp < a.ngroups) {
+    issue(rsrc_of(grp), 0, bA);
+    load_ra(grp, ra_next);
+  }
+  while (grp < a.ngroups) {
+    const long long nxt = grp + wstride;
+    const bool has_next = nxt < a.ngroups;
+    const auto rs = rsrc_of(grp);
+    double ra_pf[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) ra_pf[jt] = ra_next[jt];
+    // ---- contraction: stage c + 1 is in flight while stage c is consumed; the last stage overlaps the NEXT group's first
+    issue(rs, 1, bB);
+    kstage(0, bA, std::true_type{});
+    for (int c = 1; c + 1 < nstage; c += 2) {
+      issue(rs, c + 1, bA);
+      kstage(c, bB, std::false_type{});
+      issue(rs, c + 2, bB);
+      kstage(c + 1, bA, std::false_type{});
+    }
+    if (has_next) {
+      issue(rsrc_of(nxt), 0, bA);
+      load_ra(nxt, ra_next);
+    }
+    kstage(nstage - 1, bB, std::false_type{});
+    RSTAMP(0);
+
+    // ---- epilogue: model values, centring, norms (shared with the staged kernel)
+    const long long row0 = grp * 32 + 2 * j;
+    k1_row_stats<MODEL, NT, JT, TL, STORE>(acc, tv, ra_pf, a, S, lane, g, tabl, row0, grp * 32 + 32 <= a.n_rows);
+    RSTAMP(1);
+    const long long tile = grp >> 2;
+    const int row_base = 32 * (int)(grp & 3) + 2 * j;
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.tiles + (size_t)tile * S * BC_TILE), 0, S * BC_TILE * 8, 0x00020000);
+    const int woff = (g * BC_TILE + row_base) * 8;
+    // stores + column partials.  The 25 pair sums of a lane go through the wave's transposition scratch five at a time:
+    // [value][g][16 row pairs] -> lanes 0..19 add up one (value, g) each in row order and add the total to the wave's
+    // running column sum.  LDS operations of one wave execute in issue order: no barrier, only the compiler is held.
+    auto flush = [&](int v0idx, int nvals) __attribute__((always_inline)) {
+      asm volatile("" ::: "memory");
+      if (lane < 4 * nvals) {
+        const double* src = mytr + lane * 17;
+        double t = 0.;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) t += src[jj];
+        const int val = v0idx + (lane >> 2), gg = lane & 3;          // value index 0..24 -> sample
+        const int smp = (val < NT * 4) ? 16 * (val >> 2) + 4 * (val & 3) + gg : NT * 16 + gg;
+        if (smp < S) mycs[smp] += t;
+      }
+      asm volatile("" ::: "memory");
+    };
+    int nq = 0;                                                        // values parked since the last flush
+    int vbase = 0;
+    auto put = [&](int vidx, int s0, double v0, double v1) __attribute__((always_inline)) {
+      if (STORE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bc_u4v, (bc_d2v){v0, v1}), wrsrc, woff, s0 * BC_TILE * 8, BC_K1_Z_AUX);
+      mytr[((vidx - vbase) * 4 + g) * 17 + j] = v0 + v1;
+    };
+#pragma unroll
+    for (int st = 0; st < NT; ++st)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int vidx = 4 * st + reg;
+        put(vidx, 16 * st + 4 * reg, acc[0][st][reg], acc[1][st][reg]);
+        if (++nq == 5) { flush(vbase, 5); vbase += 5; nq = 0; }
+      }
+    if (TL > 0) {
+      put(4 * NT, NT * 16, tv[0], tv[1]);
+      ++nq;
+    }
+    if (nq > 0) flush(vbase, nq);
+    RSTAMP(2);
+    grp = nxt;
+  }
+#ifdef BC_K1_STAMPS
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + w) * 8;
+    o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = __builtin_amdgcn_s_memtime() - tstart; o[4] = tstart;
+  }
+#endif
+  // ---- the wave's column sums: row (blockIdx.x * 8 + w) of tile_part
+  asm volatile("" ::: "memory");
+  double* outp = a.tile_part + ((size_t)blockIdx.x * 8 + w) * S;
+  for (int s = lane; s < S; s += 64) outp[s] = mycs[s];
 }
 
 // S > 256, second stage: centre the rows of one tile (subtract the mean over all s_total samples; constant
@@ -821,6 +1037,48 @@ static int launch_project_model(bc_ctx* ctx, const ProjArgs& a, long long ntiles
   }
 }
 
+// ---- Theta-resident kernel: one 512-thread block per CU, LDS = Theta + per-wave column sums + transposition scratch (+ tables)
+static size_t project_r_lds_bytes(int nr, int dk, bool tables) {
+  return ((size_t)nr * (dk + 2) + 8 * (size_t)nr + 8 * (5 * 4 * 17) + (tables ? BC_K1_TAB_DOUBLES : 0)) * sizeof(double);
+}
+
+template <int MODEL, int NT, int TL, bool STORE>
+static int launch_project_r(bc_ctx* ctx, const ProjArgs& a, int grid) {
+  const size_t lds = project_r_lds_bytes(NT * 16 + TL, a.dk, bc_model_uses_tables<MODEL>());
+  static unsigned attr_done = 0;
+  const unsigned bit = 1u << (ctx->device & 31);
+  if (!(attr_done & bit)) {
+    BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_r<MODEL, NT, TL, STORE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+    attr_done |= bit;
+  }
+  hipLaunchKernelGGL((k_project_r<MODEL, NT, TL, STORE>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, a);
+  BC_HIP(hipGetLastError());
+  return BC_OK;
+}
+
+template <int MODEL, bool STORE>
+static int launch_project_r_nt(bc_ctx* ctx, const ProjArgs& a, int grid, int ntsel) {
+  switch (ntsel) {
+    case 4: return launch_project_r<MODEL, 4, 0, STORE>(ctx, a, grid);
+    case 6: return launch_project_r<MODEL, 6, 4, STORE>(ctx, a, grid);
+    default: return launch_project_r<MODEL, 7, 0, STORE>(ctx, a, grid);
+  }
+}
+
+template <bool STORE>
+static int launch_project_r_model(bc_ctx* ctx, const ProjArgs& a, int grid, int model, int ntsel) {
+  switch (model) {
+    case BC_MODEL_LINREG_LL: return launch_project_r_nt<BC_MODEL_LINREG_LL, STORE>(ctx, a, grid, ntsel);
+    case BC_MODEL_LINREG_BETA: return launch_project_r_nt<BC_MODEL_LINREG_BETA, STORE>(ctx, a, grid, ntsel);
+    case BC_MODEL_LOGISTIC_LL: return launch_project_r_nt<BC_MODEL_LOGISTIC_LL, STORE>(ctx, a, grid, ntsel);
+    case BC_MODEL_LOGISTIC_BETA: return launch_project_r_nt<BC_MODEL_LOGISTIC_BETA, STORE>(ctx, a, grid, ntsel);
+    case BC_MODEL_GAUSS_LL: return launch_project_r_nt<BC_MODEL_GAUSS_LL, STORE>(ctx, a, grid, ntsel);
+    case BC_MODEL_GAUSS_BETA: return launch_project_r_nt<BC_MODEL_GAUSS_BETA, STORE>(ctx, a, grid, ntsel);
+    default: return launch_project_r_nt<BC_MODEL_GAUSS_BETA_GRAD, STORE>(ctx, a, grid, ntsel);
+  }
+}
+
 static int launch_project_raw(bc_ctx* ctx, const ProjArgs& a, long long ntiles, int model) {
   switch (model) {
     case BC_MODEL_LINREG_LL: return launch_project<BC_MODEL_LINREG_LL, 16, 16, 1, true>(ctx, a, ntiles);
@@ -925,6 +1183,22 @@ static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, co
   return BC_OK;
 }
 
+// The resident kernel serves large shards whose Theta fits one CU's LDS next to the per-wave scratch: at least 8 tiles
+// per wave slot of the grid (tile_part then has room for the per-wave partial rows, and the grid is full), S <= 112.
+// BC_K1_STAGED=1 forces the staged kernel (A/B measurements).
+static int project_r_grid(const bc_ctx* ctx, const ProjPlan& pl, const bc_phi* phi, int mode) {
+  const char* env = getenv("BC_K1_STAGED");          // read per call: tests toggle it inside one process
+  if ((env && atoi(env) > 0) || mode == PROJ_RAW) return 0;
+  if (pl.ntsel != 4 && pl.ntsel != 6 && pl.ntsel != 7) return 0;
+  if (pl.model == BC_MODEL_LOGISTIC_BETA && !(env && atoi(env) < 0)) return 0;      // measured slower there (0.80 vs 0.74 ms at N = 1M, D = 128): four
+                                                                                       // transcendental bodies per element; BC_K1_STAGED=-1 forces the resident kernel
+  const int nr = pl.ntsel * 16 + (pl.ntsel == 6 ? 4 : 0);
+  if (project_r_lds_bytes(nr, pl.a.dk, true) > (size_t)ctx->max_lds) return 0;
+  const long long grid = ctx->n_cu;
+  if (phi->ntiles < grid * 8) return 0;
+  return (int)grid;
+}
+
 // One launch of a staged projection over `data`'s rows.  mode PROJ_FULL: the whole of Phi (s == s_total <= 256),
 // centred, with norms and column partials.  PROJ_RAW: samples [s_off, s_off + s) of s_total, un-centred.
 // PROJ_COLSUM: `phi` is a stats-only Phi: column partials only.  rowaux: the scratch that receives x^T Siginv x.
@@ -958,7 +1232,14 @@ static int plan_launch(bc_ctx* ctx, const ProjPlan& pl, const bc_data* data, bc_
   }
   int rc = bc_timer_begin(ctx, 1);
   if (rc) return rc;
-  if (mode == PROJ_RAW) rc = launch_project_raw(ctx, a, phi->ntiles, pl.model);
+  const int rgrid = project_r_grid(ctx, pl, phi, mode);
+  phi->part_rows = phi->ntiles;                 // rows of tile_part this launch fills (one per tile, or one per wave)
+  if (rgrid > 0) {
+    a.ngroups = (data->n_rows + 31) / 32;
+    phi->part_rows = (int64_t)rgrid * 8;
+    rc = mode == PROJ_COLSUM ? launch_project_r_model<false>(ctx, a, rgrid, pl.model, pl.ntsel)
+                             : launch_project_r_model<true>(ctx, a, rgrid, pl.model, pl.ntsel);
+  } else if (mode == PROJ_RAW) rc = launch_project_raw(ctx, a, phi->ntiles, pl.model);
   else if (mode == PROJ_COLSUM) rc = launch_project_model<false>(ctx, a, phi->ntiles, pl.model, pl.ntsel);
   else rc = launch_project_model<true>(ctx, a, phi->ntiles, pl.model, pl.ntsel);
   if (!rc) rc = bc_timer_end(ctx, 1);

@@ -515,3 +515,62 @@ def test_logistic_models_special_values(bc):
         big = ok[:, None] & (np.abs(raw) > 1e-3)
         rel = np.abs((got + raw.mean(axis=1)[:, None]) - raw)[big] / np.abs(raw)[big]
         assert rel.max() < 1e-12, rel.max()
+
+
+# ------------------------------------------------------------------ Theta-resident K1 (round 3)
+@pytest.mark.parametrize('n,d,s', [(300_000, 64, 100), (262_144 + 77, 37, 100), (270_000, 128, 64), (300_001, 20, 112),
+                                   (280_000, 13, 16), (263_000, 160, 97)])
+def test_theta_resident_kernel_matches_staged_and_oracle(bc, n, d, s):
+    """Large shards (>= 2048 tiles) run k_project_r: Theta resident in LDS, B operands read straight from global memory,
+    waves independent, per-wave column partials.  Against the staged kernel (BC_K1_STAGED=1, same process) on the same
+    inputs -- values / norms / column sums agree to rounding (the two contract the D axis in a different order) -- and
+    against the oracle on scattered rows; ragged N (dead rows in the last group), D not a multiple of 16 or 32 (masked
+    columns), constant (zero-feature) rows, every model."""
+    import os
+    rng = np.random.RandomState(n % 1000 + d + s)
+    pick = np.unique(np.concatenate(([0, 1, 31, 32, 127, 128, n - 33, n - 32, n - 1], rng.choice(n, 300, replace=False))))
+    zero_rows = pick[5:8]
+    Sig = np.diag(rng.uniform(0.5, 2.0, d))
+    cases = [('linreg', bc.likelihoods.LinearRegression(1.3), d + 1, (None, 0.3),
+              lambda Z, th, b: M.linreg_loglik(Z, th, 1.3) if b is None else M.linreg_beta_lik(Z, th, b, 1.3)),
+             ('logistic', bc.likelihoods.LogisticRegression(), d, (None, 0.2),
+              lambda Z, th, b: M.logistic_loglik(Z, th) if b is None else M.logistic_beta_lik(Z, th, b)),
+             ('gauss', bc.likelihoods.GaussianLocation(np.linalg.inv(Sig), np.linalg.slogdet(Sig)[1]), d, (None, 0.5),
+              lambda Z, th, b: M.gauss_loglik(Z, th, np.linalg.inv(Sig), np.linalg.slogdet(Sig)[1]) if b is None
+              else M.gauss_beta_lik(Z, th, b, np.linalg.inv(Sig), np.linalg.slogdet(Sig)[1]))]
+    for name, model, dz, betas, ref_fn in cases:
+        Z = rng.randn(n, dz)
+        Z[zero_rows, :d] = 0.
+        th = rng.randn(s, d) * (0.6 / np.sqrt(d))
+        prj = bc.DeviceBetaProjector(fixed(th), s, model)
+        dd = bc.DeviceData(Z)
+        for beta in betas:
+            run = lambda: prj.project(dd) if beta is None else prj.project_f(dd, beta)
+            os.environ.pop('BC_K1_STAGED', None)
+            res = run()
+            rows_r, norms_r, cs_r = res.rows(pick), res.norms(), res.colsum()
+            sf = prj.colsum(dd, beta=beta)
+            assert np.array_equal(sf, cs_r), name                       # store-free == materialised, bit for bit
+            del res
+            os.environ['BC_K1_STAGED'] = '1'
+            try:
+                old = run()
+                rows_s, norms_s, cs_s = old.rows(pick), old.norms(), old.colsum()
+                del old
+            finally:
+                os.environ.pop('BC_K1_STAGED', None)
+            raw = ref_fn(Z[pick], th, beta)
+            ref = raw - raw.mean(axis=1)[:, None]
+            scale = 1. + np.abs(raw).max()
+            assert np.abs(rows_r - ref).max() <= 1e-11 * scale, (name, beta)
+            assert np.abs(rows_r - rows_s).max() <= 1e-12 * scale, (name, beta)
+            np.testing.assert_allclose(norms_r, norms_s, rtol=1e-11, atol=1e-13 * scale)
+            np.testing.assert_allclose(cs_r, cs_s, rtol=1e-9, atol=1e-9 * scale)
+            np.testing.assert_allclose(norms_r[pick], np.sqrt((ref ** 2).sum(axis=1)), rtol=1e-9, atol=1e-12 * scale)
+            if name != 'gauss':
+                assert np.array_equal(rows_r[5:8] if False else res_const(rows_r, pick, zero_rows), res_const(rows_s, pick, zero_rows))
+
+
+def res_const(rows, pick, zero_rows):
+    """the rows of `rows` (gathered at indices `pick`) that belong to the constant (zero-feature) data rows"""
+    return rows[np.isin(pick, zero_rows)]

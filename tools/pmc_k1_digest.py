@@ -21,11 +21,11 @@ def main():
                     k = row.get('Kernel_Name', '')
                     if 'k_project' not in k:
                         continue
-                    m = re.search(r'k_project<([^>]*)>', k)
+                    m = re.search(r'(k_project(?:_r)?<[^>]*>)', k)
                     key = m.group(1) if m else k
                     acc[key][row['Counter_Name']].append((row.get('Dispatch_Id'), float(row['Counter_Value'])))
     names = sorted({c for k in acc for c in acc[k]})
-    print(','.join(['k_project<model,NT,KC,JT,RAW,TL,STORE>', 'launches'] + names))
+    print(','.join(['kernel: k_project<model,NT,KC,JT,RAW,TL,STORE> | k_project_r<model,NT,TL,STORE>', 'launches'] + names))
     for k in sorted(acc):
         n = 0
         vals = []
