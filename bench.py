@@ -437,6 +437,11 @@ def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args))
+    # ONE JSON line on stdout: libraries that print banners there (RCCL writes its version block at communicator creation)
+    # are pointed at stderr until the line is ready
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -579,6 +584,35 @@ def main():
             k3_bytes = 4.0 * n_local * S + 8.0 * n_local + 4.0 * n_local
     else:
         k3_bytes = 8.0 * n_local * S + 8.0 * n_local      # one streaming read of Phi + the norms
+    # ---------------- diagnostic pass (untimed): HIP events around every stage of every step -- sweep, rescoring / local
+    # winner, candidate all-gather, finish -- so that a multi-GPU run shows where its step time goes.  The event pairs cost
+    # stream time (~11 us each), which is why this is a pass of its own and not part of `value`.
+    diag_steps = 30
+    ctx.timing_classes(0x3f)
+    ctx.enable_timing(1)
+    ctx.kernel_time_reset()
+    t0 = time.perf_counter()
+    alg.snnls.build(diag_steps)
+    barrier()
+    t_diag = time.perf_counter() - t0
+    stage_ms = {}
+    for nm, cl in (('sweep', 0), ('rescoring_or_local_winner', 3), ('all_gather', 4), ('finish', 5)):
+        ms_, n_ = ctx.kernel_time(cl)
+        stage_ms[nm] = ms_ / n_ if n_ else None
+    ctx.enable_timing(0)
+    ctx.timing_classes(0x7)
+    rccl_ranks = None
+    if eng_.native_exchange:
+        import ctypes as _C
+        from beta_cores_amd import _native as _N
+        rr, ww = _C.c_int32(), _C.c_int32()
+        _N.call('bc_comm_info', comm.native_comm(ctx), _C.byref(rr), _C.byref(ww))
+        rccl_ranks = int(ww.value)
+    step_diag = {'stage_ms (HIP events, every step of a separate %d-step pass)' % diag_steps: stage_ms,
+                 'instrumented_ms_per_step': 1e3 * t_diag / diag_steps, 'rccl_ranks': rccl_ranks,
+                 'transport': exchange_kind,
+                 'note': 'single rank with the pre-filter: rescoring runs inside the finish launch; '
+                         'multi-rank: sweep -> rescoring -> ncclAllGather of one (S+4)-double record per rank -> replicated finish'}
     alg._pull()
     wts, pts, idcs = alg.get()
     err = alg.error()
@@ -629,6 +663,7 @@ def main():
             'posterior_gram': dict(k4_entry(n_local, D, max(k4_ms / max(k4_n, 1), 1e-9)), wall_ms=1e3 * t_post,
                                    note='K4 X^T W X on fp64 MFMA, all local rows, w = 1 (sampler set-up, cold first launch)'),
             'prefilter': dict(zip(('sweeps', 'candidates_rescored', 'fp64_fallbacks'), alg.snnls._eng.prefilter_stats())),
+            'step_stages': step_diag,
             'solver_init_ms': 1e3 * t_init, 'solver_init': init_parts, 'setup_s': t_setup,
             'coreset': {'size': int(len(idcs)), 'error': err, 'failed_steps': int(st_tr.sum())},
         }
@@ -700,9 +735,12 @@ def main():
             out['parity_failure'] = {'device_sample': dsel.tolist(), 'oracle_sample': rsel.tolist(),
                                      'device_full': f_tr[:len(rsel_full)].tolist(), 'oracle_full': rsel_full.tolist()}
         del phi_ref, ref
+    sys.stdout.flush()
+    os.dup2(_stdout_fd, 1)
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
+    os.dup2(2, 1)                         # teardown chatter goes to stderr again
     if world > 1 or force_xchg:
         dist.barrier()
         comm.close()                      # the library's own RCCL communicator, before torch's

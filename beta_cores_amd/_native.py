@@ -31,6 +31,7 @@ _SIGNATURES = {
     'bc_ctx_kernel_time': [vp, C.c_int, c_dp, c_i64p],
     'bc_ctx_kernel_time_reset': [vp],
     'bc_ctx_enable_timing': [vp, C.c_int],
+    'bc_ctx_timing_classes': [vp, C.c_uint32],
     'bc_ctx_phase_times': [vp, vp, C.c_int32, c_i64p, C.c_int],
     'bc_data_from_host': [vp, vp, C.c_int64, C.c_int32, vpp],
     'bc_data_from_device': [vp, vp, C.c_int64, C.c_int32, vpp],

@@ -116,8 +116,14 @@ extern "C" int bc_ctx_enable_timing(bc_ctx* ctx, int on) {
   return BC_OK;
 }
 
+extern "C" int bc_ctx_timing_classes(bc_ctx* ctx, uint32_t mask) {
+  if (!ctx) return BC_INVALID_ARGUMENT;
+  ctx->timing_mask = mask & 0x3f;
+  return BC_OK;
+}
+
 int bc_timer_begin(bc_ctx* ctx, int which) {
-  if (!ctx->timing) return BC_OK;
+  if (!ctx->timing || !((ctx->timing_mask >> which) & 1u)) return BC_OK;
   bc_timer& t = ctx->timers[which];
   t.armed = (t.seq++ % ctx->timing) == 0;
   if (!t.armed) return BC_OK;
@@ -155,7 +161,7 @@ static int timer_collect(bc_ctx* ctx, bc_timer& t) {
 }
 
 extern "C" int bc_ctx_kernel_time(bc_ctx* ctx, int which, double* total_ms, int64_t* launches) {
-  if (!ctx || which < 0 || which > 2) { bc_set_error("bc_ctx_kernel_time: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (!ctx || which < 0 || which > 5) { bc_set_error("bc_ctx_kernel_time: bad argument"); return BC_INVALID_ARGUMENT; }
   int rc = timer_collect(ctx, ctx->timers[which]);
   if (rc) return rc;
   if (total_ms) *total_ms = ctx->timers[which].acc_ms;

@@ -44,7 +44,9 @@ struct bc_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int timing = 0;                // 0 = off, n >= 1: every n-th launch of each kernel class is timed
-  bc_timer timers[3];
+  unsigned timing_mask = 0x7;    // which classes (bit = class): the step stages 3-5 only on request (bc_ctx_timing_classes)
+  bc_timer timers[6];            // 0 K3 sweep | 1 K1 projection | 2 K4 Gram + reduce | 3 rescoring / local winner |
+                                 // 4 candidate all-gather (RCCL) | 5 step finish
   int n_cu = 256;
   int max_lds = 64 * 1024;       // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
   double* pinned = nullptr;      // small pinned staging area (host)

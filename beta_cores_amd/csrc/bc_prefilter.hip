@@ -504,8 +504,10 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   RescoreArgs r;
   int rc = bc_pref_launch_sweep(p, mode, v_dev, v_norm_dev, post_div, skip_flag, rec_dev, &r);
   if (rc) return rc;
+  rc = bc_timer_begin(p->ctx, 3);
+  if (rc) return rc;
   if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
   else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
   BC_HIP(hipGetLastError());
-  return BC_OK;
+  return bc_timer_end(p->ctx, 3);
 }

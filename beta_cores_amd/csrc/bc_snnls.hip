@@ -1249,7 +1249,10 @@ extern "C" int bc_snnls_bind_comm(bc_snnls* h, bc_comm* c) {
 // the record all-gather between the local sweep and the replicated finish / pick (native exchange only)
 static int exchange(bc_snnls* h) {
   if (!h->comm) return BC_OK;
-  return bc_comm_all_gather_dev(h->comm, h->cand_send, h->cand_all_owned, (size_t)h->d.rec_len);
+  int rc = bc_timer_begin(h->ctx, 4);
+  if (!rc) rc = bc_comm_all_gather_dev(h->comm, h->cand_send, h->cand_all_owned, (size_t)h->d.rec_len);
+  if (!rc) rc = bc_timer_end(h->ctx, 4);
+  return rc;
 }
 
 static int mode_of(const bc_snnls* h) { return h->alg == BC_ALG_GIGA ? 0 : 1; }
@@ -1339,6 +1342,8 @@ extern "C" int bc_snnls_step_finish(bc_snnls* h) {
   h->rs_pending = false;
   h->exact_step = false;
   const long long nrec = fused ? d.rec_len : (d.fuse_winner ? 0 : (long long)d.world * d.rec_len);
+  int rct = bc_timer_begin(h->ctx, 5);
+  if (rct) return rct;
   if (fused || finish_pf_ok(h, nrec)) {
     const int hint = (int)h->nnz_upper;
     const size_t lds = ((size_t)5 * d.s + nrec + 2 * (size_t)(hint + 1)) * sizeof(double);
@@ -1365,7 +1370,7 @@ extern "C" int bc_snnls_step_finish(bc_snnls* h) {
     BC_HIP(hipGetLastError());
     h->nnz_upper += 1;
     h->iter_upper += 1;
-    return BC_OK;
+    return bc_timer_end(h->ctx, 5);
   }
   const int lds_vecs = d.s <= 1024 ? 1 : 0;
   const size_t lds = lds_vecs ? (size_t)5 * d.s * sizeof(double) : 0;
@@ -1376,7 +1381,7 @@ extern "C" int bc_snnls_step_finish(bc_snnls* h) {
   BC_HIP(hipGetLastError());
   h->nnz_upper += 1;
   h->iter_upper += 1;
-  return BC_OK;
+  return bc_timer_end(h->ctx, 5);
 }
 
 extern "C" int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* iterations_consumed, int* pending_exact) {

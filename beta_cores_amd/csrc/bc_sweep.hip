@@ -68,10 +68,12 @@ int bc_launch_sweep(bc_phi* p, int mode, const double* v_dev, double post_div, c
   rc = bc_timer_end(ctx, 0);
   if (rc) return rc;
   if (!rec_dev) return BC_OK;
+  rc = bc_timer_begin(ctx, 3);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_local_winner, dim3(1), dim3(256), 0, ctx->stream, p->blk_val, p->blk_idx, grid,
                      p->tiles, p->norms, p->s, (long long)p->row_offset, skip_flag, rec_dev);
   BC_HIP(hipGetLastError());
-  return BC_OK;
+  return bc_timer_end(ctx, 3);
 }
 
 extern "C" int bc_phi_argmax(bc_phi* p, int mode, const double* v, double post_div, int64_t* best, double* score) {

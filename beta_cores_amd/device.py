@@ -50,8 +50,14 @@ class Context:
         """on: False/0 = off, True/1 = time every launch of the dominant kernels, n > 1 = every n-th launch."""
         N.call('bc_ctx_enable_timing', self.h, int(on))
 
+    def timing_classes(self, mask):
+        """Which kernel classes enable_timing applies to (bit i = class i); default 0x7.  Classes 3-5 are the other stages of
+        a greedy step (rescoring / local winner, candidate all-gather, step finish): for diagnostic passes."""
+        N.call('bc_ctx_timing_classes', self.h, int(mask))
+
     def kernel_time(self, which):
-        """(total_ms, launches) of kernel class `which` (0 = K3 sweep, 1 = K1 projection, 2 = K4 gram)."""
+        """(total_ms, launches) of kernel class `which` (0 = K3 sweep, 1 = K1 projection, 2 = K4 gram + reduce, 3 = rescoring /
+        local winner, 4 = candidate all-gather, 5 = step finish)."""
         ms, n = C.c_double(), C.c_int64()
         N.call('bc_ctx_kernel_time', self.h, int(which), C.byref(ms), C.byref(n))
         return ms.value, n.value

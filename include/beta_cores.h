@@ -80,12 +80,17 @@ int bc_ctx_destroy(bc_ctx* ctx);
 int bc_ctx_sync(bc_ctx* ctx);
 /* time (ms) spent inside the dominant kernels since the last reset, measured
  * with HIP events on the launch stream; which: 0 = K3 score/argmax sweep,
- * 1 = K1 projection, 2 = K4 XtWX.  launches returns the number of TIMED launches.
+ * 1 = K1 projection, 2 = K4 XtWX (Gram kernel + its split-order reduction), and the other stages of a greedy step:
+ * 3 = rescoring / local winner, 4 = candidate all-gather (RCCL), 5 = step finish.  launches returns the number of
+ * TIMED launches.
  * bc_ctx_enable_timing(ctx, n): 0 = off (default), n >= 1 = time every n-th launch of each class
  * (an event pair costs ~11 us of stream time on MI355X, which matters next to a 50 us sweep). */
 int bc_ctx_kernel_time(bc_ctx* ctx, int which, double* total_ms, int64_t* launches);
 int bc_ctx_kernel_time_reset(bc_ctx* ctx);
 int bc_ctx_enable_timing(bc_ctx* ctx, int on);
+/* which classes bc_ctx_enable_timing applies to (bit i = class i of bc_ctx_kernel_time); default 0x7: the three dominant
+ * kernels.  The stage timers 3-5 cost an event pair each per timed step: switch them on for a diagnostic pass only. */
+int bc_ctx_timing_classes(bc_ctx* ctx, uint32_t mask);
 /* accumulated GPU time (HIP events, ms) of the BC_VI_PHASES = 5 phases of the bc_vi_gradient calls made while timing
  * was on: upload (Theta, coreset rows, w) | K1 of the coreset rows | store-free K1 over the data rows | column-sum
  * reduction (+ rank-order sum over ranks) | M x S algebra + download; *calls = number of timed calls; reset != 0 clears. */
