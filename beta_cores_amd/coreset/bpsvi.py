@@ -31,7 +31,7 @@ class BatchPSVICoreset(Coreset):
         self.n_subsample_opt = n_subsample_opt if n_subsample_opt is None else min(n, n_subsample_opt)   # bpsvi.py:11
         self._resident = None
         wants_pin = pin_data and self.n_subsample_opt is None and hasattr(ll_projector, 'pin')
-        if wants_pin and isinstance(data, np.ndarray) and data.ndim == 2 and n >= 4096:
+        if wants_pin and isinstance(data, np.ndarray) and data.base is None and data.ndim == 2 and n >= 4096:
             # every gradient re-projects ALL rows: keep them in HBM (read-only on the host while pinned)
             self._resident = ll_projector.pin(data)
             self._unpin = weakref.finalize(self, ll_projector.unpin, data)

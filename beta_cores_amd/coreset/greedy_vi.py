@@ -9,6 +9,7 @@ projection.  With a Device(Beta)Projector the N-row projection (K1), its column 
 touch the host; with a black-box projector the reference's NumPy expressions are used
 on whatever array the callable returns.
 """
+import os
 import weakref
 
 import numpy as np
@@ -38,15 +39,23 @@ class GreedyVICoreset(Coreset):
         self.groups = groups
         self.selected_groups = []
         self.fused_gradient = bool(fused_gradient)     # False: every gradient materialises Phi (the general path)
-        self.comm = comm if (comm is not None and comm.world > 1) else None
+        # BC_FORCE_EXCHANGE=1 keeps a 1-rank group on the collective paths (rehearsal of the RCCL code on one GPU)
+        self.comm = comm if (comm is not None and (comm.world > 1 or os.environ.get('BC_FORCE_EXCHANGE') == '1')) else None
         self._dev_data = data if isinstance(data, DeviceData) else None      # rows already resident in HBM
+        self._tmode, self._tpos = 'shard', None      # how the last tangent space is spread over ranks (see _tangent)
+        self._n_total = n
         if self.comm is not None:
-            if groups is not None or n_subsample_select is not None or n_subsample_opt is not None:
-                raise NotImplementedError('sharded rows support the full-data, ungrouped mode only')
+            # `data` is this rank's contiguous row shard; indices (idcs, groups, sub-samples) are GLOBAL row numbers
             off = self.comm.row_offset(n)
             self._local = (off, n)
-            self._dev_data = DeviceData(data, ctx=getattr(ll_projector, 'ctx', None), row_offset=off)
-        elif pin_data and hasattr(ll_projector, 'pin') and isinstance(data, np.ndarray) and data.ndim == 2 \
+            self._n_total = self.comm.total_rows(n)
+            self.n_subsample_select = None if n_subsample_select is None else min(self._n_total, n_subsample_select)
+            self.n_subsample_opt = None if n_subsample_opt is None else min(self._n_total, n_subsample_opt)
+            if not isinstance(data, DeviceData):
+                self._dev_data = DeviceData(data, ctx=getattr(ll_projector, 'ctx', None), row_offset=off)
+            if groups is not None:        # the members of every group that live on this rank, as local row numbers, in member order
+                self._local_groups = [np.asarray([i - off for i in g if off <= i < off + n], dtype=np.int64) for g in groups]
+        elif pin_data and hasattr(ll_projector, 'pin') and isinstance(data, np.ndarray) and data.base is None and data.ndim == 2 \
                 and data.shape[0] >= 4096 and (n_subsample_select is None or n_subsample_opt is None or groups is not None):
             # every full-data tangent space re-projects ALL rows: keep them in HBM instead of uploading per gradient
             # step.  While pinned, `data` is read-only on the host (an in-place edit raises instead of going unseen);
@@ -66,6 +75,7 @@ class GreedyVICoreset(Coreset):
         and, with `grad`, the row-centred beta-gradient of the coreset rows (projector.py:56-61) as a sixth item."""
         self.ll_projector.update(w, p)
         group_idcs = None
+        self._tmode, self._tpos = 'shard', None
         if n_subsample is None and self.groups is None:
             sub_idcs = None
             vecs = self._proj(self._dev_data if self._dev_data is not None else self.data, beta)
@@ -76,9 +86,11 @@ class GreedyVICoreset(Coreset):
             vecs = self._group_vecs(group_idcs, beta)
             sum_scaling = 1.
         elif n_subsample and (self.groups is None or not select):
-            sub_idcs = np.random.randint(self.data.shape[0], size=n_subsample)
-            vecs = self._proj(self.data[sub_idcs], beta)
-            sum_scaling = self.data.shape[0] / n_subsample
+            # (every rank draws the same indices: the ranks share the seed of the global NumPy stream, as they must for
+            # the sampler's draws already)
+            sub_idcs = np.random.randint(self._n_total, size=n_subsample)
+            vecs = self._proj(self.data[sub_idcs], beta) if self.comm is None else self._subsample_vecs(sub_idcs, beta)
+            sum_scaling = self._n_total / n_subsample
         else:
             group_idcs = np.random.randint(len(self.groups), size=n_subsample)
             sub_idcs = _flatten([self.groups[i] for i in group_idcs])
@@ -92,8 +104,8 @@ class GreedyVICoreset(Coreset):
             else:
                 corevecs = np.asarray(self._proj(p, beta))
         else:
-            corevecs = np.zeros((0, vecs.shape[1]))
-            betagrads = np.zeros((0, vecs.shape[1]))
+            corevecs = np.zeros((0, self.ll_projector.projection_dimension))
+            betagrads = np.zeros((0, self.ll_projector.projection_dimension))
         if grad:
             return self._on_device(vecs), sum_scaling, sub_idcs, group_idcs, corevecs, betagrads
         return self._on_device(vecs), sum_scaling, sub_idcs, group_idcs, corevecs
@@ -101,24 +113,44 @@ class GreedyVICoreset(Coreset):
     def _group_vecs(self, group_idcs, beta):
         """One vector per group: the sum of its rows' projections (bcores.py:46-50, 56-61).  A device projector
         projects all rows once (K1) and the groups are summed on the device (bc_phi_group_sum) -- the same rows,
-        the same order of additions; a black-box projector is called group by group like in the reference."""
+        the same order of additions; a black-box projector is called group by group like in the reference.
+        Row-sharded: every rank sums the members it owns (member order), the partial sums are added in rank order
+        (one G x S collective) and every rank continues with the same, complete group vectors."""
         from .projector import _DeviceProjectorBase
+        if self.comm is not None:
+            full = self._proj(self._dev_data, beta)
+            part = np.asarray(full.group_sum([self._local_groups[i] for i in group_idcs]))
+            self._tmode = 'replicated'
+            return self.comm.sum_in_rank_order(part)
         if isinstance(self.ll_projector, _DeviceProjectorBase):
             full = self._proj(self._dev_data if self._dev_data is not None else self.data, beta)
             if isinstance(full, DevicePhi):
                 return full.group_sum([self.groups[i] for i in group_idcs])
         return np.array([np.sum(np.asarray(self._proj(self.data[self.groups[i], :], beta)), axis=0) for i in group_idcs])
 
+    def _subsample_vecs(self, sub_idcs, beta):
+        """Row-sharded sub-sample (bcores.py:51-55): this rank projects the drawn rows it owns, in draw order; `_tpos`
+        keeps their positions in the draw (the reference's row numbers of `vecs`)."""
+        off, n = self._local
+        pos = np.flatnonzero((sub_idcs >= off) & (sub_idcs < off + n))
+        self._tmode, self._tpos = 'positions', pos
+        if pos.size == 0:
+            return None
+        return self._proj(self.data[sub_idcs[pos] - off], beta)
+
     def _on_device(self, vecs):
         """Black-box projectors hand back a host array; its N-row reductions still run on the GPU."""
-        if isinstance(vecs, DevicePhi):
+        if isinstance(vecs, DevicePhi) or vecs is None:
             return vecs
         return DevicePhi.from_host(np.ascontiguousarray(vecs, dtype=np.float64), ctx=getattr(self.ll_projector, 'ctx', None))
 
     def _colsum(self, vecs):
-        if self.comm is not None:
-            return self.comm.colsum(vecs)          # in-library all-gather + rank-order sum over RCCL (dist.py)
-        return vecs.sum(axis=0)
+        if self.comm is None or self._tmode == 'replicated':
+            return vecs.sum(axis=0)
+        if self._tmode == 'positions':          # a handful of rows per rank: host collective
+            S = self.ll_projector.projection_dimension
+            return self.comm.sum_in_rank_order(vecs.sum(axis=0) if vecs is not None else np.zeros(S))
+        return self.comm.colsum(vecs)              # in-library all-gather + rank-order sum over RCCL (dist.py)
 
     def _best_correlation(self, vecs, resid):
         """`np.argmax(corrs)`, `corrs.max()` for corrs = vecs.resid / ||vecs_i|| / S (bcores.py:78-81), one K3 sweep.
@@ -126,22 +158,31 @@ class GreedyVICoreset(Coreset):
         All-zero rows stay in the tangent space: the filter at bcores.py:67-68 / sparsevi.py:64-65 needs
         select=True with groups=None and the ungrouped _select passes neither (bcores.py:76).  Their correlation
         is 0/0 = NaN, so NumPy's argmax is the FIRST such row and the maximum is NaN -- every `>` against it is
-        False (golden F13).  The sweep masks zero-norm rows, so that case is decided here from the norms."""
-        S = vecs.shape[1]
-        n_zero = vecs.norm_stats()[0]
-        if self.comm is not None:
-            n_zero_all = int(self.comm.sum_in_rank_order(np.array([float(n_zero)]))[0])
+        False (golden F13).  The sweep masks zero-norm rows, so that case is decided here from the norms.
+        Row-sharded: ranks compare (score, row number of `vecs`) and the lowest row number wins ties, like argmax."""
+        S = self.ll_projector.projection_dimension if vecs is None else vecs.shape[1]
+        shared = self.comm is not None and self._tmode != 'replicated'
+        if self._tmode == 'positions':
+            rownum = (lambda k: int(self._tpos[k]))                     # local row -> position in the draw
         else:
-            n_zero_all = n_zero
+            rownum = (lambda k: int(k))                                 # argmax / row_offset already speak global rows
+        n_zero = vecs.norm_stats()[0] if vecs is not None else 0
+        n_zero_all = int(self.comm.sum_in_rank_order(np.array([float(n_zero)]))[0]) if shared else n_zero
         if n_zero_all > 0:
             first = np.inf
             if n_zero > 0:
-                first = float(vecs.row_offset + int(np.flatnonzero(vecs.norms() == 0.)[0]))
-            if self.comm is not None:
+                k = int(np.flatnonzero(vecs.norms() == 0.)[0])
+                first = float(rownum(k) if self._tmode == 'positions' else vecs.row_offset + k)
+            if shared:
                 first = float(self.comm.gather_host(np.array([first])).min())
             return int(first), np.nan
-        best, score = vecs.argmax(resid, mode=1, post_div=float(S))
-        if self.comm is not None:
+        if vecs is not None:
+            best, score = vecs.argmax(resid, mode=1, post_div=float(S))
+            if self._tmode == 'positions' and best >= 0:
+                best = rownum(best - vecs.row_offset)
+        else:
+            best, score = -1, -np.inf
+        if shared:
             cands = self.comm.gather_host(np.array([score, float(best)]))
             best, score = -1, -np.inf
             for sc, bi in cands:
@@ -151,11 +192,19 @@ class GreedyVICoreset(Coreset):
         return best, score
 
     def _row(self, f):
+        return self._rows([f])[0]
+
+    def _rows(self, idx):
+        """data[idx] for GLOBAL row numbers: every rank contributes the rows it owns, the rest comes from the others."""
+        idx = np.asarray(idx, dtype=np.int64)
         if self.comm is None:
-            return self.data[f]
+            return self.data[idx]
         off, n = self._local
-        row = np.asarray(self.data[f - off], dtype=np.float64) if off <= f < off + n else np.zeros(self.data.shape[1])
-        return self.comm.sum_in_rank_order(row)
+        out = np.zeros((idx.shape[0], self.data.shape[1]))
+        mine = (idx >= off) & (idx < off + n)
+        if mine.any():
+            out[mine] = np.asarray(self.data[idx[mine] - off], dtype=np.float64)
+        return self.comm.sum_in_rank_order(out)
 
     def _append(self, new_idcs, new_pts):
         k = len(new_idcs)
@@ -198,7 +247,7 @@ class GreedyVICoreset(Coreset):
             f = best if self.n_subsample_select is None else group_idcs[best]
             if not any(f == g for g in self.selected_groups):
                 self.selected_groups.append(f)
-                self._append(self.groups[f], self.data[self.groups[f], :])
+                self._append(self.groups[f], self._rows(self.groups[f]) if self.comm is not None else self.data[self.groups[f], :])
 
     # -- bcores.py:141-150
     def _fused_gradient(self, w, beta):

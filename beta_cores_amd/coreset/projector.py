@@ -149,40 +149,46 @@ class _PhiPool:
 # ---- host arrays pinned on the device.  While an ndarray is pinned its device copy is what gets projected, so an
 # in-place edit of the array would go unseen; the array is therefore made read-only for as long as any pin holds it
 # (NumPy then raises on assignment instead of the device silently serving stale rows).
-_pin_guard = {}      # id(ndarray) -> [count, original writeable flag, weakref]
+_pin_guard = {}      # id(ndarray) -> entry [count, original writeable flag, weakref]; an entry is only trusted while its
+                     # weakref still points at the array (ids are recycled once an array dies)
 
 
 def _guard_acquire(arr):
+    """Make `arr` read-only while pinned; returns the guard entry to hand to _guard_release."""
     key = id(arr)
     ent = _pin_guard.get(key)
     if ent is not None and ent[2]() is arr:
         ent[0] += 1
-        return
+        return ent
     was = bool(arr.flags.writeable)
     try:
         arr.flags.writeable = False
     except ValueError:
         pass
+    ent = [1, was, None]
     try:
-        ref = weakref.ref(arr, lambda _, k=key: _pin_guard.pop(k, None))
+        ent[2] = weakref.ref(arr, lambda _, k=key, e=ent: _pin_guard.pop(k, None) if _pin_guard.get(k) is e else None)
     except TypeError:
-        ref = lambda: arr
-    _pin_guard[key] = [1, was, ref]
+        ent[2] = lambda: arr
+    _pin_guard[key] = ent
+    return ent
 
 
-def _guard_release(key):
-    ent = _pin_guard.get(key)
+def _guard_release(ent):
+    """Drop one pin of the array this ENTRY guards (not whatever array carries the same id() today)."""
     if ent is None:
         return
     ent[0] -= 1
     if ent[0] <= 0:
         arr = ent[2]()
-        if arr is not None and ent[1]:
-            try:
-                arr.flags.writeable = True
-            except ValueError:
-                pass
-        _pin_guard.pop(key, None)
+        if arr is not None:
+            if ent[1]:
+                try:
+                    arr.flags.writeable = True
+                except ValueError:
+                    pass
+            if _pin_guard.get(id(arr)) is ent:
+                _pin_guard.pop(id(arr), None)
 
 
 class _DeviceProjectorBase(Projector):
@@ -212,26 +218,30 @@ class _DeviceProjectorBase(Projector):
         if hit is not None and hit[0]() is pts:
             hit[3] += 1                     # pins nest: the copy goes when the last holder unpins
             return hit[1]
+        if isinstance(pts, np.ndarray) and pts.base is not None:
+            # a view: edits through its base array would go unseen by the device copy (the read-only flag only guards
+            # the view itself), so views are not pinned -- they are uploaded per call like any live array
+            raise ValueError('pin(): the array is a view of another array; pin the base array or pass a copy')
         arr = np.atleast_2d(pts)
         dd = DeviceData(arr, ctx=self.ctx)
-        _guard_acquire(pts)
-        fin = weakref.finalize(self, _guard_release, key)      # a dying projector lets go of its pins
+        ent = _guard_acquire(pts)
+        fin = weakref.finalize(self, _guard_release, ent)      # a dying projector lets go of its pins
         try:
             ref = weakref.ref(pts, lambda _, k=key, pins=self._pins: pins.pop(k, None))
         except TypeError:
             ref = lambda: pts
-        self._pins[key] = [ref, dd, fin, 1]
+        self._pins[key] = [ref, dd, fin, 1, ent]
         return dd
 
     def unpin(self, pts):
         hit = self._pins.get(id(pts))
-        if hit is None:
+        if hit is None or hit[0]() is not pts:
             return
         hit[3] -= 1
         if hit[3] <= 0:
             self._pins.pop(id(pts), None)
             hit[2].detach()
-            _guard_release(id(pts))
+            _guard_release(hit[4])
 
     def forget(self, pts=None):
         """Drop the pinned device copy of `pts` (or of everything) and the spare Phi buffers."""
@@ -241,7 +251,7 @@ class _DeviceProjectorBase(Projector):
         for key in list(self._pins):
             hit = self._pins.pop(key)
             hit[2].detach()
-            _guard_release(key)
+            _guard_release(hit[4])
         self._pool.clear()
 
     def device_data(self, pts):

@@ -150,6 +150,8 @@ extern "C" int bc_comm_precheck(bc_ctx* ctx) {
   return BC_OK;
 }
 
+bc_ctx* bc_comm_ctx(const bc_comm* c) { return c ? c->ctx : nullptr; }
+
 extern "C" int bc_comm_info(const bc_comm* c, int32_t* rank, int32_t* world) {
   if (!c) return BC_INVALID_ARGUMENT;
   if (rank) *rank = c->rank;

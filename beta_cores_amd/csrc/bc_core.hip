@@ -726,11 +726,16 @@ extern "C" int bc_phi_colsum(bc_phi* p, double* out) {
 
 struct bc_comm;
 extern "C" int bc_comm_sum_doubles(bc_comm* c, const double* in_dev, int64_t count, double* out_host);
+extern "C" int bc_comm_info(const bc_comm* c, int32_t* rank, int32_t* world);
+bc_ctx* bc_comm_ctx(const bc_comm* c);
 
 // b = Phi^T 1 over ALL ranks' row shards (hilbert.py:17, bcores.py:77): this shard's column sums are already in HBM
 // (K1 fuses them); they are all-gathered and added in rank order without leaving the device.
 extern "C" int bc_phi_colsum_all(bc_phi* p, bc_comm* c, double* out) {
   if (!p || !c || !out) { bc_set_error("bc_phi_colsum_all: bad argument"); return BC_INVALID_ARGUMENT; }
+  int32_t rk = 0, wd = 0;
+  if (bc_comm_info(c, &rk, &wd) != BC_OK) { bc_set_error("bc_phi_colsum_all: bad communicator"); return BC_INVALID_ARGUMENT; }
+  if (bc_comm_ctx(c) != p->ctx) { bc_set_error("bc_phi_colsum_all: Phi and communicator belong to different contexts"); return BC_INVALID_ARGUMENT; }
   return bc_comm_sum_doubles(c, p->colsum, p->s, out);
 }
 

@@ -1326,6 +1326,7 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
 // i.e. of the N x S projection only its S column sums are used.  The materialising path writes 8*N*S bytes to read S
 // numbers back; here K1 keeps its per-tile column partials and stores nothing else (k_project<..., STORE = false>).
 int bc_comm_sum_dev(bc_comm* c, const double* in_dev, int64_t count, const double** result_dev);   // bc_comm.hip
+bc_ctx* bc_comm_ctx(const bc_comm* c);
 
 // the context's stats-only Phi, sized for n_rows x s
 static int colsum_phi_for(bc_ctx* ctx, int64_t n_rows, int32_t s, bc_phi** out) {
@@ -1350,6 +1351,7 @@ extern "C" int bc_project_colsum(bc_ctx* ctx, const bc_data* data, int model, co
   int rc = project_check(ctx, data, model, theta, s, params, n_params, "bc_project_colsum");
   if (rc) return rc;
   if (!out_s) { bc_set_error("bc_project_colsum: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (comm && bc_comm_ctx(comm) != ctx) { bc_set_error("bc_project_colsum: the communicator belongs to another context"); return BC_INVALID_ARGUMENT; }
   if (s > 256) { bc_set_error("bc_project_colsum: at most 256 samples (S = %d): project and take bc_phi_colsum", s); return BC_INVALID_ARGUMENT; }
   BC_HIP(hipSetDevice(ctx->device));
   ProjPlan pl;
@@ -1401,6 +1403,7 @@ extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* co
   if (rc) return rc;
   if (m <= 0 || !core_rows || !w || !out_grad) { bc_set_error("bc_vi_gradient: needs a non-empty coreset (m = %lld)", (long long)m); return BC_INVALID_ARGUMENT; }
   if (s > 256) { bc_set_error("bc_vi_gradient: at most 256 samples (S = %d)", s); return BC_INVALID_ARGUMENT; }
+  if (comm && bc_comm_ctx(comm) != ctx) { bc_set_error("bc_vi_gradient: the communicator belongs to another context"); return BC_INVALID_ARGUMENT; }
   const int dz = data->dz;
   const size_t n_core = (size_t)m * dz, n_down = (size_t)m + (size_t)s;
   if (n_down > ctx->pinned_doubles) {

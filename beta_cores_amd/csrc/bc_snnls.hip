@@ -1278,7 +1278,9 @@ static bool fused_rescore_ok(const bc_snnls* h) {
   if (no_fuse || !use_pref(h) || h->d.world != 1 || h->comm || !h->cand_send_owned) return false;
   if (!finish_pf_ok(h, h->d.rec_len)) return false;
   const size_t lds = ((size_t)5 * h->d.s + h->d.rec_len + 2 * (size_t)(h->nnz_upper + 1)) * sizeof(double);
-  return lds <= BC_RS_MAX_DYN_LDS;
+  // static LDS of the fused kernel (rescoring strips 32 KB, current / best row 16 KB, tile list 4 KB, ...) + the dynamic part
+  // must fit the device's per-block limit (160 KB on gfx950; the two-launch path is taken otherwise)
+  return lds <= BC_RS_MAX_DYN_LDS && lds + 56 * 1024 <= (size_t)h->ctx->max_lds;
 }
 
 static int launch_sweep(bc_snnls* h, bool with_record, bool allow_fused) {
@@ -1349,13 +1351,14 @@ extern "C" int bc_snnls_step_finish(bc_snnls* h) {
     const size_t lds = ((size_t)5 * d.s + nrec + 2 * (size_t)(hint + 1)) * sizeof(double);
     const long long n_rows = h->phi->n_rows;
     if (fused) {
-      static bool attr_done = false;       // 42 KB static + up to 48 KB dynamic LDS: above the 64 KB default limit
+      static unsigned attr_done_mask = 0;  // 42 KB static + up to 48 KB dynamic LDS: above the 64 KB default limit; per device
+      const bool attr_done = (attr_done_mask >> (h->ctx->device & 31)) & 1u;
       if (!attr_done) {
         BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_GIGA, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
         BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_FW, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
-        attr_done = true;
+        attr_done_mask |= 1u << (h->ctx->device & 31);
       }
       if (h->alg == BC_ALG_GIGA)
         hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, true>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);

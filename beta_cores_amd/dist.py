@@ -152,6 +152,8 @@ class ShardComm:
         cache = self.__dict__.setdefault('_native', {})
         key = id(ctx)
         if key in cache:
+            if cache[key][0] is not None and cache[key][3]:
+                raise RuntimeError('the native RCCL communicator of this context was aborted (a rank failed mid-loop)')
             return cache[key][0]
         import torch
         from . import _native as N
@@ -197,7 +199,7 @@ class ShardComm:
         if handle is not None:
             fin = weakref.finalize(self, N.load().bc_comm_destroy, handle)
             fin.atexit = False            # at interpreter exit the process teardown reclaims it; peers may be gone
-        cache[key] = (handle, fin, ctx)      # keeps ctx alive as long as the communicator
+        cache[key] = [handle, fin, ctx, False]      # keeps ctx alive as long as the communicator; [3]: aborted
         return handle
 
     def colsum(self, vecs):
@@ -212,13 +214,14 @@ class ShardComm:
     def abort(self):
         """ncclCommAbort on the native communicators: a rank that failed mid-loop calls this before it exits."""
         from . import _native as N
-        for handle, _, _ in self.__dict__.get('_native', {}).values():
-            if handle is not None:
-                N.load().bc_comm_abort(handle)
+        for ent in self.__dict__.get('_native', {}).values():
+            if ent[0] is not None:
+                N.load().bc_comm_abort(ent[0])
+                ent[3] = True                 # native_comm() no longer hands this handle out
 
     def close(self):
         """Destroy the native communicators (call before torch.distributed.destroy_process_group)."""
-        for handle, fin, _ in self.__dict__.pop('_native', {}).values():
+        for handle, fin, _, _ in self.__dict__.pop('_native', {}).values():
             if fin is not None:
                 fin()
 

@@ -166,6 +166,110 @@ def main():
             local = (idcs >= lo) & (idcs < hi)
             assert np.array_equal(pts[local], Z[idcs[local]])
             assert np.all(np.isnan(pts[~local]))
+    elif mode.startswith('gpu_golden_'):
+        # the reference's goldens through ROW-SHARDED coresets (two ranks, one GPU, gloo): grouped (F8), sub-sampled (F9),
+        # grouped + sub-sampled (F11) tangent spaces of the greedy-VI classes; all-zero rows and sub-sampling with a sharded
+        # HilbertCoreset (F12).  Every rank seeds the global NumPy stream like the golden's generator did.
+        from conftest import load_golden
+        from oracle import models_ref as M
+        ctx = bc.Context(device=0)
+        bc.set_default_context(ctx)
+        what = mode[len('gpu_golden_'):]
+        sched = lambda i: 0.1 / (1. + i)
+
+        def lin_sampler(Z, E):
+            D = Z.shape[1] - 1
+
+            def sampler(sz, wts, pts):
+                if pts.shape[0] == 0:
+                    wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+                mu, L, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+                return mu + E.dot(L.T)
+            return sampler
+        if what in ('f8', 'f11'):
+            g = load_golden('f8_grouped_vi' if what == 'f8' else 'f11_grouped_subsampled')
+            Z, E = g['Z'], g['E']
+            groups = [list(map(int, r)) for r in g['groups']]
+            S, opt_itrs = E.shape[0], int(g['opt_itrs'])
+            bounds = bc.shard_bounds(Z.shape[0], world)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            model = bc.likelihoods.LinearRegression(1.0)
+            for nm in ('bcores', 'svi'):
+                if what == 'f11':
+                    np.random.seed(110)
+                kw = dict(opt_itrs=opt_itrs, step_sched=sched, groups=groups, comm=comm)
+                if what == 'f11':
+                    kw.update(n_subsample_select=8, n_subsample_opt=50)
+                if nm == 'bcores':
+                    alg = bc.BetaCoreset(Z[lo:hi].copy(), bc.DeviceBetaProjector(lin_sampler(Z, E), S, model, ctx=ctx), beta=0.1,
+                                         learn_beta=False, **kw)
+                else:
+                    alg = bc.SparseVICoreset(Z[lo:hi].copy(), bc.DeviceProjector(lin_sampler(Z, E), S, model, ctx=ctx), **kw)
+                nb = 4 if what == 'f8' else 5
+                for m in range(nb):
+                    alg.build(1, 12 * (m + 1))
+                    res['%s_idcs_%d' % (nm, m)] = alg.idcs.copy()
+                    res['%s_w_%d' % (nm, m)] = alg.wts.copy()
+                    res['%s_groups_%d' % (nm, m)] = np.array([int(x) for x in alg.selected_groups])
+                    res['%s_pts_%d' % (nm, m)] = alg.pts.copy()
+                if what == 'f11':
+                    res['%s_rng_after' % nm] = np.array(np.random.rand())
+        elif what == 'f9':
+            g = load_golden('f9_subsampled_gaussian')
+            X, Siginv, logdet = g['X'], g['Siginv'], float(g['logdet'])
+            d, S = X.shape[1], 40
+            mu0, Sig0inv = np.zeros(d), np.eye(d)
+            bounds = bc.shard_bounds(X.shape[0], world)
+            lo, hi = bounds[rank], bounds[rank + 1]
+
+            def sampler_w(sz, wts, pts):
+                if pts.shape[0] == 0:
+                    wts, pts = np.zeros(1), np.zeros((1, d))
+                muw, LSigw, _ = M.gauss_weighted_post(mu0, Sig0inv, Siginv, pts, wts)
+                return muw + np.random.randn(sz, muw.shape[0]).dot(LSigw.T)
+            model = bc.likelihoods.GaussianLocation(Siginv, logdet)
+            for nm in ('bcores', 'svi'):
+                np.random.seed(90)
+                kw = dict(opt_itrs=8, n_subsample_opt=60, n_subsample_select=150, step_sched=sched, comm=comm)
+                if nm == 'bcores':
+                    alg = bc.BetaCoreset(X[lo:hi].copy(), bc.DeviceBetaProjector(sampler_w, S, model, ctx=ctx), beta=.1, learn_beta=False, **kw)
+                else:
+                    alg = bc.SparseVICoreset(X[lo:hi].copy(), bc.DeviceProjector(sampler_w, S, model, ctx=ctx), **kw)
+                for m in range(6):
+                    alg.build(1, m + 1)
+                    res['%s_idcs_%d' % (nm, m)] = alg.idcs.copy()
+                    res['%s_w_%d' % (nm, m)] = alg.wts.copy()
+                res['%s_rng_after' % nm] = np.array(np.random.rand())
+        elif what == 'f12':
+            g = load_golden('f12_constant_rows')
+            for kind in ('lin', 'log'):
+                for S in (100, 200):
+                    tag = '%s_S%d_' % (kind, S)
+                    if tag + 'Z' not in g.files:
+                        continue
+                    Z, th = g[tag + 'Z'], g[tag + 'th']
+                    bounds = bc.shard_bounds(Z.shape[0], world)
+                    lo, hi = bounds[rank], bounds[rank + 1]
+                    model = bc.likelihoods.LinearRegression(1.0) if kind == 'lin' else bc.likelihoods.LogisticRegression()
+                    prj = bc.DeviceProjector(lambda n, w, p, th=th: th, S, model, ctx=ctx)
+                    for an, cls in (('giga', bc.snnls.GIGA), ('fw', bc.snnls.FrankWolfe)):
+                        if tag + an + '_sel' not in g.files:
+                            continue
+                        steps = g[tag + an + '_sel'].shape[0]
+                        h = bc.HilbertCoreset(Z[lo:hi].copy(), prj, snnls=cls, comm=comm)
+                        h.build(steps, steps)
+                        wts, pts, idcs = h.get()
+                        res[tag + an + '_idcs'], res[tag + an + '_wts'], res[tag + an + '_pts'] = idcs, wts, pts
+            # sub-sampled HilbertCoreset over sharded rows against the single-rank device run with the same seed
+            Z, th = linreg_problem()
+            bounds = bc.shard_bounds(Z.shape[0], world)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            prj = bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0), ctx=ctx)
+            np.random.seed(77)
+            h = bc.HilbertCoreset(Z[lo:hi].copy(), prj, n_subsample=700, comm=comm)
+            h.build(20, 20)
+            wts, pts, idcs = h.get()
+            res['sub_idcs'], res['sub_wts'], res['sub_pts'] = idcs, wts, pts
     np.savez(out + '.rank%d.npz' % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -123,3 +123,79 @@ def test_prefilter_overflow_across_ranks(tmp_path, mode, world):
                 assert float(r[nm + '_err']) == ref.error()
             assert int(r[nm + '_next']) == nxt
         assert sum(int(r[nm + '_fallbacks']) for r in res) >= 1
+
+
+# ------------------------------------------------------------------ row-sharded forms of the remaining reference modes (round 3)
+def _merge_pts(a, b):
+    return np.where(np.isnan(a), b, a)
+
+
+@pytest.mark.parametrize('what', ['f8', 'f11'])
+def test_sharded_grouped_tangent_spaces_reproduce_goldens(tmp_path, what):
+    """Grouped (F8) and grouped + sub-sampled (F11) tangent spaces with the rows sharded over two ranks (bcores.py:46-61):
+    group sums completed across ranks in rank order, random groups / rows drawn from the shared global stream --
+    selected groups, indices, weights (1e-5) and the RNG position equal the reference's on both ranks."""
+    from conftest import load_golden
+    g = load_golden('f8_grouped_vi' if what == 'f8' else 'f11_grouped_subsampled')
+    Z = g['Z']
+    r0, r1 = launch('gpu_golden_' + what, tmp_path)
+    nb = 4 if what == 'f8' else 5
+    for nm in ('bcores', 'svi'):
+        for m in range(nb):
+            for r in (r0, r1):
+                np.testing.assert_array_equal(r['%s_idcs_%d' % (nm, m)], g['%s_allidcs_%d' % (nm, m)])
+                np.testing.assert_array_equal(r['%s_groups_%d' % (nm, m)], g['%s_groups_%d' % (nm, m)])
+                np.testing.assert_allclose(r['%s_w_%d' % (nm, m)], g['%s_allw_%d' % (nm, m)], rtol=1e-5, atol=1e-12)
+                assert np.array_equal(r['%s_pts_%d' % (nm, m)], Z[g['%s_allidcs_%d' % (nm, m)]])      # rows fetched from their owners
+            assert np.array_equal(r0['%s_w_%d' % (nm, m)], r1['%s_w_%d' % (nm, m)])                    # replicated state
+        if what == 'f11':
+            for r in (r0, r1):
+                assert float(r['%s_rng_after' % nm]) == float(g['%s_rng_after' % nm])
+
+
+def test_sharded_subsampled_tangent_space_reproduces_golden_f9(tmp_path):
+    """Sub-sampled selection and gradient steps (bcores.py:51-55) over sharded rows: every rank projects the drawn rows it
+    owns, the argmax compares (score, position in the draw) across ranks -- golden F9 selections / weights / RNG position."""
+    from conftest import load_golden
+    g = load_golden('f9_subsampled_gaussian')
+    r0, r1 = launch('gpu_golden_f9', tmp_path)
+    for nm in ('bcores', 'svi'):
+        for m in range(6):
+            for r in (r0, r1):
+                np.testing.assert_array_equal(r['%s_idcs_%d' % (nm, m)], g['%s_allidcs_%d' % (nm, m)])
+                np.testing.assert_allclose(r['%s_w_%d' % (nm, m)], g['%s_allw_%d' % (nm, m)], rtol=1e-5, atol=1e-12)
+        for r in (r0, r1):
+            assert float(r['%s_rng_after' % nm]) == float(g['%s_rng_after' % nm])
+
+
+def test_sharded_hilbert_zero_rows_and_subsampling(tmp_path):
+    """HilbertCoreset over sharded rows with all-zero projection rows (golden F12: the index shift of hilbert.py:16,32 from
+    the exchanged list of dropped rows) and with n_subsample (hilbert.py:12-15: shared draw, rows collected from their
+    owners, the sub-sample sharded again by position) -- equal to the reference / to the single-rank device run."""
+    import beta_cores_amd as bc
+    from conftest import load_golden
+    g = load_golden('f12_constant_rows')
+    r0, r1 = launch('gpu_golden_f12', tmp_path)
+    seen = 0
+    for kind in ('lin', 'log'):
+        for S in (100, 200):
+            tag = '%s_S%d_' % (kind, S)
+            for an in ('giga', 'fw'):
+                if tag + an + '_idcs' not in r0.files:
+                    continue
+                seen += 1
+                Z = g[tag + 'Z']
+                for r in (r0, r1):
+                    np.testing.assert_array_equal(r[tag + an + '_idcs'], g[tag + an + '_idcs'])
+                    np.testing.assert_allclose(r[tag + an + '_wts'], g[tag + an + '_wts'], rtol=1e-5)
+                pts = _merge_pts(r0[tag + an + '_pts'], r1[tag + an + '_pts'])
+                assert np.array_equal(pts, Z[g[tag + an + '_idcs']])
+    assert seen >= 2
+    Z, th = linreg_problem()
+    np.random.seed(77)
+    single = bc.HilbertCoreset(Z, bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0)), n_subsample=700)
+    single.build(20, 20)
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r['sub_idcs'], single.idcs)
+        np.testing.assert_allclose(r['sub_wts'], single.wts, rtol=1e-9)
+    assert np.array_equal(_merge_pts(r0['sub_pts'], r1['sub_pts']), Z[single.idcs])
