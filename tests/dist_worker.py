@@ -37,10 +37,14 @@ def main():
     mode, out = sys.argv[1], sys.argv[2]
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    if mode in ('gpu_nccl1', 'gpu_nccl1_torch', 'gpu_nccl1_overflow'):
+    if mode in ('gpu_nccl1', 'gpu_nccl1_torch', 'gpu_nccl1_overflow', 'gpu_nccl1_bcores'):
         import torch
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    elif mode.startswith('gpu_ncclN'):
+        import torch                        # one GPU per rank: the real multi-GPU transport (needs >= world devices)
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
     else:
         dist.init_process_group('gloo', rank=rank, world_size=world)
     import beta_cores_amd as bc
@@ -101,6 +105,78 @@ def main():
             res[nm + '_trace_f'] = s._eng.trace()[0]
             res[nm + '_fallbacks'] = np.array(s._eng.prefilter_fallbacks())
             res[nm + '_next'] = np.array(s._select())            # step-wise protocol through the same situation
+    elif mode in ('gpu_nccl1_bcores', 'gpu_ncclN_bcores'):
+        # BetaCoreset over the library's own RCCL communicator: every gradient is ONE bc_vi_gradient call whose column sums
+        # are all-gathered and added in rank order inside the library (1 rank: rehearsal on one GPU; N ranks: one GPU each)
+        import torch
+        os.environ['BC_FORCE_EXCHANGE'] = '1'
+        dev_id = rank if mode == 'gpu_ncclN_bcores' else 0
+        stream = torch.cuda.Stream(device=dev_id)
+        torch.cuda.set_stream(stream)
+        ctx = bc.Context(device=dev_id, stream=stream.cuda_stream)
+        bc.set_default_context(ctx)
+        Z, th = linreg_problem(n=9000)
+        bounds = bc.shard_bounds(Z.shape[0], world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        E = np.random.RandomState(3).randn(th.shape[0], Z.shape[1] - 1)
+        from oracle import models_ref as M
+
+        def sampler(sz, wts, pts):
+            if pts.shape[0] == 0:
+                wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+            mu, L, _ = M.linreg_weighted_post(np.zeros(Z.shape[1] - 1), np.eye(Z.shape[1] - 1), 1.0, pts, wts)
+            return mu + E.dot(L.T)
+        prj = bc.DeviceBetaProjector(sampler, th.shape[0], bc.likelihoods.LinearRegression(1.0), ctx=ctx)
+        calls = {'n': 0}
+        orig = prj.vi_gradient
+
+        def counted(*a, **kw):
+            calls['n'] += 1
+            assert kw.get('comm') is not None
+            return orig(*a, **kw)
+        prj.vi_gradient = counted
+        alg = bc.BetaCoreset(Z[lo:hi].copy(), prj, opt_itrs=5, step_sched=lambda i: 0.1 / (1. + i), beta=0.1, learn_beta=False, comm=comm)
+        for m in range(6):
+            alg.build(1, m + 1)
+        res['idx'], res['val'], res['pts'] = alg.idcs, alg.wts, alg.pts
+        res['fused_calls'] = np.array(calls['n'])
+    elif mode in ('gpu_ncclN_hilbert', 'gpu_ncclN_overflow'):
+        import torch
+        stream = torch.cuda.Stream(device=rank)
+        torch.cuda.set_stream(stream)
+        ctx = bc.Context(device=rank, stream=stream.cuda_stream)
+        bc.set_default_context(ctx)
+        if mode == 'gpu_ncclN_hilbert':
+            Z, th = linreg_problem()
+            bounds = bc.shard_bounds(Z.shape[0], world)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            prj = bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0), ctx=ctx)
+            h = bc.HilbertCoreset(Z[lo:hi].copy(), prj, comm=comm)
+            assert h.snnls._eng.native_exchange
+            h.build(25, 25)
+            wts, pts, idcs = h.get()
+            res['idx'], res['val'], res['err'], res['pts'] = idcs, wts, np.array(h.error()), pts
+            res['trace_f'] = h.snnls._eng.trace()[0]
+            phi = h.snnls._eng.phi
+            res['colsum_native'] = comm.colsum(phi)                      # RCCL all-gather + k_sum_rank_order, world > 1
+            res['colsum_host'] = comm.sum_in_rank_order(phi.colsum())
+        else:
+            os.environ['BC_PREFILTER'] = '8'
+            os.environ['BC_PREFILTER_CAP'] = '2'
+            phi = overflow_problem()
+            b = phi.sum(axis=0)
+            bounds = bc.shard_bounds(phi.shape[0], world)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            for nm, cls in (('giga', bc.snnls.GIGA), ('fw', bc.snnls.FrankWolfe)):
+                s = cls(phi[lo:hi].T, b, comm=comm, row_offset=lo)
+                assert s._eng.prefilter == 8 and s._eng.native_exchange
+                s.build(12)
+                s.build(8)
+                idx, val = s.sparse_weights()
+                res[nm + '_idx'], res[nm + '_val'], res[nm + '_err'] = idx, val, np.array(s.error())
+                res[nm + '_trace_f'] = s._eng.trace()[0]
+                res[nm + '_fallbacks'] = np.array(s._eng.prefilter_fallbacks())
+                res[nm + '_next'] = np.array(s._select())
     elif mode in ('gpu_nccl1', 'gpu_nccl1_torch'):
         # one rank, RCCL backend, exchange forced on: the exact code path of `bench.py --gpus N`
         # (native: RCCL called by the C library inside bc_snnls_build; torch: one torch.distributed call per step)

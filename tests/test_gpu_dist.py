@@ -199,3 +199,61 @@ def test_sharded_hilbert_zero_rows_and_subsampling(tmp_path):
         np.testing.assert_array_equal(r['sub_idcs'], single.idcs)
         np.testing.assert_allclose(r['sub_wts'], single.wts, rtol=1e-9)
     assert np.array_equal(_merge_pts(r0['sub_pts'], r1['sub_pts']), Z[single.idcs])
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _beta_reference():
+    Z, th = linreg_problem(n=9000)
+    D = Z.shape[1] - 1
+    E = np.random.RandomState(3).randn(th.shape[0], D)
+
+    def sampler(sz, wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, Z.shape[1]))
+        mu, L, _ = M.linreg_weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + E.dot(L.T)
+    ref = C.RefGreedyVI(Z, lambda pts, t: C.project_f(lambda z, tt, b: M.linreg_beta_lik(z, tt, b, 1.0), pts, t, 0.1),
+                        lambda w, p: sampler(0, w, p), 5, lambda i: 0.1 / (1. + i))
+    ref.build(6)
+    return ref
+
+
+def test_fused_gradient_over_the_native_communicator_single_rank(tmp_path):
+    """BetaCoreset with `comm` on a 1-rank NCCL group (BC_FORCE_EXCHANGE): every gradient is one bc_vi_gradient call whose
+    column sums go through ncclAllGather + the rank-order sum inside the library -- the code path of a multi-GPU run."""
+    ref = _beta_reference()
+    (r0,) = launch('gpu_nccl1_bcores', tmp_path, world=1)
+    np.testing.assert_array_equal(r0['idx'], ref.idcs)
+    np.testing.assert_allclose(r0['val'], ref.wts, rtol=1e-5, atol=1e-12)
+    assert np.array_equal(r0['pts'], ref.pts)
+    assert int(r0['fused_calls']) == 6 * 5
+
+
+@pytest.mark.skipif(_gpus() < 2, reason='needs two GPUs: world > 1 over RCCL (one process per GPU)')
+def test_two_gpus_native_rccl_paths(tmp_path):
+    """World size 2 over RCCL, one GPU per rank (skipped on one-GPU boxes): the fused greedy loop with the in-library
+    all-gather, bc_phi_colsum_all / k_sum_rank_order with two ranks, the pre-filter overflow marker travelling through
+    the gathered records, and the fused beta-Cores gradient with its collective -- against single-rank results."""
+    import beta_cores_amd as bc
+    Z, th = linreg_problem()
+    single = bc.HilbertCoreset(Z, bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0)))
+    single.build(25, 25)
+    r0, r1 = launch('gpu_ncclN_hilbert', tmp_path, world=2)
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r['idx'], single.idcs)
+        np.testing.assert_allclose(r['val'], single.wts, rtol=1e-9)
+        np.testing.assert_array_equal(r['trace_f'], single.snnls._eng.trace()[0])
+        assert np.array_equal(r['colsum_native'], r['colsum_host'])           # device rank-order sum == host rank-order sum
+    assert np.array_equal(r0['val'], r1['val'])
+    ref = _beta_reference()
+    for r in launch('gpu_ncclN_bcores', tmp_path, world=2):
+        np.testing.assert_array_equal(r['idx'], ref.idcs)
+        np.testing.assert_allclose(r['val'], ref.wts, rtol=1e-5, atol=1e-12)
+        assert int(r['fused_calls']) == 6 * 5
+    res = launch('gpu_ncclN_overflow', tmp_path, world=2)
+    assert sum(int(r['giga_fallbacks']) for r in res) >= 1
+    assert np.array_equal(res[0]['giga_val'], res[1]['giga_val']) and np.array_equal(res[0]['giga_idx'], res[1]['giga_idx'])
