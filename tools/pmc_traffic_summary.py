@@ -25,12 +25,12 @@ def rows(d):
         return list(csv.DictReader(fh))
 
 
-def per_launch(rs, counter, name_part, min_grid):
+def per_launch(rs, counter, name_part, min_grid, max_grid=1 << 60):
     vals = {}
     for r in rs:
         if r['Counter_Name'] != counter or name_part not in r['Kernel_Name']:
             continue
-        if int(r['Grid_Size']) < min_grid:
+        if int(r['Grid_Size']) < min_grid or int(r['Grid_Size']) > max_grid:
             continue
         vals.setdefault(r['Dispatch_Id'], 0.)
         vals[r['Dispatch_Id']] += float(r['Counter_Value'])
@@ -53,13 +53,32 @@ def main():
                          'traffic_bytes_per_launch': 2 * f + w, 'algorithmic_bytes_per_launch': alg,
                          'ratio': (2 * f + w) / alg,
                          'correction': '2 x FETCH_SIZE + WRITE_SIZE (gfx950 counts the 128-B requests of 16-B/lane streaming reads as 64 B, MI355X_MICROARCH.md HBM section)'}
-    f, n, kn = per_launch(fetch, 'FETCH_SIZE', 'k_project', 70000 * 256)
-    w, _, _ = per_launch(write, 'WRITE_SIZE', 'k_project', 70000 * 256)
-    ar, aw = 8. * N * (D + 1), 8. * N * S
-    out['k_project'] = {'kernel': kn, 'launches': n, 'FETCH_SIZE_bytes': f, 'WRITE_SIZE_bytes': w,
-                        'algorithmic_read_bytes': ar, 'algorithmic_write_bytes': aw, 'write_ratio': w / aw,
-                        'fetch_x1_ratio': f / ar, 'fetch_x2_ratio': 2 * f / ar,
-                        'note': 'stores are 16 B/lane (WRITE_SIZE calibrated: exact); the Z loads are 8 B/lane buffer loads and the Theta re-staging per tile is served by L2 -- FETCH_SIZE for that width is uncalibrated in the guide, both readings are given'}
+    # K1 at the headline shape: the Theta-resident kernel (one 512-thread block per CU: grid 131072) since round 3, the
+    # staged one (one block per tile) before; both read Z with 16 B / 8 B per lane and write 16 B per lane
+    for key, part, min_grid, max_grid in (('k_project_r', 'k_project_r<0, 6, 4, true>', 100000, 200000),
+                                          ('k_project', 'k_project<0, 6, 32, 2, false, 4', 70000 * 256, 1 << 40)):
+        f, n, kn = per_launch(fetch, 'FETCH_SIZE', part, min_grid)
+        w, _, _ = per_launch(write, 'WRITE_SIZE', part, min_grid)
+        if f is None:
+            continue
+        ar, aw = 8. * N * (D + 1), 8. * N * S
+        out[key] = {'kernel': kn, 'launches': n, 'FETCH_SIZE_bytes': f, 'WRITE_SIZE_bytes': w,
+                    'algorithmic_read_bytes': ar, 'algorithmic_write_bytes': aw, 'write_ratio': w / aw,
+                    'fetch_x1_ratio': f / ar, 'fetch_x2_ratio': 2 * f / ar,
+                    'traffic_bytes_per_launch (2 x FETCH + WRITE)': 2 * f + w, 'ratio_to_algorithmic': (2 * f + w) / (ar + aw),
+                    'note': 'stores are 16 B/lane (WRITE_SIZE calibrated: exact).  k_project_r reads Z with 16-B-per-lane buffer loads '
+                            '(the calibrated case: FETCH_SIZE x 2); the staged kernel read it 8 B per lane (uncalibrated: both readings given)'}
+    if len(sys.argv) > 4:
+        # store-free K1 (the beta-Cores gradient loop): a separate pair of passes over tools/k1_bench.py --store-free
+        f2, w2 = rows(sys.argv[3]), rows(sys.argv[4])
+        f, n, kn = per_launch(f2, 'FETCH_SIZE', 'k_project_r<1, 6, 4, false>', 100000)
+        w, _, _ = per_launch(w2, 'WRITE_SIZE', 'k_project_r<1, 6, 4, false>', 100000)
+        if f is not None:
+            ar = 8. * N * (D + 1)
+            out['k_project_r store-free (beta-likelihood)'] = {
+                'kernel': kn, 'launches': n, 'FETCH_SIZE_bytes': f, 'WRITE_SIZE_bytes': w, 'algorithmic_bytes (8*N*Dz)': ar,
+                'traffic_bytes_per_launch (2 x FETCH + WRITE)': 2 * f + w, 'ratio_to_algorithmic': (2 * f + w) / ar,
+                'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 tools/k1_bench.py --rows 10000000 --models linreg_beta --store-free --reps 3'}
     json.dump(out, sys.stdout, indent=1)
     print()
 
