@@ -311,15 +311,20 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
         srng = np.random.RandomState(1000 + M)
         t_samp = [0.0, 0]
 
-        def sampler_w(k, wts, pts_):           # zellner_neural_linear/main.py:119-124 (the weighted_post form)
-            t0 = time.perf_counter()
-            if pts_.shape[0] == 0:
-                wts, pts_ = np.zeros(1), np.zeros((1, dz))
-            mu, L, _ = bc.weighted_post(th0, Sig0inv, 1.0, pts_, wts, ctx=ctx)
-            r = mu + srng.randn(k, d).dot(L.T)
-            t_samp[0] += time.perf_counter() - t0
-            t_samp[1] += 1
-            return r
+        # zellner_neural_linear/main.py:119-124 (the weighted_post form) as bc.samplers.LinregPosteriorSampler: the same
+        # arithmetic and draws; its prefetch() draws the next call's normals while the GPU works on the current gradient
+        base_sampler = bc.samplers.LinregPosteriorSampler(th0, Sig0inv, 1.0, rng=srng, ctx=ctx)
+
+        class TimedSampler:
+            prefetch = staticmethod(base_sampler.prefetch)
+
+            def __call__(self, k, wts, pts_):
+                t0 = time.perf_counter()
+                r = base_sampler(k, wts, pts_)
+                t_samp[0] += time.perf_counter() - t0
+                t_samp[1] += 1
+                return r
+        sampler_w = TimedSampler()
         prj = bc.DeviceBetaProjector(sampler_w, S, bc.likelihoods.LinearRegression(1.0), ctx=ctx)
         sched = lambda i: 0.01 / (1. + i)
 

@@ -18,10 +18,11 @@ from .coreset import (Coreset, HilbertCoreset, BetaCoreset, SparseVICoreset, Bat
                       Projector, BlackBoxProjector,
                       BetaBlackBoxProjector, DeviceProjector, DeviceBetaProjector)
 from . import likelihoods
+from . import samplers
 from .posterior import weighted_gram, weighted_post, weighted_post_corrected, gaussian_weighted_post
 from .dist import ShardComm, shard_bounds
 
-__all__ = ['util', 'snnls', 'likelihoods', 'NumericalPrecisionError', 'Context', 'DeviceData', 'DevicePhi',
+__all__ = ['util', 'snnls', 'likelihoods', 'samplers', 'NumericalPrecisionError', 'Context', 'DeviceData', 'DevicePhi',
            'default_context', 'set_default_context', 'Coreset', 'HilbertCoreset', 'BetaCoreset', 'SparseVICoreset',
            'BatchPSVICoreset', 'UniformSamplingCoreset',
            'Projector', 'BlackBoxProjector', 'BetaBlackBoxProjector', 'DeviceProjector', 'DeviceBetaProjector',

@@ -45,6 +45,8 @@ _SIGNATURES = {
     'bc_project_grad_x': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, vp],
     'bc_project_colsum': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, vp, vp],
     'bc_vi_gradient': [vp, vp, vp, C.c_int64, C.c_int, vp, C.c_int32, vp, C.c_int32, vp, C.c_double, vp, vp, vp],
+    'bc_vi_gradient_begin': [vp, vp, vp, C.c_int64, C.c_int, vp, C.c_int32, vp, C.c_int32, vp, C.c_double, vp],
+    'bc_vi_gradient_end': [vp, vp, vp],
     'bc_phi_shape': [vp, c_i64p, c_i32p, c_i64p],
     'bc_phi_colsum': [vp, vp],
     'bc_phi_norms': [vp, vp],

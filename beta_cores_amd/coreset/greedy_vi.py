@@ -250,7 +250,7 @@ class GreedyVICoreset(Coreset):
                 self._append(self.groups[f], self._rows(self.groups[f]) if self.comm is not None else self.data[self.groups[f], :])
 
     # -- bcores.py:141-150
-    def _fused_gradient(self, w, beta):
+    def _fused_gradient(self, w, beta, overlap=None):
         """The full-data, ungrouped gradient in one native call (bc_vi_gradient): the data rows go through the
         store-free K1 (only `vecs.sum(axis=0)` is needed of them, bcores.py:144-145), the coreset rows and the M x S
         algebra stay on the device, one host synchronisation.  None when this mode does not apply (black-box
@@ -266,7 +266,7 @@ class GreedyVICoreset(Coreset):
                 return None
         self.ll_projector.update(w, self.pts)
         g = self.ll_projector.vi_gradient(self._dev_data if self._dev_data is not None else self.data, self.pts, w, 1.,
-                                          beta=self._fused_beta(beta), comm=nc)
+                                          beta=self._fused_beta(beta), comm=nc, overlap=overlap)
         if g is None:
             raise RuntimeError('fused gradient not applicable after the sampler ran')      # guarded by the checks above
         return g
@@ -285,9 +285,16 @@ class GreedyVICoreset(Coreset):
         beta = self._beta()
         fused = self._fused_ok() if hasattr(self.ll_projector, 'vi_gradient') else False
 
+        # a sampler that can draw its next normals ahead of time (samplers.*PosteriorSampler.prefetch) does so while the GPU
+        # works on the current gradient -- except after the LAST gradient of this call: what follows that one is not this
+        # loop's next sampler call, and the stream must not be advanced on its behalf
+        prefetch = getattr(getattr(self.ll_projector, 'sampler', None), 'prefetch', None) if fused else None
+        calls = [0]
+
         def grd(w):
             if fused:
-                g = self._fused_gradient(w, beta)
+                calls[0] += 1
+                g = self._fused_gradient(w, beta, overlap=prefetch if calls[0] < self.opt_itrs else None)
                 if g is not None:
                     return g
             vecs, sum_scaling, _, _, corevecs = self._tangent(self.n_subsample_opt, w, self.pts, beta)

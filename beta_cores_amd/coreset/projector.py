@@ -317,12 +317,13 @@ class _DeviceProjectorBase(Projector):
                comm, _ptr(out))
         return out
 
-    def vi_gradient(self, data, core_pts, w, sum_scaling=1., beta=None, comm=None, want_resid=False):
+    def vi_gradient(self, data, core_pts, w, sum_scaling=1., beta=None, comm=None, want_resid=False, overlap=None):
         """One gradient of the greedy-VI weight optimisation in one native call (bc_vi_gradient): with the current
         samples, -corevecs.dot(sum_scaling * vecs.sum(axis=0) - w.dot(corevecs)) / S for vecs = projection of `data`
         (resident DeviceData, pinned array, or a live array that is uploaded for this call like project() does) and
         corevecs = projection of `core_pts`.  None if not covered (S > 256, no coreset rows, or a coreset too large
-        for the staging area)."""
+        for the staging area).  `overlap`: a callable run on the host between the enqueue and the wait (bc_vi_gradient_begin /
+        _end), i.e. beside the GPU -- the samplers' `prefetch` (drawing the next sample matrix's normals) goes there."""
         dd, _ = self.device_data(data)
         core = np.ascontiguousarray(np.atleast_2d(core_pts), dtype=np.float64)
         m = int(core.shape[0])
@@ -339,8 +340,13 @@ class _DeviceProjectorBase(Projector):
         params = np.ascontiguousarray(params, dtype=np.float64)
         grad = np.empty(m)
         resid = np.empty(S) if want_resid else None
-        N.call('bc_vi_gradient', self.ctx.h, dd.h, _ptr(core), m, int(model_id), _ptr(theta), S, _ptr(params),
-               int(params.shape[0]), _ptr(w), float(sum_scaling), comm, _ptr(grad), _ptr(resid) if want_resid else None)
+        N.call('bc_vi_gradient_begin', self.ctx.h, dd.h, _ptr(core), m, int(model_id), _ptr(theta), S, _ptr(params),
+               int(params.shape[0]), _ptr(w), float(sum_scaling), comm)
+        try:
+            if overlap is not None:
+                overlap()
+        finally:
+            N.call('bc_vi_gradient_end', self.ctx.h, _ptr(grad), _ptr(resid) if want_resid else None)
         return (grad, resid) if want_resid else grad
 
 

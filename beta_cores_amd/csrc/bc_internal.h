@@ -63,6 +63,9 @@ struct bc_ctx {
   hipEvent_t vi_ev[BC_VI_PHASES + 1] = {};
   double vi_phase_ms[BC_VI_PHASES] = {};
   int64_t vi_calls_timed = 0;
+  int64_t vi_pending_m = 0;      // bc_vi_gradient_begin enqueued a gradient of this many rows (bc_vi_gradient_end fetches it)
+  int32_t vi_pending_s = 0;
+  bool vi_pending_timed = false;
 };
 
 int bc_scratch_grow(bc_ctx* ctx, bc_scratch* s, size_t doubles);   // contents are NOT kept when it grows

@@ -1396,12 +1396,12 @@ __global__ __launch_bounds__(256) void k_vi_gradient(const double* __restrict__ 
   }
 }
 
-extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* core_rows, int64_t m, int model,
-                              const double* theta, int32_t s, const double* params, int32_t n_params, const double* w,
-                              double sum_scaling, bc_comm* comm, double* out_grad, double* out_resid) {
+extern "C" int bc_vi_gradient_begin(bc_ctx* ctx, const bc_data* data, const double* core_rows, int64_t m, int model,
+                                    const double* theta, int32_t s, const double* params, int32_t n_params, const double* w,
+                                    double sum_scaling, bc_comm* comm) {
   int rc = project_check(ctx, data, model, theta, s, params, n_params, "bc_vi_gradient");
   if (rc) return rc;
-  if (m <= 0 || !core_rows || !w || !out_grad) { bc_set_error("bc_vi_gradient: needs a non-empty coreset (m = %lld)", (long long)m); return BC_INVALID_ARGUMENT; }
+  if (m <= 0 || !core_rows || !w) { bc_set_error("bc_vi_gradient: needs a non-empty coreset (m = %lld)", (long long)m); return BC_INVALID_ARGUMENT; }
   if (s > 256) { bc_set_error("bc_vi_gradient: at most 256 samples (S = %d)", s); return BC_INVALID_ARGUMENT; }
   if (comm && bc_comm_ctx(comm) != ctx) { bc_set_error("bc_vi_gradient: the communicator belongs to another context"); return BC_INVALID_ARGUMENT; }
   const int dz = data->dz;
@@ -1482,6 +1482,22 @@ extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* co
   BC_HIP(hipMemcpyAsync(ctx->pinned, d_grad, n_down * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   rc = mark(5);
   if (rc) return rc;
+  ctx->vi_pending_m = m;
+  ctx->vi_pending_s = s;
+  ctx->vi_pending_timed = timed;
+  return BC_OK;
+}
+
+// second half: wait for the enqueued gradient and hand it out (whatever the host did meanwhile -- e.g. drawing the next
+// sample matrix's normals -- ran beside the GPU)
+extern "C" int bc_vi_gradient_end(bc_ctx* ctx, double* out_grad, double* out_resid) {
+  if (!ctx || !out_grad) { bc_set_error("bc_vi_gradient_end: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (ctx->vi_pending_m <= 0) { bc_set_error("bc_vi_gradient_end: no gradient is pending on this context"); return BC_INVALID_ARGUMENT; }
+  const int64_t m = ctx->vi_pending_m;
+  const int32_t s = ctx->vi_pending_s;
+  const bool timed = ctx->vi_pending_timed;
+  ctx->vi_pending_m = 0;
+  BC_HIP(hipSetDevice(ctx->device));
   BC_HIP(hipStreamSynchronize(ctx->stream));
   memcpy(out_grad, ctx->pinned, (size_t)m * sizeof(double));
   if (out_resid) memcpy(out_resid, ctx->pinned + m, (size_t)s * sizeof(double));
@@ -1494,6 +1510,15 @@ extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* co
     ctx->vi_calls_timed++;
   }
   return BC_OK;
+}
+
+extern "C" int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* core_rows, int64_t m, int model,
+                              const double* theta, int32_t s, const double* params, int32_t n_params, const double* w,
+                              double sum_scaling, bc_comm* comm, double* out_grad, double* out_resid) {
+  if (!out_grad) { bc_set_error("bc_vi_gradient: bad argument"); return BC_INVALID_ARGUMENT; }
+  int rc = bc_vi_gradient_begin(ctx, data, core_rows, m, model, theta, s, params, n_params, w, sum_scaling, comm);
+  if (rc) return rc;
+  return bc_vi_gradient_end(ctx, out_grad, out_resid);
 }
 
 extern "C" int bc_ctx_phase_times(bc_ctx* ctx, double* out_ms, int32_t n, int64_t* calls, int reset) {

@@ -171,6 +171,12 @@ int bc_project_colsum(bc_ctx* ctx, const bc_data* data, int model, const double*
 int bc_vi_gradient(bc_ctx* ctx, const bc_data* data, const double* core_rows, int64_t m, int model,
                    const double* theta, int32_t s, const double* params, int32_t n_params, const double* w,
                    double sum_scaling, bc_comm* comm, double* out_grad, double* out_resid);
+/* The same in two halves: _begin enqueues everything (including the download) and returns; _end waits and hands the result
+ * out.  Host work placed between the two runs beside the GPU (the samplers draw the next sample matrix's normals there). */
+int bc_vi_gradient_begin(bc_ctx* ctx, const bc_data* data, const double* core_rows, int64_t m, int model,
+                         const double* theta, int32_t s, const double* params, int32_t n_params, const double* w,
+                         double sum_scaling, bc_comm* comm);
+int bc_vi_gradient_end(bc_ctx* ctx, double* out_grad, double* out_resid);
 /* x-gradients of the log-likelihood at `data`'s rows (the coreset's pseudo-points), centred over the coordinate axis:
  * what BlackBoxProjector.project(pts, grad=True) returns next to the projection (projector.py:27-32) and
  * BatchPSVICoreset moves its points with (bpsvi.py:39-57).  model: BC_MODEL_LINREG_LL (model_linreg.py:12-17,

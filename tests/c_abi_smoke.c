@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
                   (void*)bc_snnls_set_weights, (void*)bc_snnls_columns, (void*)bc_snnls_reset, (void*)bc_snnls_get_flags,
                   (void*)bc_snnls_set_flags, (void*)bc_snnls_trace, (void*)bc_weighted_gram, (void*)bc_comm_load, (void*)bc_comm_unique_id, (void*)bc_comm_create,
                   (void*)bc_comm_destroy, (void*)bc_comm_info, (void*)bc_comm_all_gather, (void*)bc_comm_selftest, (void*)bc_comm_precheck, (void*)bc_comm_abort, (void*)bc_comm_sum_doubles, (void*)bc_phi_colsum_all,
-                  (void*)bc_project_colsum, (void*)bc_vi_gradient, (void*)bc_ctx_phase_times, (void*)bc_comm_rank_order_sum_selftest, (void*)bc_weighted_gram_host, (void*)bc_ctx_timing_classes,
+                  (void*)bc_project_colsum, (void*)bc_vi_gradient, (void*)bc_vi_gradient_begin, (void*)bc_vi_gradient_end, (void*)bc_ctx_phase_times, (void*)bc_comm_rank_order_sum_selftest, (void*)bc_weighted_gram_host, (void*)bc_ctx_timing_classes,
                   (void*)bc_snnls_bind_comm};
   printf("abi %d, %d entry points\n", bc_version(), (int)(sizeof(syms) / sizeof(syms[0])));
   if (bc_ctx_sync(NULL) != BC_INVALID_ARGUMENT || bc_snnls_build(NULL, 1, NULL) != BC_INVALID_ARGUMENT) return 2;

@@ -180,3 +180,50 @@ def test_rank_order_sum_kernel_on_fabricated_gather(bc):
         got = np.empty(count)
         N.call('bc_comm_rank_order_sum_selftest', ctx.h, _ptr(np.ascontiguousarray(g)), world, count, _ptr(got))
         assert np.array_equal(got, want), (world, count)
+
+
+@pytest.mark.parametrize('kind', ['bcores', 'svi'])
+def test_prefetching_sampler_keeps_results_and_rng_position(bc, kind):
+    """bc.samplers.LinregPosteriorSampler draws the NEXT call's normals while the GPU works on the current gradient
+    (bc_vi_gradient_begin / _end).  Same stream, same order, nothing consumed on anyone else's behalf: the coreset, the
+    weights and the global RNG position after the builds equal those of the reference-style closure (and the oracle's)."""
+    rng = np.random.RandomState(31)
+    n, D, S, its = 6000, 9, 48, 7
+    X = rng.randn(n, D)
+    y = X.dot(rng.randn(D)) + rng.randn(n)
+    Z = np.hstack((X, y[:, None]))
+    model = bc.likelihoods.LinearRegression(1.0)
+    sched = lambda i: 0.1 / (1. + i)
+
+    def closure(sz, wts, pts):                      # zellner_neural_linear/main.py:119-124
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, D + 1))
+        mu, L, _ = bc.weighted_post(np.zeros(D), np.eye(D), 1.0, pts, wts)
+        return mu + np.random.randn(sz, D).dot(L.T)
+
+    def run(sampler):
+        np.random.seed(5)
+        if kind == 'bcores':
+            alg = bc.BetaCoreset(Z, bc.DeviceBetaProjector(sampler, S, model), opt_itrs=its, step_sched=sched, beta=0.1, learn_beta=False)
+        else:
+            alg = bc.SparseVICoreset(Z, bc.DeviceProjector(sampler, S, model), opt_itrs=its, step_sched=sched)
+        out = []
+        for m in range(5):
+            alg.build(1, m + 1)
+            out.append((alg.idcs.copy(), alg.wts.copy()))
+        return out, np.random.rand()
+    pre = bc.samplers.LinregPosteriorSampler(np.zeros(D), np.eye(D), 1.0)
+    hits = {'n': 0}
+    orig = pre.prefetch
+
+    def counted():
+        hits['n'] += 1
+        orig()
+    pre.prefetch = counted
+    a, ra = run(pre)
+    b, rb = run(closure)
+    assert hits['n'] == 5 * (its - 1)
+    assert ra == rb                                 # the global stream stands where the closure leaves it
+    for (ia, wa), (ib, wb) in zip(a, b):
+        np.testing.assert_array_equal(ia, ib)
+        assert np.array_equal(wa, wb)               # the very same normals, so the very same bits
