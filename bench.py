@@ -746,10 +746,14 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     os.dup2(2, 1)                         # teardown chatter goes to stderr again
+    parity_failed = bool(out and 'parity_failure' in out)
     if world > 1 or force_xchg:
         dist.barrier()
         comm.close()                      # the library's own RCCL communicator, before torch's
         dist.destroy_process_group()
+    if parity_failed:                     # a fast result that differs from the oracle's is not a result: fail the run
+        sys.stderr.write('bench.py: device selections / weights differ from the CPU oracle (see parity_failure in the JSON line)\n')
+        raise SystemExit(3)
 
 
 if __name__ == '__main__':

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // one, each XCD has its own L2), and the ntri tiles of one row split all read the same rows: they are given block
   // numbers that are equal modulo 8 and adjacent in that XCD's queue, so the rows are fetched from HBM once per split
   // instead of once per tile (D = 512: ten tiles per split; with the tiles of a split on neighbouring block numbers,
-  // i.e. on ten different XCDs, the kernel moved 5x its algorithmic bytes and ran 13.5-19.8 ms instead of ~11).
+  // i.e. on ten different XCDs, the kernel ran 13.5 ms instead of 12.85 at eight rounds of blocks, 19.8 instead of 18.6 at one).
   const long long q = blockIdx.x >> 3;
   const int tri = (int)(q % a.ntri);
   const long long split = (q / a.ntri) * 8 + (blockIdx.x & 7);
@@ -222,8 +222,9 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   // Row splits, in units of the 2 * n_cu resident block slots (BC_GRAM_WAVES overrides), at least 2 slabs per split.
   // One tile (D <= 128): exactly one block per slot -- every further split writes, and the reduction reads back, another
   // 128 KB tile (8 per slot were 268 MB of partials at N = 10M, D = 128: 6.06 ms with one, 7.76 ms with eight).  Several
-  // tiles (D = 512: ten): short blocks, eight rounds -- with one round the two blocks of a CU run in lock-step (both staging,
-  // then both on the matrix pipe) and the kernel takes 18.6 ms instead of 12.9 (profiles/r03_notes.md).
+  // tiles (D = 512: ten): short blocks, eight rounds -- 12.9 ms against 18.6 with one round (8-12 rounds: the same; 16-48:
+  // 13.1-14.6).  Long blocks let the ten tile-blocks of a split drift apart by more rows than their XCD's L2 holds, so the
+  // shared rows are fetched again; static priorities or a start stagger change nothing (profiles/r03_notes.md).
   static const int waves_env = getenv("BC_GRAM_WAVES") ? atoi(getenv("BC_GRAM_WAVES")) : 0;
   const int waves = waves_env > 0 ? waves_env : (ntri == 1 ? 1 : 8);
   long long want_splits = ((long long)ctx->n_cu * 2 * (waves > 0 ? waves : 1) + ntri - 1) / ntri;
