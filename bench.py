@@ -148,7 +148,7 @@ def k4_entry(n, d, ms):
             'bytes_per_launch': 8.0 * n * (d + 1), 'hbm_frac': 8.0 * n * (d + 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
-def _time_k1(ctx, call, barrier, reps=4, warm=2):
+def _time_k1(ctx, call, barrier, reps=8, warm=3):
     for _ in range(warm):
         call()
     barrier()

@@ -234,60 +234,7 @@ __device__ __forceinline__ void bc_block_sum_n(double (&v)[N], double* red) {
   for (int i = 0; i < N; ++i) v[i] = red[i * 17 + 16];
 }
 
-// ---- the mean of a CONSTANT row, exactly as `lls.mean(axis=1)` (projector.py:26,55) rounds it.
-// NumPy reduces a contiguous axis with its pairwise sum (blocks of <= 128 elements: eight running sums over
-// strides of 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then a sequential tail; longer rows are split in
-// halves rounded down to a multiple of 8).  The rounded mean of S equal numbers c is in general NOT c, so the
-// reference centres a constant row (a data row with all-zero features: x_i = 0 / z_i = 0) to a tiny constant
-// residue (c - mean) rather than to 0, keeps it at hilbert.py:16 and applies no index shift.  On equal inputs all
-// eight running sums coincide, so the sum is a function of (c, n) only and costs ~n/8 dependent adds; it is
-// evaluated for constant rows only.  Checked against NumPy for n = 1..299, 500, 1000, 1024, 4097 (tests/test_abi_cpu.py
-// restates it; tests/golden/f12 pins the reference's behaviour).
-__device__ __forceinline__ double bc_np_sum_const_leaf(double c, int n) {   // n <= 128
-  if (n < 8) {
-    double r = 0.;
-    for (int i = 0; i < n; ++i) r += c;
-    return r;
-  }
-  double r = c;
-  const int nb = n >> 3;
-  for (int i = 1; i < nb; ++i) r += c;
-  double res = ((r + r) + (r + r)) + ((r + r) + (r + r));
-  for (int i = nb << 3; i < n; ++i) res += c;
-  return res;
-}
-
-// n <= 256 (two levels of halving always reach blocks of <= 128): the K1 kernels
-__device__ __forceinline__ double bc_np_sum_const_256(double c, int n) {
-  if (n <= 128) return bc_np_sum_const_leaf(c, n);
-  int n2 = n >> 1;
-  n2 -= n2 & 7;
-  const int m = n - n2;                        // <= 135
-  const double left = bc_np_sum_const_leaf(c, n2);
-  if (m <= 128) return left + bc_np_sum_const_leaf(c, m);
-  int m2 = m >> 1;
-  m2 -= m2 & 7;
-  return left + (bc_np_sum_const_leaf(c, m2) + bc_np_sum_const_leaf(c, m - m2));
-}
-
-// any n (explicit post-order walk of the halving tree): the S > 256 centring pass
-__device__ inline double bc_np_sum_const_any(double c, int n) {
-  int sz[40], stage[40];
-  double left[40];
-  int sp = 0;
-  double ret = 0.;
-  sz[0] = n; stage[0] = 0; left[0] = 0.; sp = 1;
-  while (sp > 0) {
-    const int t = sp - 1;
-    if (sz[t] <= 128) { ret = bc_np_sum_const_leaf(c, sz[t]); --sp; continue; }
-    int n2 = sz[t] >> 1;
-    n2 -= n2 & 7;
-    if (stage[t] == 0) { stage[t] = 1; sz[sp] = n2; stage[sp] = 0; ++sp; }
-    else if (stage[t] == 1) { left[t] = ret; stage[t] = 2; sz[sp] = sz[t] - n2; stage[sp] = 0; ++sp; }
-    else { ret = left[t] + ret; --sp; }
-  }
-  return ret;
-}
+#include "bc_np_sum.h"   // bc_np_sum_const_*: NumPy's pairwise sum of n equal numbers (the mean of a constant row)
 
 // element (row r, sample k) of a tiled Phi
 __device__ __forceinline__ size_t bc_tile_off(long long r, int k, int s) {

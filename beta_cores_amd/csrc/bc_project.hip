@@ -1062,7 +1062,13 @@ static int launch_project_r_nt(bc_ctx* ctx, const ProjArgs& a, int grid, int nts
   switch (ntsel) {
     case 4: return launch_project_r<MODEL, 4, 0, STORE>(ctx, a, grid);
     case 6: return launch_project_r<MODEL, 6, 4, STORE>(ctx, a, grid);
-    default: return launch_project_r<MODEL, 7, 0, STORE>(ctx, a, grid);
+    default:
+      if constexpr (bc_model_has_np_exp<MODEL>()) {      // not instantiated (would spill), never selected (project_r_grid)
+        bc_set_error("bc_project: internal: no resident kernel for this model at S in 101..112");
+        return BC_INVALID_ARGUMENT;
+      } else {
+        return launch_project_r<MODEL, 7, 0, STORE>(ctx, a, grid);
+      }
   }
 }
 
@@ -1186,10 +1192,15 @@ static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, co
 // The resident kernel serves large shards whose Theta fits one CU's LDS next to the per-wave scratch: at least 8 tiles
 // per wave slot of the grid (tile_part then has room for the per-wave partial rows, and the grid is full), S <= 112.
 // BC_K1_STAGED=1 forces the staged kernel (A/B measurements).
+static bool bc_model_has_np_exp_rt(int model) { return model == BC_MODEL_LINREG_BETA || model == BC_MODEL_GAUSS_BETA || model == BC_MODEL_GAUSS_BETA_GRAD; }
+
 static int project_r_grid(const bc_ctx* ctx, const ProjPlan& pl, const bc_phi* phi, int mode) {
   const char* env = getenv("BC_K1_STAGED");          // read per call: tests toggle it inside one process
   if ((env && atoi(env) > 0) || mode == PROJ_RAW) return 0;
   if (pl.ntsel != 4 && pl.ntsel != 6 && pl.ntsel != 7) return 0;
+  // S in 101..112 with an exp in the epilogue: those three instantiations need 4-6 VGPRs more than the 256 a wave of a
+  // 512-thread block may hold (they would spill): the staged kernel serves them
+  if (pl.ntsel == 7 && bc_model_has_np_exp_rt(pl.model)) return 0;
   if (pl.model == BC_MODEL_LOGISTIC_BETA && !(env && atoi(env) < 0)) return 0;      // measured slower there (0.80 vs 0.74 ms at N = 1M, D = 128): four
                                                                                        // transcendental bodies per element; BC_K1_STAGED=-1 forces the resident kernel
   const int nr = pl.ntsel * 16 + (pl.ntsel == 6 ? 4 : 0);
