@@ -98,6 +98,7 @@ extern "C" int bc_ctx_destroy(bc_ctx* ctx) {
   for (bc_scratch* sc : all)
     if (sc->p) (void)hipFree(sc->p);
   if (ctx->proj_pinned) (void)hipHostFree(ctx->proj_pinned);
+  if (ctx->vi_pinned) (void)hipHostFree(ctx->vi_pinned);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -66,6 +66,7 @@ struct bc_ctx {
   int64_t vi_pending_m = 0;      // bc_vi_gradient_begin enqueued a gradient of this many rows (bc_vi_gradient_end fetches it)
   int32_t vi_pending_s = 0;
   bool vi_pending_timed = false;
+  double* vi_pinned = nullptr;   // pinned landing area of the pending gradient
 };
 
 int bc_scratch_grow(bc_ctx* ctx, bc_scratch* s, size_t doubles);   // contents are NOT kept when it grows

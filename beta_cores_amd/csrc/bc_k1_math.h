@@ -36,11 +36,20 @@
 // exp(x) for |x| <= 2e4 (beyond 745 / 709 the result is 0 / +inf through ldexp); a NaN gives a NaN.  No clamps: the
 // callers bound their arguments once per element instead of twice per exp (a compare-and-select pair on doubles is
 // four instructions).
+BC_KM unsigned bc_k1_lo32(double d) {
+  uint64_t u;
+  memcpy(&u, &d, 8);
+  return (unsigned)u;
+}
+
 BC_KM double bc_exp_tab_core(double x, const double* tab) {
-  const double kd = rint(x * 92.33248261689366);       // 64 / ln 2
+  // z = x * 64/ln2 + 1.5 * 2^52: one rounding puts the nearest integer k in the low mantissa bits (two's complement in
+  // the low 32 for |k| < 2^31, i.e. |x| < 2e7) -- no v_rndne, no v_cvt: the integer IS the low register of z
+  const double z = fma(x, 92.33248261689366, 6755399441055744.);
+  const double kd = z - 6755399441055744.;
   double r = fma(-kd, 0.010830424695086549, x);        // ln2/64, high 32 bits: kd * hi is exact for |kd| < 2^21
   r = fma(-kd, 1.162596423439437e-12, r);              // ln2/64, low part
-  const int ki = (int)kd;
+  const int ki = (int)bc_k1_lo32(z);
   const int j = ki & 63, e = ki >> 6;                  // ki = 64 e + j, j in 0..63 (arithmetic shift)
   double p = fma(r, 1. / 120., 1. / 24.);
   p = fma(p, r, 1. / 6.);
@@ -48,6 +57,13 @@ BC_KM double bc_exp_tab_core(double x, const double* tab) {
   p = fma(p, r * r, r);                                // exp(r) - 1
   const double t = tab[j];
   return ldexp(fma(t, p, t), e);
+}
+
+// exp(x) for x <= 0 up to rounding (the beta-likelihoods' exp(-b q), q >= 0): only the lower bound needs a clamp, and
+// the comparison is written so that a NaN passes through it (three instructions instead of five)
+BC_KM double bc_exp_tab_nonpos(double x, const double* tab) {
+  const double xc = !(x < -800.) ? x : -800.;
+  return bc_exp_tab_core(xc, tab);
 }
 
 // exp(x) for any x (NaN in, NaN out)
@@ -62,8 +78,9 @@ BC_KM double bc_log1p_exp_neg_tab(double a, const double* tab) {
   const double u = bc_exp_tab_core(-a, tab);
   const double f = 1. + u;
   const double fm1 = f - 1.;                           // exact
-  int i = (int)fma(fm1, 256., 0.5);                    // nearest c_i = 1 + i/256, i in 0..256
-  i = (i < 0) ? 0 : ((i > 256) ? 256 : i);             // (a NaN converts to an arbitrary int: keep the index in range)
+  // nearest c_i = 1 + i/256, i in 0..256, from the low mantissa bits of fm1 * 256 + 1.5 * 2^52 (fm1 in [0, 1]; the mask
+  // only keeps a NaN's arbitrary bits inside the LDS allocation -- the result is a NaN either way)
+  const int i = (int)(bc_k1_lo32(fma(fm1, 256., 6755399441055744.)) & 511u);
   const double rc = tab[BC_K1_EXP_N + 2 * i], lc = tab[BC_K1_EXP_N + 2 * i + 1];
   const double t = fma(f, rc, -1.);
   double q = fma(t, -1. / 6., 1. / 5.);

@@ -109,7 +109,7 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
     }
     case BC_MODEL_LINREG_BETA: {          // k0*(k1*exp(k2*q) + k3)
       const double q = (ra * ra - p * (2. * ra)) + p * p;
-      return c[0] * (c[1] * bc_exp_tab(c[2] * q, tab) + c[3]);
+      return c[0] * (c[1] * bc_exp_tab_nonpos(c[2] * q, tab) + c[3]);
     }
     case BC_MODEL_LOGISTIC_LL: {          // m = -z.th ; m < 100 ? -log1p(exp(m)) : -m ;  log1p(e^m) = max(m, 0) + log1p(e^-|m|)
       const double m = -p;
@@ -124,11 +124,11 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
     }
     case BC_MODEL_GAUSS_BETA: {           // 1/b*exp(-.5*b*q) - (1+b)^(-.5d-1)
       const double q = (ra + sa) - 2. * p;
-      return c[0] * bc_exp_tab(c[1] * q, tab) - c[2];
+      return c[0] * bc_exp_tab_nonpos(c[1] * q, tab) - c[2];
     }
     default: {                            // BC_MODEL_GAUSS_BETA_GRAD, gaussian.py:46-62
       const double q = (ra + sa) - 2. * p;
-      const double gq = bc_exp_tab(c[1] * q, tab);
+      const double gq = bc_exp_tab_nonpos(c[1] * q, tab);
       const double t1 = c[3] * (c[0] * gq - c[2]);
       const double t2 = c[4] * gq;
       const double t3 = c[5] * q * gq;
@@ -1417,6 +1417,7 @@ extern "C" int bc_vi_gradient_begin(bc_ctx* ctx, const bc_data* data, const doub
   if (comm && bc_comm_ctx(comm) != ctx) { bc_set_error("bc_vi_gradient: the communicator belongs to another context"); return BC_INVALID_ARGUMENT; }
   const int dz = data->dz;
   const size_t n_core = (size_t)m * dz, n_down = (size_t)m + (size_t)s;
+  if (ctx->vi_pending_m > 0) { bc_set_error("bc_vi_gradient_begin: a gradient is already pending on this context (call bc_vi_gradient_end first)"); return BC_INVALID_ARGUMENT; }
   if (n_down > ctx->pinned_doubles) {
     bc_set_error("bc_vi_gradient: coreset of %lld rows x %d exceeds the staging area", (long long)m, dz);
     return BC_INVALID_ARGUMENT;
@@ -1490,7 +1491,10 @@ extern "C" int bc_vi_gradient_begin(bc_ctx* ctx, const bc_data* data, const doub
   hipLaunchKernelGGL(k_vi_gradient, dim3(1), dim3(256), (size_t)s * sizeof(double), ctx->stream, colsum, cphi->tiles, d_w,
                      (int)m, s, sum_scaling, d_resid, d_grad);
   BC_HIP(hipGetLastError());
-  BC_HIP(hipMemcpyAsync(ctx->pinned, d_grad, n_down * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  // the result lands in a pinned area of its own: whatever the host does between _begin and _end (it may well call into this
+  // library, whose other entry points stage through ctx->pinned) cannot overwrite it
+  if (!ctx->vi_pinned) BC_HIP(hipHostMalloc((void**)&ctx->vi_pinned, ctx->pinned_doubles * sizeof(double), hipHostMallocDefault));
+  BC_HIP(hipMemcpyAsync(ctx->vi_pinned, d_grad, n_down * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   rc = mark(5);
   if (rc) return rc;
   ctx->vi_pending_m = m;
@@ -1510,8 +1514,8 @@ extern "C" int bc_vi_gradient_end(bc_ctx* ctx, double* out_grad, double* out_res
   ctx->vi_pending_m = 0;
   BC_HIP(hipSetDevice(ctx->device));
   BC_HIP(hipStreamSynchronize(ctx->stream));
-  memcpy(out_grad, ctx->pinned, (size_t)m * sizeof(double));
-  if (out_resid) memcpy(out_resid, ctx->pinned + m, (size_t)s * sizeof(double));
+  memcpy(out_grad, ctx->vi_pinned, (size_t)m * sizeof(double));
+  if (out_resid) memcpy(out_resid, ctx->vi_pinned + m, (size_t)s * sizeof(double));
   if (timed) {
     for (int i = 0; i < BC_VI_PHASES; ++i) {
       float ms = 0.f;

@@ -11,6 +11,14 @@ import numpy as np
 LINREG_LL, LINREG_BETA, LOGISTIC_LL, LOGISTIC_BETA, GAUSS_LL, GAUSS_BETA, GAUSS_BETA_GRAD = range(7)
 
 
+def _checked_beta(beta):
+    """The device bodies evaluate exp(-b q) with a clamp for large NEGATIVE arguments only (q >= 0): b < 0 is refused."""
+    beta = float(beta)
+    if beta < 0.:
+        raise ValueError('beta must be >= 0 for the device beta-likelihoods (got %r)' % beta)
+    return beta
+
+
 class _Model:
     model_id = None
     beta_model_id = None
@@ -35,7 +43,7 @@ class LinearRegression(_Model):
         self.sigsq = float(sigsq)
 
     def params(self, beta=None, grad=False):
-        return np.array([self.sigsq] if beta is None else [self.sigsq, float(beta)])
+        return np.array([self.sigsq] if beta is None else [self.sigsq, _checked_beta(beta)])
 
     def data_width(self, theta_dim):
         return theta_dim + 1
@@ -48,7 +56,7 @@ class LogisticRegression(_Model):
     beta_model_id = LOGISTIC_BETA
 
     def params(self, beta=None, grad=False):
-        return np.array([] if beta is None else [float(beta)])
+        return np.array([] if beta is None else [_checked_beta(beta)])
 
     def data_width(self, theta_dim):
         return theta_dim
@@ -67,7 +75,7 @@ class GaussianLocation(_Model):
         self.logdetSig = float(logdetSig)
 
     def params(self, beta=None, grad=False):
-        head = [self.logdetSig] if beta is None else [float(beta), self.logdetSig]
+        head = [self.logdetSig] if beta is None else [_checked_beta(beta), self.logdetSig]
         return np.concatenate((np.array(head), self.Siginv.ravel()))
 
     def theta_for_device(self, samples):

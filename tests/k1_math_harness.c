@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
   ok &= isnan(bc_exp_tab(NAN, tab));
   ok &= isnan(bc_log1p_exp_neg_tab(NAN, tab));
   ok &= bc_log1p_exp_neg_tab(800.0, tab) == 0.0;
+  ok &= bc_exp_tab_nonpos(-1e300, tab) == 0.0 && isnan(bc_exp_tab_nonpos(NAN, tab)) && bc_exp_tab_nonpos(0.0, tab) == 1.0 && bc_exp_tab_nonpos(-INFINITY, tab) == 0.0;
   ok &= bc_log1p_exp_neg_tab(20000.0, tab) == 0.0;
   ok &= bc_exp_tab(-1e300, tab) == 0.0 && isinf(bc_exp_tab(1e300, tab)) && bc_exp_tab(-INFINITY, tab) == 0.0;
   ok &= bc_log1p_exp_neg_tab(50.0, tab) == exp(-50.0) || fabs(bc_log1p_exp_neg_tab(50.0, tab) / exp(-50.0) - 1.0) < 4e-16;
