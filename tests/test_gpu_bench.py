@@ -40,6 +40,16 @@ def test_bench_line_contract():
     assert c['kind'] == 'port' and c['parity_on_sample'].startswith('ok')
     assert abs(d['value'] - 1e3 / d['ms_per_step']) < 1e-6 * d['value']
     assert d['config']['sweep'].startswith('int8') and d['prefilter']['fp64_fallbacks'] == 0
+    # round 3: the beta-Cores gradient loop, the per-stage split of a step, the parts of solver_init, honest K4 numbers
+    legs = [e for e in d['beta_coreset'] if 'ms_per_gradient' in e]
+    assert len(legs) == 4 and all(e['ms_per_gradient'] > 0 and 0 < e['roofline_hbm']['frac'] < 1 and 0 < e['roofline_fp64_mfma']['frac'] < 1
+                                  and e['native_gradient_calls'] == e['gradients'] for e in legs)
+    assert any('cpu_baseline' in e for e in d['beta_coreset'])
+    st = d['step_stages']
+    assert st['transport'].startswith('none') and any(k.startswith('stage_ms') for k in st)
+    assert abs(sum(d['solver_init'].values()) - d['solver_init_ms']) <= 0.05 * d['solver_init_ms'] + 0.5
+    k4 = [e['posterior_gram_K4'] for e in d['other_configs'] if 'posterior_gram_K4' in e][0]
+    assert all(0 < v['frac_of_fp64_mfma_peak'] < 1 and v['symmetry_factor'] > 1.5 for v in k4.values())
 
 
 def test_bench_sweep_modes_agree():
