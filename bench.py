@@ -132,15 +132,19 @@ def fp64_sweep_leg(bc, ctx, alg, cls, barrier, n_local, S, args):
 
 
 def k4_entry(n, d, ms):
-    """K4 numbers that cannot exceed 1: the kernel computes the upper-triangular BT x BT tiles only (bc_gram.hip), so the
-    matrix pipe executes  tiles * 2*N*BT^2  flop, not the 2*N*(D+1)^2 of the full Gram matrix; `ms` covers the Gram kernel
-    AND its two-level split-order reduction (bc_timer brackets all three launches)."""
+    """K4 numbers that cannot exceed 1: the kernel computes the upper-triangular BT x BT tiles only, and of a DIAGONAL tile
+    only the 16 x 16 MFMA sub-tiles on or above its diagonal (bc_gram.hip: 36 of 64 at BT = 128, 10 of 16 at BT = 64), so the
+    matrix pipe executes  (off-diagonal tiles + diagonal tiles * 36/64) * 2*N*BT^2  flop, not the 2*N*(D+1)^2 of the full Gram
+    matrix; `ms` covers the Gram kernel AND its two-level split-order reduction (bc_timer brackets all three launches)."""
     bt = 128 if d > 64 else 64
     nt = -(-d // bt)
     ntri = nt * (nt + 1) // 2
-    executed = 2.0 * n * ntri * bt * bt
+    ns = bt // 16
+    diag_share = (ns * (ns + 1) // 2) / float(ns * ns)
+    executed = 2.0 * n * bt * bt * ((ntri - nt) + nt * diag_share)
     full = 2.0 * n * (d + 1) * (d + 1)
     return {'kernel_ms (gram + reduce)': ms, 'tile': bt, 'tiles_computed': ntri, 'tiles_full_square': nt * nt,
+            'diagonal_tiles': nt, 'mfma_subtiles_per_diagonal_tile': '%d of %d' % (ns * (ns + 1) // 2, ns * ns),
             'executed_tflops': executed / (ms * 1e-3) / 1e12,
             'frac_of_fp64_mfma_peak': executed / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
             'symmetry_factor': full / executed,

@@ -28,47 +28,92 @@ struct GramArgs {
   int ntri;               // nt*(nt+1)/2
 };
 
-template <int BT>
-__global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
-  constexpr int KR = 16;                 // rows per LDS slab
+// A DIAGONAL tile (ta == tb) is symmetric itself: of its (BT/16)^2 MFMA sub-tiles only those on or above the diagonal are
+// needed -- 36 of 64 at BT = 128, 10 of 16 at BT = 64.  They are dealt to the four waves 9 / 9 / 9 / 9 (3 / 2 / 2 / 3) so that each
+// wave's set touches few distinct 16-column strips of the two LDS panels (8 or 7 ds_reads per k-step, as many as the square
+// wave tile needs for 16 MFMAs).  At D <= 128 the whole Gram matrix is ONE diagonal tile: 9 MFMAs per wave and k-step instead of 16.
+template <int BT, int W> struct GramDiag;
+template <> struct GramDiag<128, 0> { static constexpr int n = 9; static constexpr int x[9] = {0, 0, 0, 1, 1, 1, 2, 2, 3}; static constexpr int y[9] = {0, 1, 2, 1, 2, 3, 2, 3, 3}; };
+template <> struct GramDiag<128, 1> { static constexpr int n = 9; static constexpr int x[9] = {0, 0, 0, 0, 0, 1, 1, 1, 1}; static constexpr int y[9] = {3, 4, 5, 6, 7, 4, 5, 6, 7}; };
+template <> struct GramDiag<128, 2> { static constexpr int n = 9; static constexpr int x[9] = {2, 2, 2, 2, 3, 3, 3, 3, 4}; static constexpr int y[9] = {4, 5, 6, 7, 4, 5, 6, 7, 7}; };
+template <> struct GramDiag<128, 3> { static constexpr int n = 9; static constexpr int x[9] = {4, 4, 4, 5, 5, 5, 6, 6, 7}; static constexpr int y[9] = {4, 5, 6, 5, 6, 7, 6, 7, 7}; };
+template <> struct GramDiag<64, 0> { static constexpr int n = 3; static constexpr int x[3] = {0, 0, 1}; static constexpr int y[3] = {0, 1, 1}; };
+template <> struct GramDiag<64, 1> { static constexpr int n = 2; static constexpr int x[3] = {0, 0, 0}; static constexpr int y[3] = {2, 3, 3}; };
+template <> struct GramDiag<64, 2> { static constexpr int n = 2; static constexpr int x[3] = {1, 1, 1}; static constexpr int y[3] = {2, 3, 3}; };
+template <> struct GramDiag<64, 3> { static constexpr int n = 3; static constexpr int x[3] = {2, 2, 3}; static constexpr int y[3] = {2, 3, 3}; };
+
+// one k-step (4 rows of the slab) of wave W's share of a diagonal tile, in two halves so that the fragments of the NEXT
+// k-step can be requested from LDS before the MFMAs of the current one are issued; acc[i] belongs to sub-tile (x[i], y[i])
+template <int BT, int W>
+__device__ __forceinline__ void gram_diag_frags(const double* __restrict__ Arow, const double* __restrict__ Brow, int j,
+                                                double (&fa)[BT / 16], double (&fb)[BT / 16]) {
+  using M = GramDiag<BT, W>;
+  constexpr int NS = BT / 16;
+  unsigned mx = 0, my = 0;
+#pragma unroll
+  for (int i = 0; i < M::n; ++i) { mx |= 1u << M::x[i]; my |= 1u << M::y[i]; }
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    fa[c] = 0.;
+    fb[c] = 0.;
+    if ((mx >> c) & 1u) fa[c] = Arow[c * 16 + j];
+    if ((my >> c) & 1u) fb[c] = Brow[c * 16 + j];
+  }
+}
+template <int BT, int W, int NA>
+__device__ __forceinline__ void gram_diag_mma(const double (&fa)[BT / 16], const double (&fb)[BT / 16], double4_t (&acc)[NA]) {
+  using M = GramDiag<BT, W>;
+#pragma unroll
+  for (int i = 0; i < M::n; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[M::x[i]], fb[M::y[i]], acc[i], 0, 0, 0);
+}
+
+template <int BT, int W, int NA>
+__device__ __forceinline__ void gram_diag_store(double* __restrict__ out, int g, int j, const double4_t (&acc)[NA]) {
+  using M = GramDiag<BT, W>;
+#pragma unroll
+  for (int i = 0; i < M::n; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[(size_t)(M::x[i] * 16 + g + 4 * reg) * BT + M::y[i] * 16 + j] = acc[i][reg];
+}
+
+__device__ const double g_gram_ones[16] = {1., 1., 1., 1., 1., 1., 1., 1., 1., 1., 1., 1., 1., 1., 1., 1.};
+
+// One (split, tile) of the Gram matrix.  V = -1: off-diagonal tile, every wave a square BT/2 x BT/2 wave tile; V = 0..3: diagonal
+// tile, wave V's share of its upper triangle (GramDiag).  The variant is block- (V < 0) or wave-uniform, chosen by a scalar
+// branch in k_gram; every variant passes the same barriers.
+template <int BT, int V>
+__device__ __forceinline__ void gram_tile(const GramArgs& a, int ta, int tb, long long split, int tri, double* __restrict__ Al,
+                                          double* __restrict__ Bl, double* __restrict__ Yl) {
+  constexpr int KR = BT == 64 ? 32 : 16; // rows per LDS slab (BT = 64: three MFMAs per wave and k-step at most -- twice the rows per barrier pair)
   constexpr int LDX = BT + 16;           // row stride == 16 (mod 32) doubles: conflict-free 2-row x 16-col reads
   constexpr int MT = BT / 32;            // MFMA tiles per wave per dimension (wave tile = BT/2 x BT/2)
   constexpr int LP = (KR * BT) / 256;    // 8-byte loads per thread per panel per slab
-  __shared__ double Al[KR * LDX];
-  __shared__ double Bl[KR * LDX];
-  __shared__ double Yl[256];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr bool diag = V >= 0;          // the diagonal block of a column panel also owns its X^T (w*y) slice
+  constexpr int NA = diag ? GramDiag<BT, diag ? V : 0>::n : MT * MT;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
-  const int wa = wv >> 1, wb = wv & 1;   // wave position inside the block tile
-  // XCD-aware block -> (split, tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
-  // one, each XCD has its own L2), and the ntri tiles of one row split all read the same rows: they are given block
-  // numbers that are equal modulo 8 and adjacent in that XCD's queue, so the rows are fetched from HBM once per split
-  // instead of once per tile (D = 512: ten tiles per split; with the tiles of a split on neighbouring block numbers,
-  // i.e. on ten different XCDs, the kernel ran 13.5 ms instead of 12.85 at eight rounds of blocks, 19.8 instead of 18.6 at one).
-  const long long q = blockIdx.x >> 3;
-  const int tri = (int)(q % a.ntri);
-  const long long split = (q / a.ntri) * 8 + (blockIdx.x & 7);
-  if (split >= a.splits) return;
-  int ta = 0, rem = tri;                 // tri -> (ta <= tb)
-  while (rem >= a.nt - ta) { rem -= a.nt - ta; ++ta; }
-  const int tb = ta + rem;
+  const int wa = V < 0 ? (tid >> 7) : 0, wb = V < 0 ? ((tid >> 6) & 1) : 0;   // wave position inside an off-diagonal block tile
   const int a0 = ta * BT, b0 = tb * BT;
   const long long r_begin = split * a.rows_per_split;
   long long r_end = r_begin + a.rows_per_split;
   if (r_end > a.n_rows) r_end = a.n_rows;
 
-  double4_t acc[MT][MT];
+  double4_t acc[NA];
 #pragma unroll
-  for (int x = 0; x < MT; ++x)
-#pragma unroll
-    for (int y = 0; y < MT; ++y) acc[x][y] = (double4_t){0., 0., 0., 0.};
+  for (int x = 0; x < NA; ++x) acc[x] = (double4_t){0., 0., 0., 0.};
 
   // staging map: thread -> (row lr = idx / BT, col lc = idx % BT) of the slab, LP passes
   const int lc = tid % BT, lr0 = tid / BT;
   constexpr int RPP = 256 / BT;          // rows covered per pass
-  const bool a_ok = a0 + lc < a.d, b_ok = b0 + lc < a.d;
-  const int ca = a_ok ? a0 + lc : 0, cb = b_ok ? b0 + lc : 0;
-  const bool diag = ta == tb;            // the diagonal block of a column panel also owns its X^T (w*y) slice
+  // Every VALU instruction of the staging code adds to the kernel time (an fp64 MFMA wave owns its SIMD's issue,
+  // profiles/r02_notes.md), so nothing is selected or compared per element: columns past d (the zero padding of the last
+  // tile) are read through an offset the descriptor's range check rejects, rows past the end likewise (z AND w: both
+  // descriptors end at the last row), and a rejected load returns 0.
+  constexpr int OOB = 0x40000000;
+  const int oa = a0 + lc < a.d ? (lr0 * a.dz + a0 + lc) * 8 : OOB;
+  const int ob = b0 + lc < a.d ? (lr0 * a.dz + b0 + lc) * 8 : OOB;
+  const int oy = (lr0 * a.dz + a.d) * 8;
+  const bool weighted = a.w != nullptr;
   double vy = 0.0;
   // raw values of the slab in flight; the weighting and the X^T (w*y) term are applied when the slab is parked in LDS,
   // so that the loads can be requested in slices spread over the previous slab's k-steps (requested in one go after the
@@ -78,26 +123,29 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   static_assert(LP % NSL == 0 || LP < NSL, "slices");
   auto load_part = [&](long long r0, int part) {
     const long long left = r_end - r0;
-    const long long rows_here = left < KR ? (left > 0 ? left : 0) : KR;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0, (int)(rows_here * a.dz * 8), 0x00020000);
+    const int rows_here = left < KR ? (left > 0 ? (int)left : 0) : KR;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)r0 * a.dz), 0, rows_here * a.dz * 8, 0x00020000);
+    // (no weights: sixteen ones stand in for them -- a base pointer chosen by the scalar unit, no branch and no constant moves)
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(weighted ? a.w + r0 : g_gram_ones), 0, rows_here * 8, 0x00020000);
 #pragma unroll
     for (int q = part * LP / NSL; q < (part + 1) * LP / NSL; ++q) {
-      const int lr = lr0 + q * RPP;
-      vw[q] = 1.0;
-      if (a.w) vw[q] = (r0 + lr < r_end) ? a.w[r0 + lr] : 0.0;
-      va[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + ca) * 8, 0, 0));
-      vb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + cb) * 8, 0, 0));
-      vyv[q] = 0.;
-      if (diag) vyv[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (lr * a.dz + a.d) * 8, 0, 0));
+      vw[q] = 1.0;    // (BT = 64 is bound by its loads, not by the matrix pipe: no stand-in loads there)
+      if (BT == 128 || weighted) vw[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rw, (lr0 + q * RPP) * 8, 0, 0));
+      va[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, oa + q * RPP * a.dz * 8, 0, 0));
+      if (diag) {                          // both panels are the same columns: one load
+        vyv[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, oy + q * RPP * a.dz * 8, 0, 0));
+      } else {
+        vb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, ob + q * RPP * a.dz * 8, 0, 0));
+      }
     }
   };
   auto store_slab = [&]() {
 #pragma unroll
     for (int q = 0; q < LP; ++q) {
       const int lr = lr0 + q * RPP;
-      const double raq = a_ok ? vw[q] * va[q] : 0.0;     // A panel carries the weights: (w[:,None]*X)
+      const double raq = vw[q] * va[q];                  // A panel carries the weights: (w[:,None]*X)
       Al[lr * LDX + lc] = raq;
-      Bl[lr * LDX + lc] = b_ok ? vb[q] : 0.0;
+      Bl[lr * LDX + lc] = diag ? va[q] : vb[q];
       if (diag) vy = fma(raq, vyv[q], vy);               // (w[:,None]*Y[:,None]*X).sum(axis=0), model_linreg.py:31
     }
   };
@@ -110,18 +158,35 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     store_slab();
     __syncthreads();
     const bool more = r0 + KR < r_end;
+    // fragments of k-step kk + 1 are requested before the MFMAs of k-step kk are issued
+    constexpr int NF = diag ? BT / 16 : MT;
+    double fa[2][NF], fb[2][NF];
+    auto frags = [&](int kk, double (&xa)[NF], double (&xb)[NF]) {
+      const double* Arow = Al + (kk * 4 + g) * LDX;
+      const double* Brow = Bl + (kk * 4 + g) * LDX;
+      if constexpr (diag) {
+        gram_diag_frags<BT, V>(Arow, Brow, j, xa, xb);
+      } else {
+#pragma unroll
+        for (int x = 0; x < MT; ++x) xa[x] = Arow[wa * (BT / 2) + x * 16 + j];
+#pragma unroll
+        for (int y = 0; y < MT; ++y) xb[y] = Brow[wb * (BT / 2) + y * 16 + j];
+      }
+    };
+    frags(0, fa[0], fb[0]);
 #pragma unroll
     for (int kk = 0; kk < KR / 4; ++kk) {
       if (more) load_part(r0 + KR, kk);
-      double fa[MT], fb[MT];
+      if (kk + 1 < KR / 4) frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+      if constexpr (diag) {
+        gram_diag_mma<BT, V>(fa[kk & 1], fb[kk & 1], acc);
+      } else {
 #pragma unroll
-      for (int x = 0; x < MT; ++x) fa[x] = Al[(kk * 4 + g) * LDX + wa * (BT / 2) + x * 16 + j];
+        for (int x = 0; x < MT; ++x)
 #pragma unroll
-      for (int y = 0; y < MT; ++y) fb[y] = Bl[(kk * 4 + g) * LDX + wb * (BT / 2) + y * 16 + j];
-#pragma unroll
-      for (int x = 0; x < MT; ++x)
-#pragma unroll
-        for (int y = 0; y < MT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[x], fb[y], acc[x][y], 0, 0, 0);
+          for (int y = 0; y < MT; ++y)
+            acc[x * MT + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][x], fb[kk & 1][y], acc[x * MT + y], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);     // keeps each slice of loads with its k-step
     }
     __syncthreads();
@@ -138,16 +203,46 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
   double* out = a.partial + ((size_t)split * a.ntri + tri) * BT * BT;
+  if constexpr (diag) {                  // sub-tiles below the diagonal are neither computed nor written (nor read: k_gram_reduce*)
+    gram_diag_store<BT, V>(out, g, j, acc);
+  } else {
 #pragma unroll
-  for (int x = 0; x < MT; ++x)
+    for (int x = 0; x < MT; ++x)
 #pragma unroll
-    for (int y = 0; y < MT; ++y)
+      for (int y = 0; y < MT; ++y)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = wa * (BT / 2) + x * 16 + g + 4 * reg;
-        const int col = wb * (BT / 2) + y * 16 + j;
-        out[(size_t)row * BT + col] = acc[x][y][reg];
-      }
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = wa * (BT / 2) + x * 16 + g + 4 * reg;
+          const int col = wb * (BT / 2) + y * 16 + j;
+          out[(size_t)row * BT + col] = acc[x * MT + y][reg];
+        }
+  }
+}
+
+template <int BT>
+__global__ __launch_bounds__(256, BT == 64 ? 3 : 2) void k_gram(GramArgs a) {
+  __shared__ double Al[(BT == 64 ? 32 : 16) * (BT + 16)];
+  __shared__ double Bl[(BT == 64 ? 32 : 16) * (BT + 16)];
+  __shared__ double Yl[256];
+  // XCD-aware block -> (split, tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+  // one, each XCD has its own L2), and the ntri tiles of one row split all read the same rows: they are given block
+  // numbers that are equal modulo 8 and adjacent in that XCD's queue, so the rows are fetched from HBM once per split
+  // instead of once per tile (D = 512: ten tiles per split; with the tiles of a split on neighbouring block numbers,
+  // i.e. on ten different XCDs, the kernel ran 13.5 ms instead of 12.85 at eight rounds of blocks, 19.8 instead of 18.6 at one).
+  const long long q = blockIdx.x >> 3;
+  const int tri = (int)(q % a.ntri);
+  const long long split = (q / a.ntri) * 8 + (blockIdx.x & 7);
+  if (split >= a.splits) return;
+  int ta = 0, rem = tri;                 // tri -> (ta <= tb)
+  while (rem >= a.nt - ta) { rem -= a.nt - ta; ++ta; }
+  const int tb = ta + rem;
+  if (ta != tb) { gram_tile<BT, -1>(a, ta, tb, split, tri, Al, Bl, Yl); return; }
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {     // (scalar branch: one variant per wave)
+    case 0: gram_tile<BT, 0>(a, ta, tb, split, tri, Al, Bl, Yl); break;
+    case 1: gram_tile<BT, 1>(a, ta, tb, split, tri, Al, Bl, Yl); break;
+    case 2: gram_tile<BT, 2>(a, ta, tb, split, tri, Al, Bl, Yl); break;
+    default: gram_tile<BT, 3>(a, ta, tb, split, tri, Al, Bl, Yl); break;
+  }
 }
 
 // Sum of the per-split partial tiles IN SPLIT ORDER, in two levels so that it is parallel: level 1 adds runs of SEG
@@ -157,10 +252,17 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
 // D = 128, 13 % on top of the Gram kernel itself.)
 #define BC_GRAM_SEG 16
 __global__ __launch_bounds__(256) void k_gram_reduce1(const double* __restrict__ partial, long long splits, long long nruns,
-                                                     size_t tile_elems /* ntri*bt*bt */, double* __restrict__ part2) {
+                                                     size_t tile_elems /* ntri*bt*bt */, int nt, int bt, double* __restrict__ part2) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const long long run = blockIdx.y;
   if (e >= tile_elems) return;
+  {
+    // sub-tiles below the diagonal of a diagonal tile were never written (k_gram) and are never read (k_gram_reduce2)
+    const int tri = (int)(e / ((size_t)bt * bt)), ee = (int)(e % ((size_t)bt * bt));
+    int ta = 0, rem = tri;
+    while (rem >= nt - ta) { rem -= nt - ta; ++ta; }
+    if (rem == 0 && (ee / bt) / 16 > (ee % bt) / 16) return;
+  }
   const long long s0 = run * BC_GRAM_SEG;
   long long s1 = s0 + BC_GRAM_SEG;
   if (s1 > splits) s1 = splits;
@@ -218,7 +320,7 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   const int dz = data->dz, d = dz - 1;
   const int nt = (d + BT - 1) / BT;
   const int ntri = nt * (nt + 1) / 2;
-  const int KR = 16;
+  const int KR = BT == 64 ? 32 : 16;
   // Row splits, in units of the 2 * n_cu resident block slots (BC_GRAM_WAVES overrides), at least 2 slabs per split.
   // One tile (D <= 128): exactly one block per slot -- every further split writes, and the reduction reads back, another
   // 128 KB tile (8 per slot were 268 MB of partials at N = 10M, D = 128: 6.06 ms with one, 7.76 ms with eight).  Several
@@ -227,7 +329,8 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   // shared rows are fetched again; static priorities or a start stagger change nothing (profiles/r03_notes.md).
   static const int waves_env = getenv("BC_GRAM_WAVES") ? atoi(getenv("BC_GRAM_WAVES")) : 0;
   const int waves = waves_env > 0 ? waves_env : (ntri == 1 ? 1 : 8);
-  long long want_splits = ((long long)ctx->n_cu * 2 * (waves > 0 ? waves : 1) + ntri - 1) / ntri;
+  const int slots = BT == 64 ? 3 : 2;      // resident blocks per CU (k_gram's launch bounds)
+  long long want_splits = ((long long)ctx->n_cu * slots * (waves > 0 ? waves : 1) + ntri - 1) / ntri;
   long long max_splits = (data->n_rows + 2 * KR - 1) / (2 * KR);
   long long splits = want_splits < max_splits ? want_splits : max_splits;
   if (splits < 1) splits = 1;
@@ -265,7 +368,7 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   if (!rc && e == hipSuccess) {
     double* part2 = partial + (size_t)splits * tile_elems;
     hipLaunchKernelGGL(k_gram_reduce1, dim3((unsigned)((tile_elems + 255) / 256), (unsigned)nruns), dim3(256), 0, ctx->stream, partial, splits,
-                       nruns, tile_elems, part2);
+                       nruns, tile_elems, nt, BT, part2);
     hipLaunchKernelGGL(k_gram_reduce2, dim3(ntri, (BT * BT + 255) / 256), dim3(256), 0, ctx->stream, part2, partial_y, splits, nruns, ntri,
                        nt, BT, d, out_dev, outy_dev);
     e = hipGetLastError();

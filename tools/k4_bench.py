@@ -16,7 +16,8 @@ for (N, D) in [(2_000_000, 512), (10_000_000, 128), (4_000_000, 64)]:
     wall = (time.perf_counter() - t0) / 3
     ms, n = ctx.kernel_time(2); ms /= n
     bt = 128 if D > 64 else 64; nt = -(-D // bt); ntri = nt * (nt + 1) // 2
-    fl = 2. * N * ntri * bt * bt
+    ns = bt // 16                                     # diagonal tiles: sub-tiles on or above the diagonal only
+    fl = 2. * N * bt * bt * ((ntri - nt) + nt * (ns * (ns + 1) // 2) / (ns * ns))
     print('gram N=%d D=%d: gram+reduce %.3f ms (wall %.1f ms)  executed %.1f TF = %.3f of 78.6  %.0f GB/s' % (N, D, ms, wall * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 78.6, 8. * N * (D + 1) / ms / 1e6))
     del data, Z
     torch.cuda.empty_cache()
