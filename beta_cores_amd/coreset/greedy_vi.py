@@ -9,6 +9,7 @@ projection.  With a Device(Beta)Projector the N-row projection (K1), its column 
 touch the host; with a black-box projector the reference's NumPy expressions are used
 on whatever array the callable returns.
 """
+import contextlib
 import os
 import weakref
 
@@ -300,7 +301,10 @@ class GreedyVICoreset(Coreset):
             vecs, sum_scaling, _, _, corevecs = self._tangent(self.n_subsample_opt, w, self.pts, beta)
             resid = sum_scaling * self._colsum(vecs) - w.dot(corevecs)
             return -corevecs.dot(resid) / corevecs.shape[1]
-        self.wts = nn_opt(self.wts, grd, opt_itrs=self.opt_itrs, step_sched=self.step_sched)
+        # (a sampler of ours keeps its single-thread BLAS limit open over the whole loop instead of entering it per call)
+        scope = getattr(getattr(self.ll_projector, 'sampler', None), 'scope', None)
+        with (scope() if scope is not None else contextlib.nullcontext()):
+            self.wts = nn_opt(self.wts, grd, opt_itrs=self.opt_itrs, step_sched=self.step_sched)
 
     def error(self):
         return 0.   # the reference has no KL estimate either (bcores.py:152-153)

@@ -306,6 +306,37 @@ __global__ __launch_bounds__(256) void k_gram_reduce2(const double* __restrict__
   out[(size_t)c * dz + r] = acc;
 }
 
+// Coreset-sized Gram (the samplers: <= a few hundred rows, once per gradient of the beta-Cores loop): ONE launch, no partials
+// and no reduction.  Block (ta <= tb) owns the 16 x 16 tile of Z^T diag(w) Z over ALL dz columns (y included: column d of the
+// tile row is X^T (w*y)); the rows are parked in LDS 128 at a time and summed in row order.
+#define BC_GRAM_SMALL_ROWS 512
+__global__ __launch_bounds__(256) void k_gram_small(const double* __restrict__ z, const double* __restrict__ w, int n_rows, int dz,
+                                                   double* __restrict__ out, double* __restrict__ out_y) {
+  const int ta = blockIdx.x, tb = blockIdx.y;
+  if (ta > tb) return;
+  __shared__ double za[128][17], zb[128][16];
+  const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+  const int r = ta * 16 + tr, c = tb * 16 + tc, d = dz - 1;
+  double acc = 0.;
+  for (int i0 = 0; i0 < n_rows; i0 += 128) {
+    const int rows = n_rows - i0 < 128 ? n_rows - i0 : 128;
+    for (int e = threadIdx.x; e < rows * 16; e += 256) {
+      const int i = e >> 4, k = e & 15;
+      const double wi = w ? w[i0 + i] : 1.0;
+      const int ca = ta * 16 + k, cb = tb * 16 + k;
+      za[i][k] = ca < dz ? wi * z[(size_t)(i0 + i) * dz + ca] : 0.;      // (w[:,None]*X)
+      zb[i][k] = cb < dz ? z[(size_t)(i0 + i) * dz + cb] : 0.;
+    }
+    __syncthreads();
+    for (int i = 0; i < rows; ++i) acc = fma(za[i][tr], zb[i][tc], acc);
+    __syncthreads();
+  }
+  if (r > c || c >= dz || r >= d) return;
+  if (c == d) { out_y[r] = acc; return; }
+  out[(size_t)r * d + c] = acc;
+  out[(size_t)c * d + r] = acc;
+}
+
 // grow-only device scratch, owned by the context: the sampler calls weighted_post on <= M coreset rows thousands of
 // times (bcores.py:39 -> sampler -> weighted_post), a hipMalloc/hipFree pair per call would dominate
 static int gram_buf(bc_ctx* ctx, int which, size_t doubles, double** out) {
@@ -416,7 +447,17 @@ extern "C" int bc_weighted_gram_host(bc_ctx* ctx, const double* z_rowmajor, int6
   view.z = in_dev;
   view.owned = false;
   const double* w_dev = w ? in_dev + n_z : nullptr;
-  rc = d > 64 ? run_gram<128>(ctx, &view, w_dev, out_dev, out_dev + (size_t)d * d) : run_gram<64>(ctx, &view, w_dev, out_dev, out_dev + (size_t)d * d);
+  if (n_rows <= BC_GRAM_SMALL_ROWS) {
+    const int nb = (dz + 15) / 16;
+    rc = bc_timer_begin(ctx, 2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gram_small, dim3(nb, nb), dim3(256), 0, ctx->stream, (const double*)in_dev, w_dev, (int)n_rows, dz, out_dev,
+                       out_dev + (size_t)d * d);
+    BC_HIP(hipGetLastError());
+    rc = bc_timer_end(ctx, 2);
+  } else {
+    rc = d > 64 ? run_gram<128>(ctx, &view, w_dev, out_dev, out_dev + (size_t)d * d) : run_gram<64>(ctx, &view, w_dev, out_dev, out_dev + (size_t)d * d);
+  }
   if (rc) return rc;
   BC_HIP(hipMemcpyAsync(ctx->pinned, out_dev, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   BC_HIP(hipStreamSynchronize(ctx->stream));

@@ -27,17 +27,32 @@ except Exception:                                     # pragma: no cover
 _controller = None
 
 
-def _small_lapack(d):
+_limit_depth = 0
+
+
+@contextlib.contextmanager
+def small_lapack_scope(d):
     """The D x D Cholesky / triangular solve of a coreset posterior is microseconds of work; on a
     many-core host a multi-threaded BLAS spends milliseconds synchronising its pool on it (measured:
     4.9 ms per solve_triangular at D = 64 with 128 threads).  Same routines, one thread.  The controller is
-    created once: discovering the loaded BLAS libraries costs ~0.9 ms, more than the solve it guards."""
-    global _controller
-    if _Controller is None or d > 512:
-        return contextlib.nullcontext()
+    created once: discovering the loaded BLAS libraries costs ~0.9 ms, more than the solve it guards.
+    Re-entrant: entering the limit costs ~10 us, so a caller that runs many posteriors in a row (the greedy-VI
+    optimisation loop) opens the scope once and the calls inside find it open."""
+    global _controller, _limit_depth
+    if _Controller is None or d > 512 or _limit_depth > 0:
+        yield
+        return
     if _controller is None:
         _controller = _Controller()
-    return _controller.limit(limits=1, user_api='blas')
+    with _controller.limit(limits=1, user_api='blas'):
+        _limit_depth += 1
+        try:
+            yield
+        finally:
+            _limit_depth -= 1
+
+
+_small_lapack = small_lapack_scope
 
 
 def weighted_gram(z, w=None, ctx=None, comm=None):

@@ -15,7 +15,7 @@ next call, so the results and the RNG position after a build are the reference's
 """
 import numpy as np
 
-from .posterior import gaussian_weighted_post, weighted_post
+from .posterior import gaussian_weighted_post, small_lapack_scope, weighted_post
 
 
 class _PosteriorSampler:
@@ -25,6 +25,11 @@ class _PosteriorSampler:
 
     def _randn(self, n, d):
         return np.random.randn(n, d) if self._rng is None else self._rng.randn(n, d)
+
+    def scope(self):
+        """Context for a run of calls (the optimisation loop of BetaCoreset / SparseVI opens it once): the single-thread
+        BLAS limit the D x D solves want is entered once instead of per call."""
+        return small_lapack_scope(self._dim())
 
     def prefetch(self):
         """Draw the next call's normals now (no-op if they are already waiting)."""
@@ -49,6 +54,9 @@ class LinregPosteriorSampler(_PosteriorSampler):
         self.ctx = ctx
         self._shape = None
 
+    def _dim(self):
+        return self.th0.shape[0]
+
     def __call__(self, n, wts, pts):
         d = self.th0.shape[0]
         if pts.shape[0] == 0:
@@ -65,6 +73,9 @@ class GaussianPosteriorSampler(_PosteriorSampler):
         self.mu0, self.Sig0inv, self.Siginv = np.asarray(mu0, dtype=np.float64), np.asarray(Sig0inv, dtype=np.float64), np.asarray(Siginv, dtype=np.float64)
         self.ctx = ctx
         self._shape = None
+
+    def _dim(self):
+        return self.mu0.shape[0]
 
     def __call__(self, n, wts, pts):
         d = self.mu0.shape[0]
