@@ -224,6 +224,53 @@ def test_config4_headline_size(env, shard):
     torch.cuda.empty_cache()
 
 
+def test_config4_all_rows_vs_oracle(env):
+    """The headline workload with NOTHING sampled: all 10M rows of bench.py's data recipe through the NumPy oracle on the
+    host (its own K1 in row chunks, then GIGA) and through the device path; the selections of the first greedy iterations
+    are identical and the weights agree.  (bench.py's cpu_baseline leg makes the same comparison inside the driver's run;
+    here a difference is a red test.)  ~35 s of host work, 8 GB of host memory for the oracle's Phi."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    bc, torch, ctx = env
+    N, D, S, ITERS = 10_000_000, 128, 100, 6
+    dev = torch.device('cuda', ctx.device)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(39)
+    thstar = torch.randn((D,), generator=g0, dtype=torch.float64, device=dev)
+    Z = bench.gen_rows(torch, dev, 0, N, D, thstar)
+    torch.cuda.synchronize()
+    data = bc.DeviceData.from_torch(Z, ctx=ctx)
+    mu, L, _ = bc.weighted_post(np.zeros(D), np.eye(D), 1.0, data, None)
+    theta = mu + np.random.default_rng(41).standard_normal((S, D)).dot(L.T)
+    model = bc.likelihoods.LinearRegression(1.0)
+    h = bc.HilbertCoreset(data, bc.DeviceProjector(lambda k, w, p: theta, S, model, ctx=ctx))
+    h.build(ITERS, ITERS)
+    dsel = h.snnls._eng.trace()[0][:ITERS]
+    didx, dwts = h.idcs.copy(), h.wts.copy()
+    derr = h.error()
+    del h
+    torch.cuda.empty_cache()
+    ll = lambda z, t: M.linreg_loglik(z, t, 1.0)
+    phi_ref = np.empty((N, S))
+    CH = 1_000_000
+    for a in range(0, N, CH):
+        zc = Z[a:a + CH].cpu().numpy()
+        for b in range(0, zc.shape[0], 100_000):       # rows are independent: chunking does not change the result
+            blk = zc[b:b + 100_000]
+            phi_ref[a + b:a + b + blk.shape[0]] = C.project(ll, blk, theta)
+    del Z, data
+    torch.cuda.empty_cache()
+    ref = RefGIGA(phi_ref.T, phi_ref.sum(axis=0))
+    ref.build(ITERS)
+    rsel = np.array([t[0] for t in ref.trace])
+    np.testing.assert_array_equal(dsel, rsel)
+    ridx = np.where(ref.w > 0)[0]
+    np.testing.assert_array_equal(didx, ridx)
+    np.testing.assert_allclose(dwts, ref.w[ridx], rtol=1e-5)
+    assert abs(derr - ref.error()) <= 1e-6 * max(1., ref.error())
+
+
 def test_config1_stated_size_giga_vs_oracle():
     """BASELINE configs[0] at its stated size: the examples/zellner_gaussian recipe (main.py:33-54: N = 10 000 clean rows,
     d = 8, three outlier clusters of N/50, N/50, N/10 rows, S = 200 samples from the exact posterior = `prj_optimal`,
