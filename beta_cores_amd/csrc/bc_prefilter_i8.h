@@ -88,12 +88,18 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
   const long long r = t * BC_ITILE + threadIdx.x;
   const bool live = r < n_rows && norms[r < n_rows ? r : 0] != 0.;
   const double nr = live ? norms[r] : 1.;
+  // u = Phi / ||Phi|| through ONE reciprocal per row instead of two fp64 divisions per element (u, then u / scale): 3.71 ->
+  // 3.23 ms at 10M rows.  Nothing downstream needs the correctly rounded quotient: delta_i is MEASURED below against the
+  // values actually stored, u's relative error of 2^-52 is far inside the (1 + 1e-6) inflation of delta, and any integer
+  // q with |q| <= 127 is a valid digit.  (Holding the row in registers between the two passes instead of re-reading it:
+  // 4.24 ms, slower.)
+  const double inr = 1. / nr;
   const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
   double mx = 0.;
   bool has_nan = false;
   if (live)
     for (int k = 0; k < S; ++k) {
-      const double u = p[(size_t)k * BC_TILE] / nr;
+      const double u = p[(size_t)k * BC_TILE] * inr;
       has_nan |= !(fabs(u) <= 1.7976931348623157e308);   // NaN or inf
       mx = fmax(mx, fabs(u));
     }
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
     if ((float)hs < 6.2e-5f) hs = (_Float16)6.2e-5f;     // keep it a normal half (rows with tiny maxima do not exist for unit rows)
   }
   const double scale = (double)(float)hs;
+  const double iscale = ok ? 1. / scale : 0.;
   double err2 = 0.;
   int* q = u8 + (size_t)t * SP4 * BC_ITILE + threadIdx.x;
   for (int g = 0; g < SP4; ++g) {
@@ -115,8 +122,8 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
       const int k = 4 * g + j;
       int qi = 0;
       if (ok && k < S) {
-        const double u = p[(size_t)k * BC_TILE] / nr;
-        qi = (int)rint(u / scale);
+        const double u = p[(size_t)k * BC_TILE] * inr;
+        qi = (int)rint(u * iscale);
         qi = qi > 127 ? 127 : (qi < -127 ? -127 : qi);
         const double d = (double)qi * scale - u;
         err2 = fma(d, d, err2);
