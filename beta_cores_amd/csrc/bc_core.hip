@@ -99,6 +99,9 @@ extern "C" int bc_ctx_destroy(bc_ctx* ctx) {
     if (sc->p) (void)hipFree(sc->p);
   if (ctx->proj_pinned) (void)hipHostFree(ctx->proj_pinned);
   if (ctx->vi_pinned) (void)hipHostFree(ctx->vi_pinned);
+  if (ctx->vi_side) { (void)hipStreamSynchronize(ctx->vi_side); (void)hipStreamDestroy(ctx->vi_side); }
+  if (ctx->vi_ev_staged) (void)hipEventDestroy(ctx->vi_ev_staged);
+  if (ctx->vi_ev_core) (void)hipEventDestroy(ctx->vi_ev_core);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -67,6 +67,8 @@ struct bc_ctx {
   int32_t vi_pending_s = 0;
   bool vi_pending_timed = false;
   double* vi_pinned = nullptr;   // pinned landing area of the pending gradient
+  hipStream_t vi_side = nullptr;  // bc_vi_gradient: the coreset rows' K1 runs here, beside the data rows' launch on `stream`
+  hipEvent_t vi_ev_staged = nullptr, vi_ev_core = nullptr;
 };
 
 int bc_scratch_grow(bc_ctx* ctx, bc_scratch* s, size_t doubles);   // contents are NOT kept when it grows

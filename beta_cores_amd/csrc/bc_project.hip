@@ -1469,9 +1469,29 @@ extern "C" int bc_vi_gradient_begin(bc_ctx* ctx, const bc_data* data, const doub
     ctx->core_phi = cphi;
   }
   cphi->stats_valid = false;
+  // The coreset rows' launch (one tile or a few: ~20 us of dependent latency, no work to speak of) runs on a side stream
+  // BESIDE the data rows' launch instead of in front of it; the algebra kernel waits for both (0.441 -> 0.427 ms per native
+  // call at N = 1M, D = 64).  The instrumented pass (timing on) keeps everything on one stream, so that its five phases stay a
+  // partition of the call.
+  const bool beside = !timed;
+  if (beside && !ctx->vi_side) {
+    BC_HIP(hipStreamCreateWithFlags(&ctx->vi_side, hipStreamNonBlocking));
+    BC_HIP(hipEventCreateWithFlags(&ctx->vi_ev_staged, hipEventDisableTiming));
+    BC_HIP(hipEventCreateWithFlags(&ctx->vi_ev_core, hipEventDisableTiming));
+  }
   const int saved_timing = ctx->timing;
   ctx->timing = 0;                      // the coreset rows' launch is not a K1 sample of the kernel timer
-  rc = plan_launch(ctx, pl, cd, cphi, PROJ_FULL, s, 0, &ctx->proj_rowaux);
+  if (beside) {
+    BC_HIP(hipEventRecord(ctx->vi_ev_staged, ctx->stream));             // Theta, the coreset rows and w have landed
+    BC_HIP(hipStreamWaitEvent(ctx->vi_side, ctx->vi_ev_staged, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->vi_side;
+    rc = plan_launch(ctx, pl, cd, cphi, PROJ_FULL, s, 0, &ctx->proj_rowaux);
+    ctx->stream = main_stream;
+    if (!rc) BC_HIP(hipEventRecord(ctx->vi_ev_core, ctx->vi_side));
+  } else {
+    rc = plan_launch(ctx, pl, cd, cphi, PROJ_FULL, s, 0, &ctx->proj_rowaux);
+  }
   ctx->timing = saved_timing;
   if (!rc) rc = mark(2);
   bc_phi* phi = nullptr;
@@ -1488,6 +1508,7 @@ extern "C" int bc_vi_gradient_begin(bc_ctx* ctx, const bc_data* data, const doub
   }
   rc = mark(4);
   if (rc) return rc;
+  if (beside) BC_HIP(hipStreamWaitEvent(ctx->stream, ctx->vi_ev_core, 0));
   hipLaunchKernelGGL(k_vi_gradient, dim3(1), dim3(256), (size_t)s * sizeof(double), ctx->stream, colsum, cphi->tiles, d_w,
                      (int)m, s, sum_scaling, d_resid, d_grad);
   BC_HIP(hipGetLastError());
