@@ -507,6 +507,16 @@ def main():
     theta = posterior_samples(bc, data, D, S, comm)
     t_post = time.perf_counter() - t0
     k4_ms, k4_n = ctx.kernel_time(2)
+    # ... and warm: three more launches over the same rows (the first one above pays the scratch allocation and cold caches)
+    k4_warm_ms = None
+    if world == 1:
+        ctx.kernel_time_reset()
+        for _ in range(3):
+            bc.weighted_gram(data, None)
+        barrier()
+        k4w, k4wn = ctx.kernel_time(2)
+        k4_warm_ms = k4w / max(k4wn, 1)
+        ctx.kernel_time_reset()
     model = bc.likelihoods.LinearRegression(1.0)
     prj = bc.DeviceProjector(lambda n, w, p: theta, S, model, ctx=ctx)
 
@@ -670,7 +680,8 @@ def main():
                                                   'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
                                                   'frac': k1_flops / (k1_ms_per * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}},
             'posterior_gram': dict(k4_entry(n_local, D, max(k4_ms / max(k4_n, 1), 1e-9)), wall_ms=1e3 * t_post,
-                                   note='K4 X^T W X on fp64 MFMA, all local rows, w = 1 (sampler set-up, cold first launch)'),
+                                   note='K4 X^T W X on fp64 MFMA, all local rows, w = 1 (sampler set-up, cold first launch)',
+                                   warm=(k4_entry(n_local, D, k4_warm_ms) if k4_warm_ms else None)),
             'prefilter': dict(zip(('sweeps', 'candidates_rescored', 'fp64_fallbacks'), alg.snnls._eng.prefilter_stats())),
             'step_stages': step_diag,
             'solver_init_ms': 1e3 * t_init, 'solver_init': init_parts, 'setup_s': t_setup,
