@@ -104,6 +104,36 @@ def test_fused_gradient_matches_host_algebra(bc, m):
                 np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12 * np.abs(want).max())
 
 
+def test_fused_gradient_survives_library_calls_between_begin_and_end(bc):
+    """Whatever the host does between bc_vi_gradient_begin and _end -- including calls into this library on the same context
+    (a K4 round trip, another projection that re-stages Theta through the same pinned area, a second projector's column
+    sums) -- the pending gradient is the one that was enqueued.  The coreset rows' projection runs on a side stream beside
+    the data rows' launch: this is the test that their results are joined before the algebra."""
+    rng = np.random.RandomState(77)
+    n, d, s, m = 300_000, 32, 100, 40
+    Z = rng.randn(n, d + 1)
+    th = rng.randn(s, d) * 0.3
+    model = bc.likelihoods.LinearRegression(1.3)
+    prj = bc.DeviceBetaProjector(fixed(th), s, model)
+    other = bc.DeviceProjector(fixed(rng.randn(s, d)), s, model)
+    dd = bc.DeviceData(Z)
+    core = Z[rng.choice(n, m, replace=False)]
+    w = rng.uniform(0., 3., m)
+    want, want_r = prj.vi_gradient(dd, core, w, 1.7, beta=0.2, want_resid=True)
+    side = {}
+
+    def meddle():
+        side['gram'] = bc.weighted_gram(core, w)
+        side['phi'] = other.project(Z[:5000]).colsum()
+        side['cs'] = other.colsum(dd)
+    for _ in range(3):
+        got, got_r = prj.vi_gradient(dd, core, w, 1.7, beta=0.2, want_resid=True, overlap=meddle)
+        assert np.array_equal(got, want) and np.array_equal(got_r, want_r)
+    G, v = side['gram']
+    np.testing.assert_allclose(G, (w[:, None] * core[:, :d]).T.dot(core[:, :d]), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(side['cs'], other.project(dd).colsum())
+
+
 def make_sampler(Z, E):
     D = Z.shape[1] - 1
 
