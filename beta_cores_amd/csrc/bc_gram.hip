@@ -4,10 +4,13 @@
 //
 // This is the one genuinely GEMM-shaped reduction on the path (2*N*Dz^2 flop against 8*N*Dz
 // bytes: intensity Dz/4 flop/B), so it runs on the fp64 matrix cores: v_mfma_f64_16x16x4_f64
-// with A = (w*Z)^T panel, B = Z panel, both staged through LDS in 16-row slabs (buffer loads,
-// register prefetch of the next slab).  Only the upper-triangular BT x BT tiles are computed;
+// with A = (w*Z)^T panel, B = Z panel, both staged through LDS in 16-row slabs (range-checked
+// buffer loads, register prefetch of the next slab).  Only the upper-triangular BT x BT tiles are
+// computed, and of a DIAGONAL tile only the MFMA sub-tiles on or above its diagonal (GramDiag);
 // the row range is split over the grid (split-K) and the per-split partial tiles are summed in
-// split order by a second kernel, so the result is run-to-run deterministic.
+// split order by two small kernels (k_gram_reduce1 / 2), so the result is run-to-run
+// deterministic.  Coreset-sized inputs (the samplers, once per gradient) take one launch,
+// k_gram_small, with no partials at all.
 #include "bc_internal.h"
 #include <cmath>
 #include <cstdlib>
