@@ -390,8 +390,15 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   e = hipMemsetAsync(p->ctrl, 0, 256, ctx->stream);
   if (e == hipSuccess) {
     if (p->prec == 8)
-      hipLaunchKernelGGL(k_build_i8, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
-                         (long long)phi->n_rows, phi->s, p->sp4, p->u8, p->rowq);
+    {
+      const int two_pass = getenv("BC_BUILD_I8_TWO_PASS") ? atoi(getenv("BC_BUILD_I8_TWO_PASS")) : 0;   // (A/B and tests: read per call)
+      if (phi->s <= 104 && !two_pass)        // (S <= 104 covers every BASELINE configuration; two-pass kernel for the rest)
+        hipLaunchKernelGGL(k_build_i8_r<104>, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                           (long long)phi->n_rows, phi->s, p->sp4, p->u8, p->rowq);
+      else
+        hipLaunchKernelGGL(k_build_i8, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                           (long long)phi->n_rows, phi->s, p->sp4, p->u8, p->rowq);
+    }
     else if (p->prec == 16)
       hipLaunchKernelGGL(k_build_u16, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
                          (long long)phi->n_rows, phi->s, p->sp, p->u16, p->live);

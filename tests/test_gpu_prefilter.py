@@ -200,6 +200,28 @@ def test_prefilter_statistics(bc, prec):
     assert sweeps <= cands <= 64 * sweeps          # at least the winner each time, and a selective filter
 
 
+@pytest.mark.parametrize('n,s', [(30000, 100), (30081, 64), (128 * 235 + 1, 104), (257, 8), (70000, 97)])
+def test_int8_mirror_builders_agree(bc, n, s, monkeypatch):
+    """S <= 104: the mirror is built in one pass over Phi (k_build_i8_r: the row stays in registers); otherwise, or with
+    BC_BUILD_I8_TWO_PASS=1, in two (k_build_i8).  Same digits, same scales, same measured deltas: the sweeps select the same
+    candidates step for step (identical rescoring counters) and the solver traces are identical -- on row counts whose last
+    mirror tile is only partly backed by Phi tiles (an odd number of 128-row tiles; the rows past the end are dead rows)."""
+    rng = np.random.RandomState(n + s)
+    phi = correlated(rng, n, s)
+    out = []
+    for two_pass in ('0', '1'):
+        monkeypatch.setenv('BC_BUILD_I8_TWO_PASS', two_pass)
+        with prefilter(8):
+            sv = bc.snnls.GIGA(phi.T, phi.sum(axis=0))
+        assert sv._eng.prefilter == 8
+        sv.build(25)
+        out.append((sv._eng.trace(), sv._eng.sparse_weights(), sv._eng.prefilter_stats()))
+    (ta, wa, sa), (tb, wb, sb) = out
+    assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
+    assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1])
+    assert sa == sb
+
+
 def _fuzz_problem(rng, n, s, kind):
     if kind == 0:
         phi = rng.randn(n, s)
