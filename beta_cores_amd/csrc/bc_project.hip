@@ -1394,7 +1394,15 @@ __global__ __launch_bounds__(256) void k_vi_gradient(const double* __restrict__ 
   extern __shared__ double rs[];      // [s]
   for (int k = threadIdx.x; k < s; k += blockDim.x) {
     double acc = 0.;
-    for (int i = 0; i < m; ++i) acc = fma(w[i], core[bc_tile_off(i, k, s)], acc);
+    int i = 0;
+    for (; i + 8 <= m; i += 8) {           // same fma chain, eight loads in flight (one block, pure latency)
+      double c[8], ww[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { c[u] = core[bc_tile_off(i + u, k, s)]; ww[u] = w[i + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fma(ww[u], c[u], acc);
+    }
+    for (; i < m; ++i) acc = fma(w[i], core[bc_tile_off(i, k, s)], acc);
     const double r = scale * colsum[k] - acc;
     rs[k] = r;
     resid_out[k] = r;
@@ -1402,7 +1410,15 @@ __global__ __launch_bounds__(256) void k_vi_gradient(const double* __restrict__ 
   __syncthreads();
   for (int i = threadIdx.x; i < m; i += blockDim.x) {
     double acc = 0.;
-    for (int k = 0; k < s; ++k) acc = fma(core[bc_tile_off(i, k, s)], rs[k], acc);
+    int k = 0;
+    for (; k + 8 <= s; k += 8) {
+      double c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = core[bc_tile_off(i, k + u, s)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fma(c[u], rs[k + u], acc);
+    }
+    for (; k < s; ++k) acc = fma(core[bc_tile_off(i, k, s)], rs[k], acc);
     grad_out[i] = -acc / (double)s;
   }
 }
