@@ -42,6 +42,7 @@ _SIGNATURES = {
     'bc_phi_from_host': [vp, vp, C.c_int64, C.c_int32, C.c_int64, vpp],
     'bc_phi_create': [vp, C.c_int64, C.c_int32, vpp],
     'bc_project': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, C.c_int64, vpp],
+    'bc_project_from_host': [vp, vp, C.c_int64, C.c_int32, C.c_int, vp, C.c_int32, vp, C.c_int32, C.c_int64, vpp, vpp],
     'bc_project_grad_x': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, vp],
     'bc_project_colsum': [vp, vp, C.c_int, vp, C.c_int32, vp, C.c_int32, vp, vp],
     'bc_vi_gradient': [vp, vp, vp, C.c_int64, C.c_int, vp, C.c_int32, vp, C.c_int32, vp, C.c_double, vp, vp, vp],

@@ -35,6 +35,9 @@ class BatchPSVICoreset(Coreset):
             # every gradient re-projects ALL rows: keep them in HBM (read-only on the host while pinned)
             self._resident = ll_projector.pin(data)
             self._unpin = weakref.finalize(self, ll_projector.unpin, data)
+        elif wants_pin and isinstance(data, np.ndarray) and data.base is not None and data.ndim == 2 and n >= 4096:
+            from .greedy_vi import resident_copy_of_view
+            self._resident = resident_copy_of_view(data, ll_projector)       # a view: copied once, with a warning
         super().__init__(**kw)
 
     # ---- bpsvi.py:17-25: a fresh random initialisation of all `sz` points, then the optimisation (itrs is unused)

@@ -11,6 +11,7 @@ on whatever array the callable returns.
 """
 import contextlib
 import os
+import warnings
 import weakref
 
 import numpy as np
@@ -22,6 +23,18 @@ from .coreset import Coreset
 
 def _flatten(groups):
     return [i for g in groups for i in g]
+
+
+def resident_copy_of_view(data, ll_projector):
+    """A VIEW (Z[:n], a reshaped or memory-mapped array: `data.base is not None`) cannot be guarded against in-place edits
+    the way a pinned array is -- writes through its base would go unseen -- so it is not pinned.  Left at that, every
+    full-data gradient would upload all N x Dz rows again (~10 GB per gradient at the headline size).  Instead the rows are
+    copied to the device ONCE into a DeviceData this coreset owns, and the caller is told: later edits of the host array
+    are not seen (pin_data=False keeps the reference's read-the-live-array-every-time behaviour, bcores.py:44)."""
+    warnings.warn('data is a view of another array: its %d rows were copied to the GPU once for this coreset; in-place edits of '
+                  'the host array after construction are not seen (pass pin_data=False to re-read it on every projection)'
+                  % data.shape[0], UserWarning, stacklevel=3)
+    return DeviceData(np.ascontiguousarray(data, dtype=np.float64), ctx=getattr(ll_projector, 'ctx', None))
 
 
 class GreedyVICoreset(Coreset):
@@ -63,6 +76,9 @@ class GreedyVICoreset(Coreset):
             # pin_data=False restores the reference's read-the-live-array-every-time behaviour (bcores.py:44).
             self._dev_data = ll_projector.pin(data)
             self._unpin = weakref.finalize(self, ll_projector.unpin, data)      # released with this coreset
+        elif pin_data and hasattr(ll_projector, 'pin') and isinstance(data, np.ndarray) and data.base is not None and data.ndim == 2 \
+                and data.shape[0] >= 4096 and (n_subsample_select is None or n_subsample_opt is None or groups is not None):
+            self._dev_data = resident_copy_of_view(data, ll_projector)
         super().__init__(**kw)
         self.initialized = int(initialized) * len(self.wts)
 

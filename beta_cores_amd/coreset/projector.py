@@ -16,7 +16,7 @@ import weakref
 import numpy as np
 
 from .. import _native as N
-from ..device import DeviceData, DevicePhi, _ptr, default_context
+from ..device import DeviceData, DevicePhi, _as_f64, _ptr, default_context
 
 
 class Projector(object):
@@ -83,6 +83,7 @@ class BetaBlackBoxProjector(Projector):
 
 
 _SMALL_ROWS = 4096     # below this an input is treated as transient (coreset points, sub-samples)
+_PIPE_ROWS = 65536     # live host arrays from this size on are uploaded and projected in one pipelined call
 _BIG_ROWS = 65536      # Phi buffers above this are not hoarded: at most one free buffer per S is kept
 
 
@@ -269,7 +270,31 @@ class _DeviceProjectorBase(Projector):
             return slot.update(pts), True
         return DeviceData(pts, ctx=self.ctx), False            # live array, uploaded for this call
 
+    def _run_from_host(self, pts, model_id, params, keep=False):
+        """project(ndarray) for a LARGE live host array: upload and K1 pipelined in one native call (bc_project_from_host;
+        Phi, norms and column sums are the resident path's bit for bit).  Returns (DevicePhi, DeviceData of the uploaded
+        rows); the latter is dropped by the caller unless it wants the rows to stay in HBM."""
+        pts = _as_f64(np.atleast_2d(pts), 'data')
+        theta = self.model.theta_for_device(self.samples)
+        if pts.shape[1] != self.model.data_width(theta.shape[1]):
+            raise ValueError('data rows have %d columns, model expects %d for %d-dimensional samples'
+                             % (pts.shape[1], self.model.data_width(theta.shape[1]), theta.shape[1]))
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        S = int(theta.shape[0])
+        cap, h = self._pool.acquire(pts.shape[0], S)
+        dh = C.c_void_p()
+        try:
+            N.call('bc_project_from_host', self.ctx.h, _ptr(pts), int(pts.shape[0]), int(pts.shape[1]), int(model_id), _ptr(theta), S,
+                   _ptr(params), int(params.shape[0]), 0, C.byref(dh), C.byref(h))
+        except Exception:
+            self._pool.releaser(cap, S)(h)
+            raise
+        dd = DeviceData._adopt(dh, pts.shape, self.ctx)
+        return DevicePhi(h, self.ctx, release=self._pool.releaser(cap, S)), dd
+
     def _run(self, pts, model_id, params):
+        if isinstance(pts, np.ndarray) and pts.ndim == 2 and pts.shape[0] >= _PIPE_ROWS and self._pins.get(id(pts)) is None:
+            return self._run_from_host(pts, model_id, params)[0]
         dd, transient = self.device_data(pts)
         theta = self.model.theta_for_device(self.samples)
         if dd.shape[1] != self.model.data_width(theta.shape[1]):

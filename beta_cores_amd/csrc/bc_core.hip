@@ -23,7 +23,7 @@ int bc_hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 extern "C" const char* bc_last_error(void) { return g_err; }
-extern "C" int bc_version(void) { return 201; }
+extern "C" int bc_version(void) { return 210; }
 
 // ------------------------------------------------------------------ context
 extern "C" int bc_ctx_create(int device, void* stream, bc_ctx** out) {
@@ -103,6 +103,7 @@ extern "C" int bc_ctx_destroy(bc_ctx* ctx) {
   if (ctx->vi_ev_staged) (void)hipEventDestroy(ctx->vi_ev_staged);
   if (ctx->vi_ev_core) (void)hipEventDestroy(ctx->vi_ev_core);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  bc_uploader_free(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return BC_OK;
@@ -200,9 +201,10 @@ extern "C" int bc_data_from_host(bc_ctx* ctx, const double* z, int64_t n_rows, i
     hipError_t e = hipMalloc((void**)&d->z, bytes);
     if (e != hipSuccess) { delete d; return bc_hip_fail(e, "hipMalloc(data)", __FILE__, __LINE__); }
     d->cap_rows = n_rows;
-    e = hipMemcpyAsync(d->z, z, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(d->z); delete d; return bc_hip_fail(e, "hipMemcpy(data)", __FILE__, __LINE__); }
+    // pipelined through pinned staging on several copy streams (bc_upload.hip); ctx->stream waits for every chunk, and the
+    // host buffer is only borrowed for the call (every byte has left it when bc_upload_rows returns)
+    int rc = bc_upload_rows(ctx, z, d->z, n_rows, dz, bc_upload_default_chunk_rows(n_rows, dz), nullptr);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d->z); delete d; return rc; }
   }
   *out = d;
   return BC_OK;
@@ -235,8 +237,8 @@ extern "C" int bc_data_upload(bc_data* d, const double* z, int64_t n_rows) {
   }
   d->n_rows = n_rows;
   if (n_rows > 0) {
-    BC_HIP(hipMemcpyAsync(d->z, z, (size_t)n_rows * d->dz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    BC_HIP(hipStreamSynchronize(ctx->stream));     // the host buffer is only borrowed for the call
+    int rc = bc_upload_rows(ctx, z, d->z, n_rows, d->dz, bc_upload_default_chunk_rows(n_rows, d->dz), nullptr);
+    if (rc) return rc;                             // (the host buffer is only borrowed for the call: it has been read when this returns)
   }
   return BC_OK;
 }

@@ -292,34 +292,38 @@ __global__ __launch_bounds__(256) void k_gram_reduce2(const double* __restrict__
   // with eight loads in flight, the run sums added in run order -- the association is fixed by (splits), run-to-run
   // deterministic.  (One thread per column walking all splits with one load in flight: 0.18 ms at 512 splits, 0.33 ms at
   // D = 512 -- the tail of the whole Gram.)
-  if (tri == 0 && blockIdx.y * 32 < dz) {
+  // (the chunk loop strides by the grid: bt*bt/256 blocks cover 2048 columns at BT = 128 in one trip, any D in several)
+  if (tri == 0) {
     __shared__ double ys[8][32];
-    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5, c = blockIdx.y * 32 + cl;
-    const long long len = (splits + 7) / 8;
-    const long long s0 = part * len;
-    long long s1 = s0 + len;
-    if (s1 > splits) s1 = splits;
-    double acc = 0.0;
-    if (c < dz) {
-      const double* py = partial_y + c;
-      const size_t st = (size_t)nt * bt;
-      long long sp = s0;
-      for (; sp + 8 <= s1; sp += 8) {
-        double v[8];
+    for (int c0 = blockIdx.y * 32; c0 < dz; c0 += gridDim.y * 32) {       // block-uniform trip count
+      const int cl = threadIdx.x & 31, part = threadIdx.x >> 5, c = c0 + cl;
+      const long long len = (splits + 7) / 8;
+      const long long s0 = part * len;
+      long long s1 = s0 + len;
+      if (s1 > splits) s1 = splits;
+      double acc = 0.0;
+      if (c < dz) {
+        const double* py = partial_y + c;
+        const size_t st = (size_t)nt * bt;
+        long long sp = s0;
+        for (; sp + 8 <= s1; sp += 8) {
+          double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = py[(size_t)(sp + u) * st];
+          for (int u = 0; u < 8; ++u) v[u] = py[(size_t)(sp + u) * st];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+          for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; sp < s1; ++sp) acc += py[(size_t)sp * st];
       }
-      for (; sp < s1; ++sp) acc += py[(size_t)sp * st];
-    }
-    ys[part][cl] = acc;
-    __syncthreads();
-    if (part == 0 && c < dz) {
-      double t = ys[0][cl];
+      ys[part][cl] = acc;
+      __syncthreads();
+      if (part == 0 && c < dz) {
+        double t = ys[0][cl];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) t += ys[q][cl];
-      out_y[c] = t;
+        for (int q = 1; q < 8; ++q) t += ys[q][cl];
+        out_y[c] = t;
+      }
+      __syncthreads();
     }
   }
   int ta = 0, rem = tri;

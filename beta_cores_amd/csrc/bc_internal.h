@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <functional>
 #include <vector>
 #include "../../include/beta_cores.h"
 
@@ -69,7 +70,16 @@ struct bc_ctx {
   double* vi_pinned = nullptr;   // pinned landing area of the pending gradient
   hipStream_t vi_side = nullptr;  // bc_vi_gradient: the coreset rows' K1 runs here, beside the data rows' launch on `stream`
   hipEvent_t vi_ev_staged = nullptr, vi_ev_core = nullptr;
+  struct bc_uploader* upl = nullptr;   // pipelined host -> HBM uploads (bc_upload.hip): copy streams, pinned staging, events
 };
+
+// bc_upload.hip: rows of a host array -> dst_dev through pinned staging and several copy threads; the hook (optional) is
+// called per chunk in row order with the event that marks the chunk's arrival (nullptr: it has already landed)
+typedef std::function<int(int64_t chunk, int64_t row0, int64_t rows, hipEvent_t landed)> bc_chunk_hook;
+int bc_upload_rows(bc_ctx* ctx, const double* src, double* dst_dev, int64_t n_rows, int32_t dz, int64_t chunk_rows,
+                   const bc_chunk_hook* on_chunk);
+int64_t bc_upload_default_chunk_rows(int64_t n_rows, int32_t dz);
+void bc_uploader_free(bc_ctx* ctx);
 
 int bc_scratch_grow(bc_ctx* ctx, bc_scratch* s, size_t doubles);   // contents are NOT kept when it grows
 

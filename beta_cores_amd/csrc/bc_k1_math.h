@@ -78,9 +78,11 @@ BC_KM double bc_log1p_exp_neg_tab(double a, const double* tab) {
   const double u = bc_exp_tab_core(-a, tab);
   const double f = 1. + u;
   const double fm1 = f - 1.;                           // exact
-  // nearest c_i = 1 + i/256, i in 0..256, from the low mantissa bits of fm1 * 256 + 1.5 * 2^52 (fm1 in [0, 1]; the mask
-  // only keeps a NaN's arbitrary bits inside the LDS allocation -- the result is a NaN either way)
-  const int i = (int)(bc_k1_lo32(fma(fm1, 256., 6755399441055744.)) & 511u);
+  // nearest c_i = 1 + i/256, i in 0..256, from the low mantissa bits of fm1 * 256 + 1.5 * 2^52 (fm1 in [0, 1]: the low
+  // word IS i; the unsigned min only matters for a NaN, whose arbitrary payload bits must not index past the 257 table
+  // entries -- the table is the last piece of the kernels' LDS -- and whose result is a NaN either way)
+  const unsigned iu = bc_k1_lo32(fma(fm1, 256., 6755399441055744.));
+  const int i = (int)(iu < 256u ? iu : 256u);
   const double rc = tab[BC_K1_EXP_N + 2 * i], lc = tab[BC_K1_EXP_N + 2 * i + 1];
   const double t = fma(f, rc, -1.);
   double q = fma(t, -1. / 6., 1. / 5.);

@@ -53,6 +53,8 @@ struct ProjArgs {
   int dz, d, dk, s, model;
   int s_total, s_off;     // RAW passes (S > 256): this launch fills samples [s_off, s_off + s) of s_total, un-centred
   long long ngroups;      // k_project_r: 32-row groups of this launch
+  int part_init;          // k_project_r: start the per-wave column partials from tile_part instead of 0 (a later chunk of
+                          // a chunked projection, bc_project_from_host: the same sums in the same order as ONE launch)
   double c[8];            // model constants, see model_constants()
 #ifdef BC_K1_STAMPS       // diagnostic build: s_memtime of wave 0 at phase boundaries, 32 slots per tile
   unsigned long long* stamps;
@@ -148,8 +150,10 @@ __device__ __forceinline__ double bc_exp_like_numpy(double x) {
 // The model value of a CONSTANT row (all S values equal: a data row with all-zero features) with the reference's bits:
 // which of these rows the reference's centring leaves exactly 0 depends on the last bit of the constant (section 7 of
 // DESIGN.md, golden F13), so their np.exp() is restated exactly; the formulas without a transcendental are already
-// bit-identical, and the two logistic ones are left to bc_model_value (log1p(exp(0)) = log 2 matches; the
-// beta-likelihood's np.power is not restated).
+// bit-identical; the logistic log-likelihood's log1p(exp(0)) = RN(log 2) matches as it is; the logistic beta-likelihood's
+// constant at m = 0 (a data row z = 0: two np.power(2, .) calls, model_lr.py:85) is handed in by the caller as c[3] --
+// the host layer evaluates the reference's expression with NumPy itself (likelihoods.LogisticRegression.params) --
+// and rows that are constant because every sample saturated (m << 0: -((b+1)/b - 1); m >> 0: 1) need no power at all.
 template <int MODEL>
 __device__ __forceinline__ double bc_model_value_np(double p, double ra, double sa, const double* c, const double* tab) {
   switch (MODEL) {
@@ -169,19 +173,25 @@ __device__ __forceinline__ double bc_model_value_np(double p, double ra, double 
       const double t3 = c[5] * q * gq;
       return ((t1 - t2) - t3) - c[6];
     }
+    case BC_MODEL_LOGISTIC_BETA:
+      if (p == 0. && c[3] == c[3]) return c[3];
+      return bc_model_value<MODEL>(p, ra, sa, c, tab);
     default:
       return bc_model_value<MODEL>(p, ra, sa, c, tab);
   }
 }
 template <int MODEL>
 constexpr bool bc_model_has_np_exp() { return MODEL == BC_MODEL_LINREG_BETA || MODEL == BC_MODEL_GAUSS_BETA || MODEL == BC_MODEL_GAUSS_BETA_GRAD; }
+// models whose constant rows are re-evaluated with the reference's bits (bc_model_value_np)
+template <int MODEL>
+constexpr bool bc_model_const_fixup() { return bc_model_has_np_exp<MODEL>() || MODEL == BC_MODEL_LOGISTIC_BETA; }
 
 // the constant of a constant row from the contraction value `p` of the lane's first sample: every lane of the row
 // evaluates its own (they agree up to the last bit), the lane with g == 0 decides
 template <int MODEL>
-__device__ __forceinline__ double bc_const_row_value(double devval, double p, double ra, double sa, const double* c, int lane) {
-  if (!bc_model_has_np_exp<MODEL>()) return devval;
-  double v = bc_model_value_np<MODEL>(p, ra, sa, c, nullptr);
+__device__ __forceinline__ double bc_const_row_value(double devval, double p, double ra, double sa, const double* c, int lane, const double* tab) {
+  if (!bc_model_const_fixup<MODEL>()) return devval;
+  double v = bc_model_value_np<MODEL>(p, ra, sa, c, tab);
   v = __shfl(v, lane & 15, BC_WAVE);
   // the restated value is the same number as the device's own up to the last bits; anything else means the row is
   // constant for another reason than equal arguments (it then keeps the device's value)
@@ -271,7 +281,7 @@ __device__ __forceinline__ void k1_row_stats(double4_t (&acc)[JT][NT], double (&
         ok &= (d0 == __shfl_xor(d0, 32, BC_WAVE)) ? 1 : 0;
         ok &= __shfl_xor(ok, 32, BC_WAVE);
         if (ok) {                                    // the four lanes of a constant row take this together
-          const double cval = bc_const_row_value<MODEL>(mean + d0, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
+          const double cval = bc_const_row_value<MODEL>(mean + d0, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane, tabl);
           mean = bc_np_sum_const_256(cval, S) / (double)S;
           const double v = cval - mean;
           sq = 0.;
@@ -368,8 +378,8 @@ __device__ __forceinline__ void k1_row_stats(double4_t (&acc)[JT][NT], double (&
     // NumPy's rounded mean of S copies of c, which is c only for some (c, S) -- otherwise the row keeps a tiny constant
     // residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The tree-order sum
     // above would round differently and flip that zero / non-zero status, so such rows use NumPy's order.
-    if (bc_model_has_np_exp<MODEL>() && __builtin_amdgcn_ballot_w64(constant_row && live) != 0ull) {
-      const double cnp = bc_const_row_value<MODEL>(cval, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane);
+    if (bc_model_const_fixup<MODEL>() && __builtin_amdgcn_ballot_w64(constant_row && live) != 0ull) {
+      const double cnp = bc_const_row_value<MODEL>(cval, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane, tabl);
       if (constant_row && live) {                // the reference's bits for the constant: every element of the row IS it
         cval = cnp;
 #pragma unroll
@@ -681,7 +691,17 @@ __global__ __launch_bounds__(512, 2) void k_project_r(ProjArgs a) {
   // ---- set-up: Theta -> LDS (wave w takes rows w, w + 8, ...), zero the accumulators, tables
   for (int i = w; i < NR; i += 8)
     for (int col = lane; col < dk; col += 64) Tl[i * ldt + (col & ~15) + 4 * (col & 3) + ((col >> 2) & 3)] = a.theta[(size_t)i * dk + col];
-  for (int i = tid; i < 8 * NR; i += 512) csum[i] = 0.;
+  if (a.part_init) {
+    // a chunk of a chunked projection: wave (b, w) continues the partial it left in row (8 b + w) of tile_part.  Chunks
+    // start at multiples of 8 * gridDim groups, so the wave meets the same groups in the same order as in one launch
+    // over all rows and its additions are the same ones.
+    for (int i = tid; i < 8 * NR; i += 512) {
+      const int ww = i / NR, ss = i - ww * NR;
+      csum[i] = ss < S ? a.tile_part[((size_t)blockIdx.x * 8 + ww) * S + ss] : 0.;
+    }
+  } else {
+    for (int i = tid; i < 8 * NR; i += 512) csum[i] = 0.;
+  }
   if (bc_model_uses_tables<MODEL>())
     for (int i = tid; i < BC_K1_TAB_DOUBLES; i += 512) tabl[i] = __builtin_bit_cast(double, g_k1_tab_bits[i]);
   __syncthreads();
@@ -956,11 +976,14 @@ static int model_constants(int model, const double* p, int np, int d, double* c,
     case BC_MODEL_LOGISTIC_LL:
       return np == 0 ? BC_OK : BC_INVALID_ARGUMENT;
     case BC_MODEL_LOGISTIC_BETA: {
-      if (np != 1) return BC_INVALID_ARGUMENT;
+      // params = [beta] or [beta, value of the beta-likelihood at m = 0 with the caller's np.power bits] (see
+      // bc_model_value_np): without the second one the constant of a z = 0 row is the device's own (within 2 ulp)
+      if (np != 1 && np != 2) return BC_INVALID_ARGUMENT;
       const double beta = p[0];
       c[0] = (beta + 1.) / beta;
       c[1] = -beta;
       c[2] = -beta - 1.;
+      c[3] = (np == 2) ? p[1] : NAN;
       return BC_OK;
     }
     case BC_MODEL_GAUSS_LL: {
@@ -1330,6 +1353,118 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// Host rows -> Phi, pipelined (hilbert.py:11-17 and bcores.py:44 hand the projector HOST arrays): the rows are uploaded in
+// chunks (bc_upload.hip) and K1 runs on chunk c behind the event that marks its arrival while chunks c+1.. are still on
+// the wire.  Rows are independent, so Phi and the norms are the resident path's bit for bit; the column sums too, because
+// the chunks keep the partial sums' association: the staged kernel writes one partial row per 128-row tile (chunks are
+// tile-aligned), the Theta-resident kernel's per-wave partials are CONTINUED from chunk to chunk (ProjArgs::part_init;
+// chunks start at multiples of 8 * n_cu groups = 65 536 rows, so every wave adds the same groups in the same order as in
+// one launch over all rows).  Which of the two kernels runs is decided once, from the total row count, exactly as
+// bc_project decides it.  *out_data receives the resident rows (the caller keeps or destroys them).
+static int launch_chunk(bc_ctx* ctx, const ProjPlan& pl, const bc_data* data, bc_phi* phi, int64_t row0, int64_t rows, int rgrid,
+                        bool first, bc_scratch* rowaux) {
+  ProjArgs a = pl.a;
+  a.rowaux = nullptr;
+  if (pl.siginv_dev) {
+    const int d = pl.d;
+    const int use_lds = (size_t)d * d * sizeof(double) <= 60 * 1024;
+    long long blocks = (rows + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_row_quadform, dim3((unsigned)blocks), dim3(256), use_lds ? (size_t)d * d * sizeof(double) : 0,
+                       ctx->stream, data->z + (size_t)row0 * data->dz, (long long)rows, d, pl.siginv_dev, rowaux->p + row0, use_lds);
+    BC_HIP(hipGetLastError());
+    a.rowaux = rowaux->p + row0;
+  }
+  const int64_t tile0 = row0 / BC_TILE, ntiles = (rows + BC_TILE - 1) / BC_TILE;
+  a.z = data->z + (size_t)row0 * data->dz;
+  a.tiles = phi->tiles + (size_t)tile0 * phi->s * BC_TILE;
+  a.norms = phi->norms + row0;
+  a.n_rows = rows;
+  a.dz = data->dz;
+  a.s_total = phi->s;
+  a.s_off = 0;
+  if (rgrid > 0) {
+    a.tile_part = phi->tile_part;                 // one row per wave, shared by all chunks
+    a.part_init = first ? 0 : 1;
+    a.ngroups = (rows + 31) / 32;
+    return launch_project_r_model<true>(ctx, a, rgrid, pl.model, pl.ntsel);
+  }
+  a.tile_part = phi->tile_part + (size_t)tile0 * phi->s;
+  return launch_project_model<true>(ctx, a, ntiles, pl.model, pl.ntsel);
+}
+
+extern "C" int bc_project_from_host(bc_ctx* ctx, const double* z_host, int64_t n_rows, int32_t dz, int model, const double* theta,
+                                    int32_t s, const double* params, int32_t n_params, int64_t row_offset, bc_data** out_data,
+                                    bc_phi** inout) {
+  if (!ctx || !z_host || n_rows <= 0 || dz <= 0 || !theta || s <= 0 || !out_data || !inout || (n_params > 0 && !params)) {
+    bc_set_error("bc_project_from_host: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  if (model < 0 || model > BC_MODEL_GAUSS_BETA_GRAD) { bc_set_error("bc_project_from_host: unknown model %d", model); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  bc_data* data = new bc_data();
+  data->ctx = ctx;
+  data->n_rows = n_rows;
+  data->dz = dz;
+  data->cap_rows = n_rows;
+  {
+    hipError_t e = hipMalloc((void**)&data->z, (size_t)n_rows * dz * sizeof(double));
+    if (e != hipSuccess) { delete data; return bc_hip_fail(e, "hipMalloc(data)", __FILE__, __LINE__); }
+  }
+  auto drop_data = [&]() { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(data->z); delete data; };
+  int rc;
+  if (s > 256) {
+    // the wide path makes several passes over all rows: plain (still multi-threaded) upload, then bc_project
+    rc = bc_upload_rows(ctx, z_host, data->z, n_rows, dz, bc_upload_default_chunk_rows(n_rows, dz), nullptr);
+    if (!rc) rc = bc_project_wide(ctx, data, model, theta, s, params, n_params, row_offset, inout);
+    if (rc) { drop_data(); return rc; }
+    *out_data = data;
+    return BC_OK;
+  }
+  ProjPlan pl;
+  rc = plan_stage(ctx, model, theta, s, params, n_params, dz, false, &pl);
+  if (rc) { drop_data(); return rc; }
+  bc_phi* phi = *inout;
+  if (phi && (phi->ctx != ctx || phi->s != s || !phi->tiles || bc_phi_set_rows(phi, n_rows) != 0)) {
+    bc_set_error("bc_project_from_host: *inout has a different S or too little row capacity; pass NULL to allocate");
+    drop_data();
+    return BC_INVALID_ARGUMENT;
+  }
+  bool fresh = false;
+  if (!phi) {
+    rc = bc_phi_alloc(ctx, n_rows, s, row_offset, &phi);
+    if (rc) { drop_data(); return rc; }
+    fresh = true;
+  }
+  phi->row_offset = row_offset;
+  phi->stats_valid = false;
+  if (pl.siginv_dev) {
+    rc = bc_scratch_grow(ctx, &ctx->proj_rowaux, (size_t)n_rows);
+    if (rc) { if (fresh) bc_phi_destroy(phi); drop_data(); return rc; }
+  }
+  const int rgrid = project_r_grid(ctx, pl, phi, PROJ_FULL);
+  phi->part_rows = rgrid > 0 ? (int64_t)rgrid * 8 : phi->ntiles;
+  // chunk = a multiple of (8 * rgrid) 32-row groups for the resident kernel, of 128-row tiles for the staged one; ~128 MiB
+  const int64_t unit = rgrid > 0 ? (int64_t)rgrid * 8 * 32 : (int64_t)BC_TILE * 512;
+  int64_t chunk_rows = (((int64_t)128 << 20) / ((int64_t)dz * 8) + unit - 1) / unit * unit;
+  const char* env = getenv("BC_PIPE_CHUNK_ROWS");      // tests: force several chunks on small inputs
+  if (env && atoll(env) > 0) chunk_rows = (atoll(env) + unit - 1) / unit * unit;
+  bool first = true;
+  bc_chunk_hook hook = [&](int64_t, int64_t row0, int64_t rows, hipEvent_t landed) -> int {
+    if (landed) BC_HIP(hipStreamWaitEvent(ctx->stream, landed, 0));
+    const int r = launch_chunk(ctx, pl, data, phi, row0, rows, rgrid, first, &ctx->proj_rowaux);
+    first = false;
+    return r;
+  };
+  rc = bc_upload_rows(ctx, z_host, data->z, n_rows, dz, chunk_rows, &hook);
+  if (!rc) rc = bc_phi_finish_stats(phi);
+  if (rc) { if (fresh) { (void)hipStreamSynchronize(ctx->stream); bc_phi_destroy(phi); } drop_data(); return rc; }
+  *inout = phi;
+  *out_data = data;
+  return BC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Store-free projection and the fused gradient of the greedy-VI weight optimisation.
 //
 // bcores.py:141-146 / sparsevi.py:129-134: every one of the opt_itrs ADAM steps of every build step evaluates
@@ -1504,36 +1639,48 @@ extern "C" int bc_vi_gradient_begin(bc_ctx* ctx, const bc_data* data, const doub
     ctx->stream = ctx->vi_side;
     rc = plan_launch(ctx, pl, cd, cphi, PROJ_FULL, s, 0, &ctx->proj_rowaux);
     ctx->stream = main_stream;
-    if (!rc) BC_HIP(hipEventRecord(ctx->vi_ev_core, ctx->vi_side));
+    if (!rc) {
+      const hipError_t e = hipEventRecord(ctx->vi_ev_core, ctx->vi_side);
+      if (e != hipSuccess) rc = bc_hip_fail(e, "hipEventRecord(vi_ev_core)", __FILE__, __LINE__);
+    }
   } else {
     rc = plan_launch(ctx, pl, cd, cphi, PROJ_FULL, s, 0, &ctx->proj_rowaux);
   }
   ctx->timing = saved_timing;
-  if (!rc) rc = mark(2);
-  bc_phi* phi = nullptr;
-  if (!rc) rc = colsum_phi_for(ctx, data->n_rows, s, &phi);
-  // (x^T Siginv x of the data rows, Gaussian models, goes to a scratch of its own: the coreset rows' is still in use)
-  if (!rc) rc = plan_launch(ctx, pl, data, phi, PROJ_COLSUM, s, 0, &ctx->proj_rowaux2);
-  if (!rc) rc = mark(3);
-  if (!rc) rc = bc_phi_reduce_colsum(phi);
-  if (rc) return rc;
-  const double* colsum = phi->colsum;
-  if (comm) {
-    rc = bc_comm_sum_dev(comm, phi->colsum, s, &colsum);
+  // Everything after the side launch runs inside `rest`: on ANY failure in it the side stream is joined before the error
+  // leaves this function -- the next call's plan_stage / bc_scratch_grow synchronise ctx->stream only and would otherwise
+  // overwrite proj_theta / free core_phi under a coreset-row kernel that is still reading them.
+  auto rest = [&]() -> int {
+    int rc = mark(2);
+    bc_phi* phi = nullptr;
+    if (!rc) rc = colsum_phi_for(ctx, data->n_rows, s, &phi);
+    // (x^T Siginv x of the data rows, Gaussian models, goes to a scratch of its own: the coreset rows' is still in use)
+    if (!rc) rc = plan_launch(ctx, pl, data, phi, PROJ_COLSUM, s, 0, &ctx->proj_rowaux2);
+    if (!rc) rc = mark(3);
+    if (!rc) rc = bc_phi_reduce_colsum(phi);
     if (rc) return rc;
+    const double* colsum = phi->colsum;
+    if (comm) {
+      rc = bc_comm_sum_dev(comm, phi->colsum, s, &colsum);
+      if (rc) return rc;
+    }
+    rc = mark(4);
+    if (rc) return rc;
+    if (beside) BC_HIP(hipStreamWaitEvent(ctx->stream, ctx->vi_ev_core, 0));
+    hipLaunchKernelGGL(k_vi_gradient, dim3(1), dim3(256), (size_t)s * sizeof(double), ctx->stream, colsum, cphi->tiles, d_w,
+                       (int)m, s, sum_scaling, d_resid, d_grad);
+    BC_HIP(hipGetLastError());
+    // the result lands in a pinned area of its own: whatever the host does between _begin and _end (it may well call into this
+    // library, whose other entry points stage through ctx->pinned) cannot overwrite it
+    if (!ctx->vi_pinned) BC_HIP(hipHostMalloc((void**)&ctx->vi_pinned, ctx->pinned_doubles * sizeof(double), hipHostMallocDefault));
+    BC_HIP(hipMemcpyAsync(ctx->vi_pinned, d_grad, n_down * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return mark(5);
+  };
+  if (!rc) rc = rest();
+  if (rc) {
+    if (beside) (void)hipStreamSynchronize(ctx->vi_side);
+    return rc;
   }
-  rc = mark(4);
-  if (rc) return rc;
-  if (beside) BC_HIP(hipStreamWaitEvent(ctx->stream, ctx->vi_ev_core, 0));
-  hipLaunchKernelGGL(k_vi_gradient, dim3(1), dim3(256), (size_t)s * sizeof(double), ctx->stream, colsum, cphi->tiles, d_w,
-                     (int)m, s, sum_scaling, d_resid, d_grad);
-  BC_HIP(hipGetLastError());
-  // the result lands in a pinned area of its own: whatever the host does between _begin and _end (it may well call into this
-  // library, whose other entry points stage through ctx->pinned) cannot overwrite it
-  if (!ctx->vi_pinned) BC_HIP(hipHostMalloc((void**)&ctx->vi_pinned, ctx->pinned_doubles * sizeof(double), hipHostMallocDefault));
-  BC_HIP(hipMemcpyAsync(ctx->vi_pinned, d_grad, n_down * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  rc = mark(5);
-  if (rc) return rc;
   ctx->vi_pending_m = m;
   ctx->vi_pending_s = s;
   ctx->vi_pending_timed = timed;

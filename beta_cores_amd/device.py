@@ -108,6 +108,17 @@ class DeviceData:
         self._fin = weakref.finalize(self, N.load().bc_data_destroy, h)
 
     @classmethod
+    def _adopt(cls, handle, shape, ctx):
+        """Wrap a bc_data handle a native call allocated (bc_project_from_host); this object owns it from here on."""
+        self = cls.__new__(cls)
+        self.ctx = ctx or default_context()
+        self.row_offset = 0
+        self.h = handle
+        self.shape = (int(shape[0]), int(shape[1]))
+        self._fin = weakref.finalize(self, N.load().bc_data_destroy, handle)
+        return self
+
+    @classmethod
     def slot(cls, dz, cap_rows=256, ctx=None):
         """A re-usable device buffer for small row sets that change every call (coreset points,
         sub-samples): allocate once, then `update(z)` in place."""

@@ -56,7 +56,22 @@ class LogisticRegression(_Model):
     beta_model_id = LOGISTIC_BETA
 
     def params(self, beta=None, grad=False):
-        return np.array([] if beta is None else [_checked_beta(beta)])
+        if beta is None:
+            return np.array([])
+        beta = _checked_beta(beta)
+        return np.array([beta, self.beta_value_at_zero(beta)])
+
+    @staticmethod
+    def beta_value_at_zero(beta):
+        """model_lr.py:85 at m = 0, i.e. the S equal values a data row z = 0 projects to, evaluated by NumPy's own ARRAY
+        arithmetic exactly as the reference does (its `**` is np.power, whose last bit differs from libm's pow for ~5 % of
+        exponents on AVX-512 hosts; a 1-element array takes the same routine as any element of an N x S one).  Whether such
+        a row centres to exactly 0 (projector.py:55) -- and then is a NaN candidate of every argmax (bcores.py:78-81) --
+        hangs on that bit, so K1 takes the constant from here instead of computing its own (goldens F19 / F20)."""
+        m = np.zeros((1, 1))
+        with np.errstate(all='ignore'):
+            c = -(((beta + 1.) / beta) * (1 + np.exp(m)) ** (-beta) - ((1 + np.exp(m)) ** (-beta - 1.) + (1 + np.exp(-m)) ** (-beta - 1.)))
+        return float(c[0, 0])
 
     def data_width(self, theta_dim):
         return theta_dim

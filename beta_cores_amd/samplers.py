@@ -15,6 +15,9 @@ next call, so the results and the RNG position after a build are the reference's
 """
 import numpy as np
 
+import scipy.linalg as sl
+from scipy.optimize import minimize
+
 from .posterior import gaussian_weighted_post, small_lapack_scope, weighted_post
 
 
@@ -32,16 +35,24 @@ class _PosteriorSampler:
         return small_lapack_scope(self._dim())
 
     def prefetch(self):
-        """Draw the next call's normals now (no-op if they are already waiting)."""
+        """Draw the next call's normals now (no-op if they are already waiting).  Only legal when the very next draw
+        from this sampler's stream is this sampler's next call with the shape of its previous one: the block is taken
+        from the stream HERE, so anything else drawn in between would see the stream one block further than the
+        reference's (GreedyVICoreset never prefetches after the last gradient of a loop for that reason)."""
         if self._ahead is None and self._shape is not None:
             self._ahead = self._randn(*self._shape)
 
     def _normals(self, n, d):
         e, self._ahead = self._ahead, None
         self._shape = (n, d)
-        if e is not None and e.shape == (n, d):
-            return e
-        return self._randn(n, d)
+        if e is None:
+            return self._randn(n, d)
+        if e.shape != (n, d):
+            # the block was already drawn from the stream: dropping it silently would leave the stream one S x D block
+            # ahead of the reference's from here on
+            raise RuntimeError('sampler called for %r normals while a prefetched block of shape %r is pending; '
+                               'prefetch() may only precede a call of the same shape' % ((n, d), e.shape))
+        return e
 
 
 class LinregPosteriorSampler(_PosteriorSampler):
@@ -82,4 +93,92 @@ class GaussianPosteriorSampler(_PosteriorSampler):
         if pts.shape[0] == 0:
             wts, pts = np.zeros(1), np.zeros((1, d))
         muw, LSigw, _ = gaussian_weighted_post(self.mu0, self.Sig0inv, self.Siginv, pts, wts, ctx=self.ctx)
+        return muw + self._normals(n, d).dot(LSigw.T)
+
+
+# ---- logistic regression: Laplace approximation around the mode of the weighted log-joint (<= M coreset rows: host work
+# in the reference too; the formulas keep model_lr.py's expression order so that, on one host, the
+# optimiser walks the same path as the reference's)
+def _lr_m(z, th):
+    z = np.atleast_2d(z)
+    th = np.atleast_2d(th)
+    m = -z.dot(th.T)
+    return z, th, m, m < 100
+
+
+def _lr_log_joint(z, th, wts):
+    """model_lr.py:72-79, 88-93"""
+    z, th, m, small = _lr_m(z, th)
+    m[small] = -np.log1p(np.exp(m[small]))
+    m[np.logical_not(small)] = -m[np.logical_not(small)]
+    return (wts[:, np.newaxis] * m).sum(axis=0) + (-0.5 * th.shape[1] * np.log(2. * np.pi) - 0.5 * (th ** 2).sum(axis=1))
+
+
+def _lr_grad_log_joint(z, th, wts):
+    """model_lr.py:98-105, 116-121"""
+    z, th, m, small = _lr_m(z, th)
+    m[small] = np.exp(m[small]) / (1. + np.exp(m[small]))
+    m[np.logical_not(small)] = 1.
+    return -th + (wts[:, np.newaxis, np.newaxis] * (m[:, :, np.newaxis] * z[:, np.newaxis, :])).sum(axis=0)
+
+
+def _lr_hess_log_joint(z, th, wts, diag):
+    """model_lr.py:123-137 (full) / 139-153 (diagonal)"""
+    z, th, m, small = _lr_m(z, th)
+    m[small] = np.exp(m[small]) / (1. + np.exp(m[small])) ** 2
+    m[np.logical_not(small)] = 0.
+    if diag:
+        hl = -m[:, :, np.newaxis] * z[:, np.newaxis, :] ** 2
+        return np.tile(-np.ones(th.shape[1]), (th.shape[0], 1)) + (wts[:, np.newaxis, np.newaxis] * hl).sum(axis=0)
+    hl = -m[:, :, np.newaxis, np.newaxis] * z[:, np.newaxis, :, np.newaxis] * z[:, np.newaxis, np.newaxis, :]
+    return np.tile(-np.eye(th.shape[1]), (th.shape[0], 1, 1)) + (wts[:, np.newaxis, np.newaxis, np.newaxis] * hl).sum(axis=0)
+
+
+def logistic_laplace(wts, Z, mu0, diag=False, rng=None):
+    """`get_laplace` (examples/zellner_logreg/main.py:86-111 == bayesiancoresets/util/opt.py:9-33): (mu, LSig, LSigInv) of
+    the Laplace approximation N(mu, LSig LSig^T) to the posterior of the rows Z with weights wts; the mode comes from
+    scipy.optimize.minimize's default method started at mu0 (third-party arithmetic, shared with the reference, not
+    restated), a failing optimisation restarts from a perturbed mu0 up to ten times.  diag=True returns the driver's
+    diagonal MATRICES (main.py:105-108; util/opt.py:27-29 has vectors, which its own caller cannot multiply with)."""
+    trials = 10
+    Zw = Z[wts > 0, :]
+    ww = wts[wts > 0]
+    while True:
+        try:
+            res = minimize(lambda mu: -_lr_log_joint(Zw, mu, ww)[0], mu0, jac=lambda mu: -_lr_grad_log_joint(Zw, mu, ww)[0, :])
+        except Exception:
+            mu0 = mu0.copy()
+            mu0 += np.sqrt((mu0 ** 2).sum()) * 0.1 * (np.random.randn(mu0.shape[0]) if rng is None else rng.randn(mu0.shape[0]))
+            trials -= 1
+            if trials <= 0:
+                raise RuntimeError('logistic_laplace: the mode search failed ten times')     # (the reference dies on `res` here)
+            continue
+        break
+    mu = res.x
+    if diag:
+        sq = np.sqrt(-_lr_hess_log_joint(Zw, mu, ww, True)[0, :])
+        return mu, np.diag(1. / sq), np.diag(sq)
+    LSigInv = np.linalg.cholesky(-_lr_hess_log_joint(Zw, mu, ww, False)[0, :, :])
+    LSig = sl.solve_triangular(LSigInv, np.eye(LSigInv.shape[0]), lower=True, overwrite_b=True, check_finite=False)
+    return mu, LSig, LSigInv
+
+
+class LogisticLaplaceSampler(_PosteriorSampler):
+    """The logistic drivers' `sampler_w` (examples/zellner_logreg/main.py:139-144): theta = mu_w + randn(S, D).LSig_w^T with
+    (mu_w, LSig_w) the Laplace fit of the weighted coreset rows pts = y*x (model_lr.py:29); an empty coreset gives the
+    prior N(0, I).  `mu0` is the optimiser's starting point (the drivers pass the prior mean), `diag` their `graddiag`."""
+
+    def __init__(self, mu0, diag=False, rng=None):
+        super().__init__(rng)
+        self.mu0, self.diag = np.asarray(mu0, dtype=np.float64), bool(diag)
+        self._shape = None
+
+    def _dim(self):
+        return self.mu0.shape[0]
+
+    def __call__(self, n, wts, pts):
+        d = self.mu0.shape[0]
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, d))
+        muw, LSigw, _ = logistic_laplace(np.asarray(wts, dtype=np.float64), np.atleast_2d(pts), self.mu0, self.diag, rng=self._rng)
         return muw + self._normals(n, d).dot(LSigw.T)

@@ -59,7 +59,9 @@ extern "C" {
 #define BC_MODEL_LINREG_LL 0     /* model_linreg.py:4-10 == model_neurlinr.py:90-97 ; params = {sigsq}          ; Z = [x(D), y] */
 #define BC_MODEL_LINREG_BETA 1   /* model_neurlinr.py:102-110                       ; params = {sigsq, beta}    ; Z = [x(D), y] */
 #define BC_MODEL_LOGISTIC_LL 2   /* model_lr.py:72-79                               ; params = {}               ; Z = y*x (D)   */
-#define BC_MODEL_LOGISTIC_BETA 3 /* model_lr.py:81-86                               ; params = {beta}           ; Z = y*x (D)   */
+#define BC_MODEL_LOGISTIC_BETA 3 /* model_lr.py:81-86                               ; params = {beta[, c0]}     ; Z = y*x (D)   */
+/*   c0 (optional): the formula's value at m = 0 carrying the caller's np.power bits; K1 uses it for the constant projection row of
+ *   a data row z = 0 (whether that row centres to exactly 0 hangs on its last bit).  Omitted: the device's own value, within 2 ulp. */
 #define BC_MODEL_GAUSS_LL 4      /* gaussian.py:7-15  ; params = {logdetSig, Siginv[d*d]}        ; Z = x (d) */
 #define BC_MODEL_GAUSS_BETA 5    /* gaussian.py:34-44 ; params = {beta, logdetSig, Siginv[d*d]}  ; Z = x (d) */
 #define BC_MODEL_GAUSS_BETA_GRAD 6 /* gaussian.py:46-62 ; params as GAUSS_BETA (d/dbeta, projector.py:56-61) */
@@ -153,6 +155,14 @@ int bc_phi_create(bc_ctx* ctx, int64_t cap_rows, int32_t s, bc_phi** out);
  * re-projects every gradient call, bcores.py:141-146). Fuses row norms and column sums (K2). */
 int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta, int32_t s,
                const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
+/* K1 straight from a HOST array, upload and projection pipelined: what `HilbertCoreset(data_ndarray, projector)` does at
+ * hilbert.py:11 (`ll_projector.project(data)`, projector.py:23-26) and the greedy-VI classes at bcores.py:44.  The rows go
+ * to HBM in chunks through pinned staging on copy streams (several host threads; bc_data_from_host uses the same
+ * uploader) and K1 runs on chunk c while chunk c+1.. are on the wire.  Phi, norms AND column sums are bit-identical to
+ * bc_data_from_host + bc_project (the chunks keep the column partials' order of additions).  *out_data: the resident rows
+ * (caller destroys); *inout as for bc_project.  z_host is only read during the call. */
+int bc_project_from_host(bc_ctx* ctx, const double* z_host, int64_t n_rows, int32_t dz, int model, const double* theta, int32_t s,
+                         const double* params, int32_t n_params, int64_t row_offset, bc_data** out_data, bc_phi** inout);
 /* K1 WITHOUT materialising Phi: only b = Phi^T 1 of the projection of `data`'s rows, S <= 256 doubles to the host.
  * What every gradient of the greedy-VI weight optimisation needs of the N x S projection (bcores.py:141-146,
  * sparsevi.py:129-134: `vecs.sum(axis=0)` inside grd).  Same contraction, formula, centring, per-tile column partials

@@ -161,3 +161,84 @@ def gauss_grad_x_loglik(x, th, Siginv):
     th = np.atleast_2d(th)
     return th.dot(Siginv)[np.newaxis, :, :] - x.dot(Siginv)[:, np.newaxis, :]
 
+
+
+# ---- the Laplace sampler of the logistic drivers (<= M coreset rows; host arithmetic in the reference too)
+def logistic_log_prior(th):
+    """model_lr.py:88-90"""
+    th = np.atleast_2d(th)
+    return -0.5 * th.shape[1] * np.log(2. * np.pi) - 0.5 * (th ** 2).sum(axis=1)
+
+
+def logistic_log_joint(z, th, wts):
+    """model_lr.py:92-93"""
+    return (wts[:, np.newaxis] * logistic_loglik(z, th)).sum(axis=0) + logistic_log_prior(th)
+
+
+def _logistic_sigmoid_m(z, th):
+    """the shared head of model_lr.py:98-105 / :127-134: m = -z.th^T, then e^m/(1+e^m) below the branch at 100"""
+    z = np.atleast_2d(z)
+    th = np.atleast_2d(th)
+    m = -z.dot(th.T)
+    return z, th, m, m < 100
+
+
+def logistic_grad_th_loglik(z, th):
+    """model_lr.py:98-105: (M, S, D)"""
+    z, th, m, idcs = _logistic_sigmoid_m(z, th)
+    m[idcs] = np.exp(m[idcs]) / (1. + np.exp(m[idcs]))
+    m[np.logical_not(idcs)] = 1.
+    return m[:, :, np.newaxis] * z[:, np.newaxis, :]
+
+
+def logistic_grad_th_log_joint(z, th, wts):
+    """model_lr.py:116-121 (the prior's gradient is -th)"""
+    return -np.atleast_2d(th) + (wts[:, np.newaxis, np.newaxis] * logistic_grad_th_loglik(z, th)).sum(axis=0)
+
+
+def logistic_hess_th_log_joint(z, th, wts):
+    """model_lr.py:123-137: (S, D, D)"""
+    z, th, m, idcs = _logistic_sigmoid_m(z, th)
+    m[idcs] = np.exp(m[idcs]) / (1. + np.exp(m[idcs])) ** 2
+    m[np.logical_not(idcs)] = 0.
+    hl = -m[:, :, np.newaxis, np.newaxis] * z[:, np.newaxis, :, np.newaxis] * z[:, np.newaxis, np.newaxis, :]
+    return np.tile(-np.eye(th.shape[1]), (th.shape[0], 1, 1)) + (wts[:, np.newaxis, np.newaxis, np.newaxis] * hl).sum(axis=0)
+
+
+def logistic_diag_hess_th_log_joint(z, th, wts):
+    """model_lr.py:139-153: (S, D)"""
+    z, th, m, idcs = _logistic_sigmoid_m(z, th)
+    m[idcs] = np.exp(m[idcs]) / (1. + np.exp(m[idcs])) ** 2
+    m[np.logical_not(idcs)] = 0.
+    dl = -m[:, :, np.newaxis] * z[:, np.newaxis, :] ** 2
+    return np.tile(-np.ones(th.shape[1]), (th.shape[0], 1)) + (wts[:, np.newaxis, np.newaxis] * dl).sum(axis=0)
+
+
+def logistic_laplace(wts, Z, mu0, diag=False):
+    """examples/zellner_logreg/main.py:86-111 (== bayesiancoresets/util/opt.py:9-33 for diag=False; the driver's copy
+    returns matrices for diag=True, which is what its sampler_w multiplies with): N(mu, LSig LSig^T) around the mode of
+    the weighted log-joint, found with scipy.optimize.minimize's default (BFGS) from mu0 -- third-party, shared."""
+    from scipy.optimize import minimize
+    trials = 10
+    Zw = Z[wts > 0, :]
+    ww = wts[wts > 0]
+    while True:
+        try:
+            res = minimize(lambda mu: -logistic_log_joint(Zw, mu, ww)[0], mu0,
+                           jac=lambda mu: -logistic_grad_th_log_joint(Zw, mu, ww)[0, :])
+        except Exception:
+            mu0 = mu0.copy()
+            mu0 += np.sqrt((mu0 ** 2).sum()) * 0.1 * np.random.randn(mu0.shape[0])
+            trials -= 1
+            if trials <= 0:
+                break
+            continue
+        break
+    mu = res.x
+    if diag:
+        sq = np.sqrt(-logistic_diag_hess_th_log_joint(Zw, mu, ww)[0, :])
+        LSigInv, LSig = np.diag(sq), np.diag(1. / sq)
+    else:
+        LSigInv = np.linalg.cholesky(-logistic_hess_th_log_joint(Zw, mu, ww)[0, :, :])
+        LSig = sl.solve_triangular(LSigInv, np.eye(LSigInv.shape[0]), lower=True, overwrite_b=True, check_finite=False)
+    return mu, LSig, LSigInv

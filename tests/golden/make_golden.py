@@ -961,6 +961,121 @@ def f18_zellner_gaussian_bpsvi_rand():
     save('f18_zellner_gaussian_bpsvi_rand', **out)
 
 
+# ---------------------------------------------------------------- F19: the greedy-VI coresets on the LOGISTIC model (BASELINE config 3)
+def logistic_problem(rng, N, D, S, zero_row=None):
+    """Z = y*x rows (model_lr.py:29) with a few rows scaled so that |m| = |z.theta| passes the branch at 100
+    (model_lr.py:76) and the beta-likelihood's overflow limits (model_lr.py:85), optionally one all-zero row."""
+    X = rng.randn(N, D)
+    ths = 2. * np.ones(D) / np.sqrt(D)
+    y = np.where(rng.rand(N) <= 1. / (1. + np.exp(-X.dot(ths))), 1., -1.)
+    Z = y[:, None] * X
+    big = np.array([5, 77, 201, 290])
+    Z[big] *= np.array([60., -90., 150., -40.])[:, None]
+    if zero_row is not None:
+        Z[zero_row] = 0.
+    E = rng.randn(S, D)
+    return Z, ths, E
+
+
+def f19_logistic_greedy_vi():
+    """BetaCoreset (model_lr.beta_likelihood, beta = 0.1) and SparseVICoreset (model_lr.log_likelihood), full-data mode,
+    5 builds x opt_itrs 10:
+      * `fixed`   -- the sampler returns the same Theta every call,
+      * `laplace` -- the reference's own wiring (zellner_logreg/main.py:139-144): get_laplace (util/opt.py:9-33) on the
+                     weighted coreset, theta = mu_w + E.LSig_w^T with the normals E fixed,
+      * `laprng`  -- the same with np.random.randn from the global stream; the stream position afterwards is recorded,
+      * `lapdiag` -- diag=True Laplace (main.py:105-108), bcores only.
+    S = 37 with an all-zero data row (its constant projection row keeps a residue of a few ulp under both likelihoods, so
+    it stays a harmless candidate -- if its constant were off by one bit it would become a NaN row and win every argmax);
+    S = 100 without one (at S = 100 that row centres to exactly 0 for beta = 0.1: the NaN case, golden F20)."""
+    out = {}
+    opt_itrs, builds, beta = 10, 5, 0.1
+    sched = lambda i: 0.5 / (1. + i)
+    fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    for S, N, D, zero_row in ((37, 500, 6, 123), (100, 400, 10, None)):
+        rng = np.random.RandomState(1900 + S)
+        Z, ths, E = logistic_problem(rng, N, D, S, zero_row)
+        th_fixed = ths + 0.5 * E
+        tag = 'S%d_' % S
+        out[tag + 'Z'], out[tag + 'E'], out[tag + 'th_fixed'] = Z, E, th_fixed
+        mu0 = np.zeros(D)
+
+        def lap(diag, normals):
+            def sampler_w(sz, w, pts):
+                if pts.shape[0] == 0:
+                    w = np.zeros(1)
+                    pts = np.zeros((1, Z.shape[1]))
+                muw, LSigw, _ = R.opt.get_laplace(w, pts, mu0, diag)
+                if diag:                      # main.py:105-108 hands back matrices where util/opt.py:27-29 has vectors
+                    LSigw = np.diag(LSigw)
+                return muw + normals(sz, muw.shape[0]).dot(LSigw.T)
+            return sampler_w
+        samplers = dict(fixed=lambda sz, w, pts: th_fixed,
+                        laplace=lap(False, lambda n, d: E),
+                        laprng=lap(False, lambda n, d: np.random.randn(n, d)),
+                        lapdiag=lap(True, lambda n, d: E))
+        with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+            for sn, sampler in samplers.items():
+                for nm in ('bcores', 'svi'):
+                    if sn == 'lapdiag' and nm == 'svi':
+                        continue
+                    np.random.seed(190)
+                    if nm == 'bcores':
+                        prj = R.projector.BetaBlackBoxProjector(sampler, S, R.lr.beta_likelihood, R.lr.log_likelihood, None)
+                        alg = R.bcores.BetaCoreset(Z, prj, opt_itrs=opt_itrs, step_sched=sched, beta=beta, learn_beta=False, **fresh())
+                    else:
+                        prj = R.projector.BlackBoxProjector(sampler, S, R.lr.log_likelihood)
+                        alg = R.sparsevi.SparseVICoreset(Z, prj, opt_itrs=opt_itrs, step_sched=sched, **fresh())
+                    for m in range(builds):
+                        quiet(alg.build, 1, m + 1)
+                        out['%s%s_%s_allw_%d' % (tag, sn, nm, m)] = alg.wts.copy()
+                        out['%s%s_%s_allidcs_%d' % (tag, sn, nm, m)] = alg.idcs.copy()
+                    out['%s%s_%s_theta_last' % (tag, sn, nm)] = np.array(prj.samples)
+                    if sn == 'laprng':
+                        out['%s%s_%s_rng_after' % (tag, sn, nm)] = np.array(np.random.rand())
+            # the sampler by itself: Laplace fit of a weighted handful of rows (both Hessian forms)
+            w5 = np.array([0.7, 0., 2.5, 1.1, 0.3])
+            p5 = Z[[1, 5, 9, 77, 200]]
+            for diag in (False, True):
+                mu, L, Li = R.opt.get_laplace(w5, p5, mu0, diag)
+                out['%slap%d_mu' % (tag, diag)], out['%slap%d_L' % (tag, diag)], out['%slap%d_Li' % (tag, diag)] = mu, L, Li
+            out[tag + 'lap_w'], out[tag + 'lap_rows'] = w5, np.array([1, 5, 9, 77, 200])
+    out['beta'], out['opt_itrs'] = np.array(beta), np.array(opt_itrs)
+    save('f19_logistic_greedy_vi', **out)
+
+
+# ---------------------------------------------------------------- F20: constant rows under the logistic beta-likelihood
+def f20_logistic_beta_constant_rows():
+    """A data row z = 0 projects to S copies of c(beta) = -((b+1)/b 2^-b - 2 2^(-b-1)), the powers by np.power
+    (model_lr.py:85).  Whether `c - mean` (projector.py:55) is exactly 0 depends on the last bit of c and on S; recorded
+    for S = 16 / 100 / 200 and beta = 0.1 / 0.2 / 0.5, plus BetaCoreset runs where the row is a NaN candidate (S = 16:
+    exact zero) and where it keeps a residue (S = 100 with beta = 0.5, S = 200 with beta = 0.1)."""
+    rng = np.random.RandomState(20)
+    N, D = 300, 5
+    zero_at = np.array([7, 40, 41, 200])
+    out = dict(zero_at=zero_at)
+    fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        for S in (16, 100, 200):
+            Z, ths, E = logistic_problem(rng, N, D, S)
+            Z[zero_at] = 0.
+            th = ths + 0.5 * E
+            out['S%d_Z' % S], out['S%d_th' % S] = Z, th
+            for beta in (0.1, 0.2, 0.5):
+                prj = R.projector.BetaBlackBoxProjector(lambda n, w, p: th, S, R.lr.beta_likelihood, R.lr.log_likelihood, None)
+                phi = prj.project_f(Z, beta)
+                out['S%d_b%g_phi_const' % (S, beta)] = phi[zero_at]
+                out['S%d_b%g_norm_pos' % (S, beta)] = np.sqrt((phi ** 2).sum(axis=1)) > 0.
+            for beta in ((0.1,) if S != 100 else (0.1, 0.5)):
+                prj = R.projector.BetaBlackBoxProjector(lambda n, w, p: th, S, R.lr.beta_likelihood, R.lr.log_likelihood, None)
+                alg = R.bcores.BetaCoreset(Z, prj, opt_itrs=5, step_sched=lambda i: 0.5 / (1. + i), beta=beta, learn_beta=False, **fresh())
+                for m in range(4):
+                    quiet(alg.build, 1, m + 1)
+                    out['S%d_b%g_allw_%d' % (S, beta, m)] = alg.wts.copy()
+                    out['S%d_b%g_allidcs_%d' % (S, beta, m)] = alg.idcs.copy()
+    save('f20_logistic_beta_constant_rows', **out)
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])
     if only:
@@ -985,3 +1100,5 @@ if __name__ == '__main__':
     f16_bpsvi()
     f17_uniform_sampling_coreset()
     f18_zellner_gaussian_bpsvi_rand()
+    f19_logistic_greedy_vi()
+    f20_logistic_beta_constant_rows()

@@ -51,6 +51,17 @@ int main(int argc, char** argv) {
   ok &= isinf(bc_exp_tab(1000.0, tab));
   ok &= isnan(bc_exp_tab(NAN, tab));
   ok &= isnan(bc_log1p_exp_neg_tab(NAN, tab));
+  {
+    /* NaNs with payloads: whatever low mantissa bits reach the table index, it must stay within the 257 entries (under
+       ASan / UBSan in tests/test_sanitized_cpu.py an escape is a hard error, here the result must still be a NaN) */
+    const unsigned long long payloads[] = {0x7ff80000000001ffULL, 0x7ff8000000000100ULL, 0x7ff80000ffffffffULL, 0xfff8000012345678ULL,
+                                           0x7ff0000000000001ULL, 0x7ff8000000000440ULL};
+    for (unsigned k = 0; k < sizeof(payloads) / sizeof(payloads[0]); ++k) {
+      double x;
+      memcpy(&x, &payloads[k], 8);
+      ok &= isnan(bc_log1p_exp_neg_tab(x, tab)) && isnan(bc_exp_tab(x, tab));
+    }
+  }
   ok &= bc_log1p_exp_neg_tab(800.0, tab) == 0.0;
   ok &= bc_exp_tab_nonpos(-1e300, tab) == 0.0 && isnan(bc_exp_tab_nonpos(NAN, tab)) && bc_exp_tab_nonpos(0.0, tab) == 1.0 && bc_exp_tab_nonpos(-INFINITY, tab) == 0.0;
   ok &= bc_log1p_exp_neg_tab(20000.0, tab) == 0.0;

@@ -329,3 +329,74 @@ def test_fresh_state_per_instance(bc):
     a = bc.Coreset()
     b = bc.Coreset()
     assert a.wts is not b.wts and a.idcs is not b.idcs and a.pts is not b.pts
+
+
+# ---- BASELINE config 3's driver: the greedy-VI coresets on the logistic model (goldens F19 / F20, generated from the reference)
+def _f19_sampler(bc, sn, Z, E, th_fixed):
+    """fixed Theta, or the reference's own wiring (zellner_logreg/main.py:139-144) through bc.samplers.LogisticLaplaceSampler:
+    `laplace` / `lapdiag` with the golden's fixed normals, `laprng` on the global NumPy stream."""
+    if sn == 'fixed':
+        return lambda sz, w, pts: th_fixed
+
+    class FixedNormals:
+        def randn(self, n, d):
+            assert (n, d) == E.shape
+            return E
+    return bc.samplers.LogisticLaplaceSampler(np.zeros(Z.shape[1]), diag=(sn == 'lapdiag'),
+                                              rng=None if sn == 'laprng' else FixedNormals())
+
+
+@pytest.mark.parametrize('S', [37, 100])
+@pytest.mark.parametrize('sn,nm', [('fixed', 'bcores'), ('fixed', 'svi'), ('laplace', 'bcores'), ('laplace', 'svi'),
+                                   ('laprng', 'bcores'), ('laprng', 'svi'), ('lapdiag', 'bcores')])
+@pytest.mark.parametrize('fused', [True, False])
+def test_f19_logistic_greedy_vi_goldens(bc, S, sn, nm, fused):
+    """BetaCoreset (model_lr.py:81-86, beta = 0.1) and SparseVI (model_lr.py:72-79) with K1 / K2 / K3 on the device: rows
+    with |m| > 100 (the branch at model_lr.py:76, the overflow limits of :85), at S = 37 one all-zero data row whose constant
+    projection row keeps a residue of a few ulp -- one wrong bit in its constant would turn it into a NaN candidate that wins
+    every argmax.  Selections exact, weights within 1e-5 (scipy's BFGS is shared with the reference, not restated)."""
+    g = load_golden('f19_logistic_greedy_vi')
+    tag = 'S%d_' % S
+    Z, E, th_fixed = g[tag + 'Z'], g[tag + 'E'], g[tag + 'th_fixed']
+    beta, opt_itrs = float(g['beta']), int(g['opt_itrs'])
+    model = bc.likelihoods.LogisticRegression()
+    sched = lambda i: 0.5 / (1. + i)
+    np.random.seed(190)
+    sampler = _f19_sampler(bc, sn, Z, E, th_fixed)
+    if nm == 'bcores':
+        alg = bc.BetaCoreset(Z, bc.DeviceBetaProjector(sampler, S, model), opt_itrs=opt_itrs, step_sched=sched, beta=beta,
+                             learn_beta=False, fused_gradient=fused)
+    else:
+        alg = bc.SparseVICoreset(Z, bc.DeviceProjector(sampler, S, model), opt_itrs=opt_itrs, step_sched=sched, fused_gradient=fused)
+    for m in range(5):
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, g['%s%s_%s_allidcs_%d' % (tag, sn, nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s%s_%s_allw_%d' % (tag, sn, nm, m)], rtol=1e-5, atol=1e-12)
+    # (the last Theta: mu_w comes out of scipy's BFGS, which stops at a gradient norm of 1e-5 -- coreset weights that differ in
+    # the 10th digit move its stopping point by ~1e-6)
+    np.testing.assert_allclose(alg.ll_projector.samples, g['%s%s_%s_theta_last' % (tag, sn, nm)], rtol=1e-4, atol=2e-5)
+    if sn == 'laprng':
+        assert np.random.rand() == float(g['%s%s_%s_rng_after' % (tag, sn, nm)])      # the global stream stands where the reference's does
+
+
+@pytest.mark.parametrize('S', [16, 100, 200])
+def test_f20_logistic_beta_constant_rows(bc, S):
+    """Data rows z = 0 under the logistic beta-likelihood: S copies of c(beta), whose two np.power(2, .) the host layer
+    evaluates with NumPy itself (likelihoods.LogisticRegression.beta_value_at_zero) -- the device rows must carry the
+    reference's residues bit for bit, be zero-norm exactly where the reference's are, and BetaCoreset must take the same
+    NaN-candidate / residue-row decisions (S = 16: exact zeros; S = 100: beta = 0.5 keeps a residue; S = 200: all do)."""
+    g = load_golden('f20_logistic_beta_constant_rows')
+    Z, th, zero_at = g['S%d_Z' % S], g['S%d_th' % S], g['zero_at']
+    model = bc.likelihoods.LogisticRegression()
+    prj = bc.DeviceBetaProjector(lambda n, w, p: th, S, model)
+    for beta in (0.1, 0.2, 0.5):
+        phi = prj.project_f(Z, beta)
+        np.testing.assert_array_equal(phi.rows(zero_at), g['S%d_b%g_phi_const' % (S, beta)])
+        np.testing.assert_array_equal(phi.norms() > 0., g['S%d_b%g_norm_pos' % (S, beta)])
+    for beta in ((0.1,) if S != 100 else (0.1, 0.5)):
+        alg = bc.BetaCoreset(Z, bc.DeviceBetaProjector(lambda n, w, p: th, S, model), opt_itrs=5, step_sched=lambda i: 0.5 / (1. + i),
+                             beta=beta, learn_beta=False)
+        for m in range(4):
+            alg.build(1, m + 1)
+            np.testing.assert_array_equal(alg.idcs, g['S%d_b%g_allidcs_%d' % (S, beta, m)])
+            np.testing.assert_allclose(alg.wts, g['S%d_b%g_allw_%d' % (S, beta, m)], rtol=1e-5, atol=1e-12)

@@ -115,6 +115,12 @@ def test_fullsize_properties(env, cfg):
     # beta-projection at full size stays finite and centred
     phib = prj.project_f(data, 0.1)
     assert np.all(np.isfinite(phib.colsum())) and np.abs(phib.matvec(np.ones(S))).max() <= 1e-9
+    # ... and equals the oracle's beta-likelihood (model_lr.py:81-86 / model_neurlinr.py:102-110) on the same scattered rows
+    oracle_bl = M.logistic_beta_lik if kind == 'logistic' else (lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0))
+    with np.errstate(over='ignore'):
+        ref_b = C.project_f(oracle_bl, Zs, theta, 0.1)
+    got_b = phib.rows(pick)
+    assert np.abs(got_b - ref_b).max() <= 1e-10 * (1. + np.abs(ref_b).max())          # same bound as the log-likelihood rows above
     # a 200k-row prefix through device and oracle: identical selections
     ns = 200_000
     Zp = Z[:ns].cpu().numpy()

@@ -16,7 +16,8 @@ def bc():
 
 
 @pytest.mark.parametrize('n,d', [(1, 1), (5, 3), (17, 16), (300, 8), (1000, 63), (1000, 64), (999, 65), (2000, 95),
-                                 (2000, 96), (3000, 127), (3000, 128), (1500, 200), (700, 512)])
+                                 (2000, 96), (3000, 127), (3000, 128), (1500, 200), (700, 512),
+                                 (40, 2049), (60, 2100), (30, 4200)])     # D > 2048: X^T (w*y) needs several chunk trips (k_gram_reduce2)
 @pytest.mark.parametrize('weighted', [True, False])
 def test_gram_matches_numpy(bc, n, d, weighted):
     rng = np.random.RandomState(n + d)

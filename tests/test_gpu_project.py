@@ -419,6 +419,32 @@ def test_live_arrays_are_read_and_pins_are_loud(bc):
     assert Z.flags.writeable
 
 
+def test_view_data_is_copied_once_with_a_warning(bc):
+    """A view (Z[:n]) cannot be made read-only through its base, so it is not pinned -- but a coreset that re-projects all
+    rows per gradient must not upload them per gradient either: the rows are copied to the device once, with a UserWarning."""
+    rng = np.random.RandomState(35)
+    n, d, s = 6000, 5, 16
+    base = rng.randn(n + 100, d + 1)
+    Z = base[:n]
+    assert Z.base is base
+    th = rng.randn(s, d) * 0.3
+    prj = bc.DeviceProjector(fixed(th), s, bc.likelihoods.LinearRegression(1.0))
+    with pytest.warns(UserWarning, match='view'):
+        alg = bc.SparseVICoreset(Z, prj, opt_itrs=3)
+    assert alg._dev_data is not None and alg._dev_data.shape == (n, d + 1) and Z.flags.writeable
+    ref = bc.SparseVICoreset(Z.copy(), prj, opt_itrs=3)                 # an owning array: the pinned path
+    for m in range(3):
+        alg.build(1, m + 1)
+        ref.build(1, m + 1)
+    assert np.array_equal(alg.idcs, ref.idcs) and np.array_equal(alg.wts, ref.wts)
+    with pytest.warns(UserWarning, match='view'):
+        bc.BatchPSVICoreset(Z, prj, opt_itrs=2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        bc.SparseVICoreset(Z, prj, opt_itrs=3, pin_data=False)          # opting out: no copy, no warning
+
+
 def test_repeated_large_subsamples_do_not_grow_device_memory(bc):
     """BetaCoreset / SparseVI with n_subsample >= 4096 project a NEW data[sub_idcs] array per gradient step: its
     device copy and its Phi must be recycled, not accumulated."""

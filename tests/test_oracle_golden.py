@@ -510,3 +510,75 @@ def test_f18_zellner_gaussian_bpsvi():
     np.testing.assert_allclose(fkl, g['BPSVI_fkl'], rtol=1e-7)
     assert rng_after == float(g['BPSVI_rng_after'])
 
+
+
+# ---- F19 / F20: the greedy-VI coresets on the logistic model (BASELINE config 3) and its constant rows
+def _f19_sampler(sn, Z, E, th_fixed):
+    D = Z.shape[1]
+
+    def lap(diag, normals):
+        def sampler(wts, pts):
+            if pts.shape[0] == 0:
+                wts, pts = np.zeros(1), np.zeros((1, D))
+            mu, L, _ = M.logistic_laplace(wts, pts, np.zeros(D), diag)
+            return mu + normals(E.shape[0], D).dot(L.T)
+        return sampler
+    return dict(fixed=lambda wts, pts: th_fixed, laplace=lap(False, lambda n, d: E),
+                laprng=lap(False, lambda n, d: np.random.randn(n, d)), lapdiag=lap(True, lambda n, d: E))[sn]
+
+
+@pytest.mark.parametrize('S', [37, 100])
+@pytest.mark.parametrize('sn,nm', [('fixed', 'bcores'), ('fixed', 'svi'), ('laplace', 'bcores'), ('laplace', 'svi'),
+                                   ('laprng', 'bcores'), ('laprng', 'svi'), ('lapdiag', 'bcores')])
+def test_f19_logistic_greedy_vi(S, sn, nm):
+    g = load_golden('f19_logistic_greedy_vi')
+    tag = 'S%d_' % S
+    Z, E, th_fixed = g[tag + 'Z'], g[tag + 'E'], g[tag + 'th_fixed']
+    beta, opt_itrs = float(g['beta']), int(g['opt_itrs'])
+    sampler = _f19_sampler(sn, Z, E, th_fixed)
+    if nm == 'bcores':
+        proj = lambda pts, th: C.project_f(M.logistic_beta_lik, pts, th, beta)
+    else:
+        proj = lambda pts, th: C.project(M.logistic_loglik, pts, th)
+    np.random.seed(190)
+    with np.errstate(all='ignore'):
+        sampler(np.array([]), np.array([]))                 # the projector constructor draws once (projector.py:18,46)
+        alg = C.RefGreedyVI(Z, proj, sampler, opt_itrs, lambda i: 0.5 / (1. + i))
+        for m in range(5):
+            alg.build(1, m + 1)
+            np.testing.assert_array_equal(alg.idcs, g['%s%s_%s_allidcs_%d' % (tag, sn, nm, m)])
+            np.testing.assert_allclose(alg.wts, g['%s%s_%s_allw_%d' % (tag, sn, nm, m)], rtol=1e-9, atol=1e-13)
+    if sn == 'laprng':
+        assert np.random.rand() == float(g['%s%s_%s_rng_after' % (tag, sn, nm)])
+
+
+@pytest.mark.parametrize('S', [37, 100])
+@pytest.mark.parametrize('diag', [False, True])
+def test_f19_laplace_fit(S, diag):
+    g = load_golden('f19_logistic_greedy_vi')
+    tag = 'S%d_' % S
+    Z = g[tag + 'Z']
+    mu, L, Li = M.logistic_laplace(g[tag + 'lap_w'], Z[g[tag + 'lap_rows']], np.zeros(Z.shape[1]), diag)
+    np.testing.assert_allclose(mu, g['%slap%d_mu' % (tag, diag)], rtol=1e-9, atol=1e-12)
+    Lg = g['%slap%d_L' % (tag, diag)]
+    np.testing.assert_allclose(L, np.diag(Lg) if diag else Lg, rtol=1e-9, atol=1e-12)       # util/opt.py:27-29 returns vectors
+    Lig = g['%slap%d_Li' % (tag, diag)]
+    np.testing.assert_allclose(Li, np.diag(Lig) if diag else Lig, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('S', [16, 100, 200])
+def test_f20_logistic_beta_constant_rows(S):
+    g = load_golden('f20_logistic_beta_constant_rows')
+    Z, th, zero_at = g['S%d_Z' % S], g['S%d_th' % S], g['zero_at']
+    with np.errstate(all='ignore'):
+        for beta in (0.1, 0.2, 0.5):
+            phi = C.project_f(M.logistic_beta_lik, Z, th, beta)
+            np.testing.assert_array_equal(phi[zero_at], g['S%d_b%g_phi_const' % (S, beta)])
+            np.testing.assert_array_equal(np.sqrt((phi ** 2).sum(axis=1)) > 0., g['S%d_b%g_norm_pos' % (S, beta)])
+        for beta in ((0.1,) if S != 100 else (0.1, 0.5)):
+            alg = C.RefGreedyVI(Z, lambda pts, t: C.project_f(M.logistic_beta_lik, pts, t, beta), lambda w, p: th, 5,
+                                lambda i: 0.5 / (1. + i))
+            for m in range(4):
+                alg.build(1, m + 1)
+                np.testing.assert_array_equal(alg.idcs, g['S%d_b%g_allidcs_%d' % (S, beta, m)])
+                np.testing.assert_allclose(alg.wts, g['S%d_b%g_allw_%d' % (S, beta, m)], rtol=1e-9, atol=1e-13)

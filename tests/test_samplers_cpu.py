@@ -1,0 +1,64 @@
+"""Host logic of bc.samplers (no GPU): the logistic drivers' Laplace sampler against golden F19 (the reference's
+get_laplace, util/opt.py:9-33 == zellner_logreg/main.py:86-111) and the prefetch contract."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+@pytest.mark.parametrize('S', [37, 100])
+@pytest.mark.parametrize('diag', [False, True])
+def test_logistic_laplace_matches_reference(S, diag):
+    from beta_cores_amd.samplers import logistic_laplace
+    g = load_golden('f19_logistic_greedy_vi')
+    tag = 'S%d_' % S
+    Z = g[tag + 'Z']
+    mu, L, Li = logistic_laplace(g[tag + 'lap_w'], Z[g[tag + 'lap_rows']], np.zeros(Z.shape[1]), diag)
+    # scipy's BFGS is shared, not restated: same routine, same inputs -> the reference's numbers to rounding
+    np.testing.assert_allclose(mu, g['%slap%d_mu' % (tag, diag)], rtol=1e-9, atol=1e-12)
+    Lg, Lig = g['%slap%d_L' % (tag, diag)], g['%slap%d_Li' % (tag, diag)]
+    np.testing.assert_allclose(L, np.diag(Lg) if diag else Lg, rtol=1e-9, atol=1e-12)    # util/opt.py:27-29 hands back vectors
+    np.testing.assert_allclose(Li, np.diag(Lig) if diag else Lig, rtol=1e-9, atol=1e-12)
+
+
+def test_logistic_laplace_sampler_prior_and_stream():
+    """An empty coreset gives the prior N(0, I) (main.py:140-142); the normals come from the given stream, one S x D block
+    per call, and a prefetched block is the one the next call uses."""
+    from beta_cores_amd.samplers import LogisticLaplaceSampler
+    D, S = 5, 7
+    smp = LogisticLaplaceSampler(np.zeros(D), rng=np.random.RandomState(3))
+    th = smp(S, np.array([]), np.array([]))
+    ref = np.random.RandomState(3)
+    e0 = ref.randn(S, D)
+    np.testing.assert_allclose(th, e0, rtol=0, atol=1e-7)          # mode 0 (to BFGS's tolerance), LSig = I
+    smp.prefetch()
+    smp.prefetch()                                                 # second one is a no-op
+    th1 = smp(S, np.array([]), np.array([]))
+    np.testing.assert_allclose(th1, ref.randn(S, D), rtol=0, atol=1e-7)
+    th2 = smp(S, np.array([]), np.array([]))
+    np.testing.assert_allclose(th2, ref.randn(S, D), rtol=0, atol=1e-7)
+
+
+def test_prefetched_block_of_another_shape_is_an_error():
+    from beta_cores_amd.samplers import LogisticLaplaceSampler
+    smp = LogisticLaplaceSampler(np.zeros(4), rng=np.random.RandomState(0))
+    smp(6, np.array([]), np.array([]))
+    smp.prefetch()
+    with pytest.raises(RuntimeError, match='prefetched'):
+        smp(9, np.array([]), np.array([]))
+
+
+def test_logistic_beta_constant_at_zero_is_numpys():
+    """likelihoods.LogisticRegression hands K1 the beta-likelihood's value at m = 0 computed by NumPy's array power --
+    the bits the reference's N x S evaluation has for a data row z = 0 (golden F20 holds such rows: their centred value
+    is c - mean(S copies of c), recomputed here from the constant alone)."""
+    from beta_cores_amd.likelihoods import LogisticRegression
+    g = load_golden('f20_logistic_beta_constant_rows')
+    for S in (16, 100, 200):
+        for beta in (0.1, 0.2, 0.5):
+            c = LogisticRegression.beta_value_at_zero(beta)
+            row = np.full((1, S), c)
+            row -= row.mean(axis=1)[:, np.newaxis]
+            np.testing.assert_array_equal(row[0], g['S%d_b%g_phi_const' % (S, beta)][0])
+    p = LogisticRegression().params(0.1)
+    assert p.shape == (2,) and p[0] == 0.1 and p[1] == LogisticRegression.beta_value_at_zero(0.1)
