@@ -46,6 +46,8 @@ def parse():
                     help='greedy iterations of the CPU baseline on ALL rows (its K1 runs row-chunked; SURVEY 8d allows a cap of 20)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the fp64-sweep leg and the other BASELINE configs')
+    ap.add_argument('--no-host', action='store_true', help='skip the from-host leg (ndarray -> upload + K1 pipelined -> first iteration)')
+    ap.add_argument('--detail', default=None, help='write the full (verbose) result object to this file instead of stderr')
     ap.add_argument('--proj-reps', type=int, default=5)
     ap.add_argument('--proj-warmup', type=int, default=3)
     return ap.parse_args()
@@ -95,6 +97,44 @@ def posterior_samples(bc, data, d, s, comm):
     mu, L, _ = bc.weighted_post(np.zeros(d), np.eye(d), 1.0, data, None, comm=comm)
     E = np.random.default_rng(40).standard_normal((s, d))
     return mu + E.dot(L.T)
+
+
+def sig(x, n=4):
+    """n significant digits (the JSON line is meant to be short enough to survive in the driver's record)"""
+    if x is None or isinstance(x, (bool, str)):
+        return x
+    if isinstance(x, int):
+        return x
+    x = float(x)
+    if x != x or x in (float('inf'), float('-inf')):
+        return None                     # (strict JSON has no NaN / inf)
+    if x == 0.:
+        return x
+    return float('%.*g' % (n, x))
+
+
+def kentry(name, ms, nbytes, flops, launches):
+    """One line of roofline.kernels: average launch time (HIP events on the launch stream), algorithmic bytes and flops per
+    launch, and what they make of the HBM / fp64-MFMA peaks."""
+    e = {'k': name, 'ms': sig(ms), 'GB': sig(nbytes / 1e9), 'GF': sig(flops / 1e9) if flops else 0, 'n': int(launches),
+         'hbm': sig(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None}
+    if flops:
+        e['mfma'] = sig(flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF) if ms > 0 else None
+    return e
+
+
+def newest_traffic(N, D, S, world, key):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process): the
+    newest profiles/rNN_pmc_traffic.json that was collected on exactly this workload shape."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')), reverse=True):
+        try:
+            tj = json.load(open(path))
+            if tj['config'] == {'N': N, 'D': D, 'S': S, 'n_gpus': world} and key in tj:
+                return tj[key]['traffic_bytes_per_launch'], 'profiles/' + os.path.basename(path)
+        except Exception:
+            pass
+    return None, None
 
 
 def fp64_sweep_leg(bc, ctx, alg, cls, barrier, n_local, S, args):
@@ -221,7 +261,15 @@ def other_configs(torch, bc, ctx, dev, barrier, no_cpu=False):
     res.append(_k1_entry('configs[2] logistic N=1M D=128', n, d, d, S, ms, 'log-likelihood (model_lr.py:72-79)'))
     ms, _ = _time_k1(ctx, lambda: prj.project_f(data, 0.1), barrier)
     res.append(_k1_entry('configs[2] logistic N=1M D=128', n, d, d, S, ms, 'beta-likelihood, beta = 0.1 (model_lr.py:81-86)'))
-    del prj, data, Zl
+    del prj
+    # ... and config 3's actual driver: BetaCoreset on the beta-tempered sigmoid score with the Laplace sampler
+    # (a) the reference's wiring to the letter: scipy's BFGS finds the Laplace mode -- hundreds of ms per sampler call at weights
+    # N/M, so the short form; (b) the same posterior through bc.samplers' Newton solver (same unique mode, ~1e-6 apart in theta)
+    beta_legs += beta_coreset_leg(bc, ctx, barrier, data, 'configs[2] Zellner logistic N=1M D=128', kind='logistic', grads=4, sizes=(100,),
+                                  extras=False, oracle_rows=None if no_cpu else 50_000, Z_host=None if no_cpu else Zl[:50_000].cpu().numpy())
+    beta_legs += beta_coreset_leg(bc, ctx, barrier, data, 'configs[2] Zellner logistic N=1M D=128', kind='logistic', grads=20,
+                                  solver='newton')
+    del data, Zl
     # config 5: neural-linear last layer, N = 2M, D = 512 random ReLU features; K4 on all rows, then K1
     n, d = 2_000_000, 512
     g.manual_seed(50)
@@ -297,17 +345,22 @@ class NativeCallTimer:
         return 1e3 * sum(v for k, v in self.acc.items() if k not in names)
 
 
-def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, opt_seed=7, oracle_rows=None, Z_host=None):
+def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, opt_seed=7, oracle_rows=None, Z_host=None,
+                     kind='linreg', solver='bfgs', extras=True):
     """The beta-Cores gradient loop (bcores.py:141-150, BetaCoreset._optimize with n_subsample_* = None, learn_beta = False,
     beta = 0.1): per gradient  sampler (weighted_post on the <= M coreset rows, model_linreg.py:25-34) -> K1 over ALL data
     rows (store-free: only vecs.sum(axis=0) is needed) -> column sums -> M x S algebra -> one ADAM step on the host.
     The coreset is pre-initialised with M rows (as the reference's drivers do with wts / idcs / pts,
     zellner_neural_linear/main.py:147-149) and `_optimize()` runs `grads` gradients."""
     n, dz = data.shape
-    d = dz - 1
+    d = dz - 1 if kind == 'linreg' else dz
     S = 100
     th0, Sig0inv = np.zeros(d), np.eye(d)
     out = []
+    # kind = 'logistic' (BASELINE configs[2]): the beta-tempered sigmoid score (model_lr.py:81-86) with the reference's own
+    # sampler wiring, the Laplace approximation of the weighted coreset posterior (zellner_logreg/main.py:139-144,
+    # util/opt.py:9-33 -> bc.samplers.LogisticLaplaceSampler: scipy's BFGS + a D x D Cholesky on the <= M coreset rows, host)
+    model = bc.likelihoods.LinearRegression(1.0) if kind == 'linreg' else bc.likelihoods.LogisticRegression()
     for M in sizes:
         rng = np.random.RandomState(opt_seed + M)
         idcs = np.sort(rng.choice(n, M, replace=False)).astype(np.int64)
@@ -317,7 +370,10 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
 
         # zellner_neural_linear/main.py:119-124 (the weighted_post form) as bc.samplers.LinregPosteriorSampler: the same
         # arithmetic and draws; its prefetch() draws the next call's normals while the GPU works on the current gradient
-        base_sampler = bc.samplers.LinregPosteriorSampler(th0, Sig0inv, 1.0, rng=srng, ctx=ctx)
+        if kind == 'linreg':
+            base_sampler = bc.samplers.LinregPosteriorSampler(th0, Sig0inv, 1.0, rng=srng, ctx=ctx)
+        else:
+            base_sampler = bc.samplers.LogisticLaplaceSampler(th0, diag=False, rng=srng, solver=solver)
 
         class TimedSampler:
             prefetch = staticmethod(base_sampler.prefetch)
@@ -329,7 +385,7 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
                 t_samp[1] += 1
                 return r
         sampler_w = TimedSampler()
-        prj = bc.DeviceBetaProjector(sampler_w, S, bc.likelihoods.LinearRegression(1.0), ctx=ctx)
+        prj = bc.DeviceBetaProjector(sampler_w, S, model, ctx=ctx)
         sched = lambda i: 0.01 / (1. + i)
 
         def make(fused):
@@ -347,11 +403,16 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
             return r
         prj.vi_gradient = timed_call
         ctx.enable_timing(0)
-        alg.opt_itrs = 5
+        alg.opt_itrs = 5 if extras else 2
         alg._optimize()                                    # warm-up: buffers, code objects
         alg.opt_itrs = grads
         barrier()
         t_samp[0], t_samp[1], t_call[0], t_call[1] = 0.0, 0, 0.0, 0
+        if not extras:
+            # short form (a sampler that takes hundreds of ms per call): the kernel timer runs inside the timed pass -- its event
+            # pairs (~11 us of stream time) vanish next to such a gradient -- and the comparison passes are skipped
+            ctx.enable_timing(1)
+            ctx.kernel_time_reset()
         t0 = time.perf_counter()
         alg._optimize()
         barrier()
@@ -359,31 +420,35 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
         samp_ms = 1e3 * t_samp[0] / max(t_samp[1], 1)
         call_ms = 1e3 * t_call[0] / max(t_call[1], 1)
         fused_calls = t_call[1]
-        # instrumented pass: HIP events between the phases of the native call (they cost stream time: not the timed pass)
-        ctx.enable_timing(1)
-        ctx.kernel_time_reset()
-        ctx.phase_times(reset=True)
-        t0 = time.perf_counter()
-        alg._optimize()
-        barrier()
-        t_instr = (time.perf_counter() - t0) / grads
-        ph, ncalls = ctx.phase_times(reset=True)
+        ph, t_instr, t_mat = {}, float('nan'), float('nan')
+        if extras:
+            # instrumented pass: HIP events between the phases of the native call (they cost stream time: not the timed pass)
+            ctx.enable_timing(1)
+            ctx.kernel_time_reset()
+            ctx.phase_times(reset=True)
+            t0 = time.perf_counter()
+            alg._optimize()
+            barrier()
+            t_instr = (time.perf_counter() - t0) / grads
+            ph, ncalls = ctx.phase_times(reset=True)
+            ph = {k: v / max(ncalls, 1) for k, v in ph.items()}
         k1_ms, k1_n = ctx.kernel_time(1)
         ctx.enable_timing(0)
         prj.vi_gradient = orig
-        ph = {k: v / max(ncalls, 1) for k, v in ph.items()}
         k1 = k1_ms / max(k1_n, 1)
-        # the general path for comparison: every gradient materialises Phi (8*N*S more bytes) and reads back its column sums
-        alg_m = make(False)
-        alg_m.opt_itrs = 3
-        alg_m._optimize()
-        gm = max(10, grads // 5)
-        alg_m.opt_itrs = gm
-        barrier()
-        t0 = time.perf_counter()
-        alg_m._optimize()
-        barrier()
-        t_mat = (time.perf_counter() - t0) / gm
+        alg_m = None
+        if extras:
+            # the general path for comparison: every gradient materialises Phi (8*N*S more bytes) and reads back its column sums
+            alg_m = make(False)
+            alg_m.opt_itrs = 3
+            alg_m._optimize()
+            gm = max(10, grads // 5)
+            alg_m.opt_itrs = gm
+            barrier()
+            t0 = time.perf_counter()
+            alg_m._optimize()
+            barrier()
+            t_mat = (time.perf_counter() - t0) / gm
         # one whole build step (select: materialised K1 + K3 sweep, then `grads` gradients)
         alg.opt_itrs = grads
         barrier()
@@ -398,7 +463,8 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
              'k1_store_free_kernel_ms': k1,
              'non_k1_fraction': max(0.0, 1.0 - k1 / (1e3 * t_fused)),
              'native_gradient_calls': fused_calls,
-             'breakdown_ms': {'sampler (host LAPACK + K4 on the M coreset rows)': samp_ms,
+             'model': kind if kind == 'linreg' else '%s/%s' % (kind, solver),
+             'breakdown_ms': {'sampler (host LAPACK + K4 on the M coreset rows; logistic: Laplace fit, scipy BFGS)': samp_ms,
                               'native gradient call, wall (Theta upload, K1 x2, column sums, M x S algebra, one sync)': call_ms,
                               'ADAM step + Python glue': max(0.0, 1e3 * t_fused - samp_ms - call_ms),
                               'gpu_phases_inside_the_call (HIP events, separate instrumented pass)': ph,
@@ -426,10 +492,14 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
         def samp(w, p):
             if p.shape[0] == 0:
                 w, p = np.zeros(1), np.zeros((1, dz))
-            mu, L, _ = models_ref.linreg_weighted_post(th0, Sig0inv, 1.0, p, w)
+            if kind == 'linreg':
+                mu, L, _ = models_ref.linreg_weighted_post(th0, Sig0inv, 1.0, p, w)
+            else:
+                mu, L, _ = models_ref.logistic_laplace(w, p, th0, False)
             return mu + srng.randn(S, d).dot(L.T)
         g_cpu = 4
-        ref = coreset_ref.RefGreedyVI(Zs, lambda p_, th: coreset_ref.project_f(lambda z, t, b: models_ref.linreg_beta_lik(z, t, b, 1.0), p_, th, 0.1),
+        blik = (lambda z, t, b: models_ref.linreg_beta_lik(z, t, b, 1.0)) if kind == 'linreg' else models_ref.logistic_beta_lik
+        ref = coreset_ref.RefGreedyVI(Zs, lambda p_, th: coreset_ref.project_f(blik, p_, th, 0.1),
                                       samp, g_cpu, lambda i: 0.01 / (1. + i), wts=np.full(M, float(oracle_rows) / M), idcs=idc, pts=Zs[idc])
         t0 = time.perf_counter()
         ref.optimize()
@@ -440,6 +510,87 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
                                      'sample': 'NumPy oracle (oracle/coreset_ref.RefGreedyVI.optimize) on the first %d of %d rows, '
                                                '%d gradients; K1 on the host is linear in the rows' % (oracle_rows, n, g_cpu)}})
     return out
+
+
+def from_host_leg(bc, ctx, barrier, Z_host, theta, S, model, cls, f_tr, args):
+    """What a drop-in user sees: `HilbertCoreset(ndarray, projector)` (hilbert.py:11-17) from a HOST array.  Wall time from the
+    ndarray to (a) the rows resident in HBM, (b) the first greedy iteration, (c) an M = 100 coreset; the upload goes through the
+    pinned-staging uploader (csrc/bc_upload.hip) and K1 runs on chunk c while chunks c+1.. are on the wire
+    (bc_project_from_host).  `plain`: the same array through ONE hipMemcpyAsync from pageable memory (BC_UPLOAD_THREADS=0)."""
+    import gc
+    n, dz = Z_host.shape
+    gb = 8.0 * n * dz / 1e9
+    res = {'GB': sig(gb)}
+
+    def timed_upload(threads):
+        old = os.environ.get('BC_UPLOAD_THREADS')
+        if threads is not None:
+            os.environ['BC_UPLOAD_THREADS'] = str(threads)
+        try:
+            barrier()
+            t0 = time.perf_counter()
+            dd = bc.DeviceData(Z_host, ctx=ctx)
+            barrier()
+            return time.perf_counter() - t0, dd
+        finally:
+            if threads is not None:
+                if old is None:
+                    os.environ.pop('BC_UPLOAD_THREADS', None)
+                else:
+                    os.environ['BC_UPLOAD_THREADS'] = old
+    t_up, dd = timed_upload(None)          # first call: allocates the staging buffers, copy streams, events
+    del dd
+    t_up, dd = timed_upload(None)
+    del dd
+    gc.collect()
+    # the pieces: the device allocation by itself, and the copy into an existing buffer (direct = hipMemcpyAsync from the
+    # pageable array, staged = 8 host threads through pinned staging buffers)
+    barrier()
+    t0 = time.perf_counter()
+    slot = bc.DeviceData.slot(dz, cap_rows=n, ctx=ctx)
+    barrier()
+    t_alloc = time.perf_counter() - t0
+    t_copy = {}
+    for nm, thr in (('direct', '0'), ('staged8', '8'), ('direct', '0')):
+        old = os.environ.get('BC_UPLOAD_THREADS')
+        os.environ['BC_UPLOAD_THREADS'] = thr
+        try:
+            barrier()
+            t0 = time.perf_counter()
+            slot.update(Z_host)
+            barrier()
+            t_copy[nm] = time.perf_counter() - t0
+        finally:
+            if old is None:
+                os.environ.pop('BC_UPLOAD_THREADS', None)
+            else:
+                os.environ['BC_UPLOAD_THREADS'] = old
+    del slot
+    gc.collect()
+    res.update({'upload_ms': sig(1e3 * t_up), 'upload_GBps': sig(gb / t_up), 'alloc_ms': sig(1e3 * t_alloc),
+                'copy_direct_GBps': sig(gb / t_copy['direct']), 'copy_staged8_GBps': sig(gb / t_copy['staged8'])})
+    prj = bc.DeviceProjector(lambda k, w, p: theta, S, model, ctx=ctx)
+    M = 100
+    for rep in range(2):                   # the second pass is the one reported (buffers and code objects exist)
+        barrier()
+        t0 = time.perf_counter()
+        alg = bc.HilbertCoreset(Z_host, prj, snnls=cls)
+        barrier()
+        t_init = time.perf_counter() - t0
+        alg.build(1, M)
+        barrier()
+        t_first = time.perf_counter() - t0
+        alg.build(M - 1, M)
+        barrier()
+        t_m = time.perf_counter() - t0
+        tr = alg.snnls._eng.trace()[0]
+        if rep == 0:
+            del alg
+            gc.collect()
+    k = min(len(tr), len(f_tr))
+    res.update({'construct_ms': sig(1e3 * t_init), 'first_iter_ms': sig(1e3 * t_first), 'M100_ms': sig(1e3 * t_m),
+                'same_trace_as_resident_run': bool(np.array_equal(tr[:k], f_tr[:k])), 'compared_steps': int(k)})
+    return res
 
 
 def main():
@@ -639,61 +790,96 @@ def main():
 
     pname = 'int8' if pref == 8 else 'fp%d' % pref
     kname = 'k_sweep_i8' if pref == 8 else 'k_sweep_f%d' % pref
-    out = None
+    algn = 'GIGA' if args.alg == 'giga' else 'dot'
+    out, detail = None, {}
+    kernels, loops = [], []
     if rank == 0:
         ach = k3_bytes / (k3_ms_per * 1e-3) / 1e9 if k3_ms_per > 0 else 0.0
-        # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
-        # this process); only quoted when it was collected on exactly this workload shape
-        traffic, traffic_src = None, None
-        for tname in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-            try:
-                tj = json.load(open(os.path.join(ROOT, 'profiles', tname)))
-                key = ('k_sweep_i8' if pref == 8 else 'k_sweep_f%d' % pref) if pref else 'k_sweep'
-                if tj['config'] == {'N': N, 'D': D, 'S': S, 'n_gpus': world} and args.alg == 'giga' and key in tj:
-                    traffic = tj[key]['traffic_bytes_per_launch']
-                    traffic_src = 'profiles/%s: %s' % (tname, tj[key]['correction'])
-                    break
-            except Exception:
-                pass
+        traffic, traffic_src = (None, None)
+        if args.alg == 'giga':
+            traffic, traffic_src = newest_traffic(N, D, S, world, (kname if pref else 'k_sweep'))
+        # ---- roofline.kernels: every kernel this run timed, one short entry each (name | avg ms | GB, GF per launch | fractions)
+        kernels.append(kentry('K1 %s linreg N=%d D=%d (headline shape)' % ('k_project_r' if n_local >= 262144 else 'k_project', n_local, D),
+                              k1_ms_per, k1_bytes, k1_flops, k1_n))
+        k4e = k4_entry(n_local, D, max(k4_warm_ms or (k4_ms / max(k4_n, 1)), 1e-9))
+        kernels.append(dict(kentry('K4 k_gram+reduce N=%d D=%d w=1 %s' % (n_local, D, 'warm' if k4_warm_ms else 'cold'),
+                                   k4e['kernel_ms (gram + reduce)'], k4e['bytes_per_launch'],
+                                   k4e['executed_tflops'] * 1e9 * k4e['kernel_ms (gram + reduce)'], 3 if k4_warm_ms else k4_n),
+                            sym=sig(k4e['symmetry_factor'])))
         out = {
             'metric': 'greedy coreset iterations/sec', 'value': args.steps / t_steps, 'unit': 'iterations/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * t_steps / args.steps,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'Zellner linear regression N=%d D=%d S=%d, %s via HilbertCoreset (BASELINE configs[3])'
-                                   % (N, D, S, args.alg.upper()),
+            'config': {'workload': 'Zellner linreg N=%d D=%d S=%d, %s via HilbertCoreset (BASELINE configs[3])' % (N, D, S, args.alg.upper()),
                        'N': N, 'D': D, 'S': S, 'M': total, 'rows_per_gpu': n_local, 'parallelism': 'rows/%d' % world,
                        'exchange': exchange_kind,
                        'sweep': '%s pre-filter + exact fp64 rescoring (bit-identical selections)' % pname if pref else 'fp64'},
-            'roofline': {'kernel': ('%s<%s> (K3 %s pre-filter sweep; winners rescored in fp64, selections '
-                                    'identical to the fp64 sweep)' % (kname, 'GIGA' if args.alg == 'giga' else 'dot', pname)
-                                    if pref else 'k_sweep<%s> (K3 score+argmax)' % ('GIGA' if args.alg == 'giga' else 'dot')),
-                         'fp64_formulation_bytes_per_launch': 8.0 * n_local * S + 8.0 * n_local,
+            'roofline': {'kernel': ('%s<%s>: K3 %s mirror sweep, winners rescored in fp64' % (kname, algn, pname)) if pref
+                                   else 'k_sweep<%s>: K3 score+argmax' % algn,
                          'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'bytes_per_launch': k3_bytes, 'avg_launch_ms': k3_ms_per, 'launches': args.steps,
-                         'launches_timed': k3_n},
-            'projection': {'points_dims_per_s': N * D / t_proj, 'ms': 1e3 * t_proj, 'kernel_ms': k1_ms_per,
-                           'roofline_hbm': {'achieved': k1_bytes / (k1_ms_per * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                                            'unit': 'GB/s', 'frac': k1_bytes / (k1_ms_per * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            'bytes_per_launch': k1_bytes},
-                           'roofline_fp64_mfma': {'achieved': k1_flops / (k1_ms_per * 1e-3) / 1e12,
-                                                  'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                                                  'frac': k1_flops / (k1_ms_per * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}},
-            'posterior_gram': dict(k4_entry(n_local, D, max(k4_ms / max(k4_n, 1), 1e-9)), wall_ms=1e3 * t_post,
-                                   note='K4 X^T W X on fp64 MFMA, all local rows, w = 1 (sampler set-up, cold first launch)',
-                                   warm=(k4_entry(n_local, D, k4_warm_ms) if k4_warm_ms else None)),
+                         'bytes_per_launch': k3_bytes, 'fp64_formulation_bytes_per_launch': 8.0 * n_local * S + 8.0 * n_local,
+                         'avg_launch_ms': k3_ms_per, 'launches': args.steps, 'launches_timed': k3_n,
+                         'kernels': kernels, 'loops': loops},
             'prefilter': dict(zip(('sweeps', 'candidates_rescored', 'fp64_fallbacks'), alg.snnls._eng.prefilter_stats())),
-            'step_stages': step_diag,
-            'solver_init_ms': 1e3 * t_init, 'solver_init': init_parts, 'setup_s': t_setup,
+            'step_stages': {'sweep': sig(stage_ms['sweep']), 'rescore': sig(stage_ms['rescoring_or_local_winner']),
+                            'gather': sig(stage_ms['all_gather']), 'finish': sig(stage_ms['finish']),
+                            'instr_ms_per_step': sig(1e3 * t_diag / diag_steps), 'rccl_ranks': rccl_ranks,
+                            'transport': exchange_kind.split(' (')[0]},
+            'solver_init_ms': sig(1e3 * t_init),
+            'solver_init': {'phi_alloc': sig(init_parts['phi_alloc (bc_phi_create)']), 'k1': sig(init_parts['K1 kernel (HIP events)']),
+                            'stats': sig(init_parts['bc_project host side + column-sum / norm statistics (two small kernels, one sync)']),
+                            'solver_create': sig(init_parts['solver create: mirror allocation + k_build_i8 + state (bc_snnls_create)']),
+                            'other_native': sig(init_parts['other native calls']), 'python': sig(init_parts['python / collectives'])},
+            'projection': {'points_dims_per_s': sig(N * D / t_proj, 6), 'ms': sig(1e3 * t_proj), 'kernel_ms': sig(k1_ms_per)},
             'coreset': {'size': int(len(idcs)), 'error': err, 'failed_steps': int(st_tr.sum())},
         }
+        detail.update({'solver_init': init_parts, 'step_stages': step_diag, 'setup_s': t_setup, 'posterior_gram_cold_wall_ms': 1e3 * t_post,
+                       'posterior_gram': k4e})
 
     # ---------------- the SURVEY 8(d) formulation, driver-timed too: the exact fp64 sweep (8*N*S + 8*N bytes per step)
     if rank == 0 and world == 1 and not args.no_extra:
-        out['fp64_sweep'] = fp64_sweep_leg(bc, ctx, alg, cls, barrier, n_local, S, args)
-        out['other_configs'], beta2 = other_configs(torch, bc, ctx, dev, barrier, no_cpu=args.no_cpu)
-        # the beta-Cores gradient loop (BetaCoreset._optimize, bcores.py:141-150) on configs 2 and 4
-        out['beta_coreset'] = beta2 + beta_coreset_leg(bc, ctx, barrier, data, 'configs[3] Zellner linreg N=%d D=%d' % (N, D))
+        f64 = fp64_sweep_leg(bc, ctx, alg, cls, barrier, n_local, S, args)
+        kernels.append(dict(kentry('K3 k_sweep<%s> fp64 Phi streamed once per step N=%d (SURVEY 8d formulation)' % (algn, n_local),
+                                   f64['avg_launch_ms'], f64['bytes_per_launch'], 0, f64['steps']),
+                            it_s=sig(f64['iterations_per_s']), same_sel=f64['same_selections_as_prefiltered_run']))
+        detail['fp64_sweep'] = f64
+        oc, beta2 = other_configs(torch, bc, ctx, dev, barrier, no_cpu=args.no_cpu)
+        detail['other_configs'] = oc
+        for e in oc:
+            nm = 'K1 %s %s' % (e['config'].split(' ', 1)[1], e['model'].split(' (')[0].split(',')[0])
+            kernels.append(kentry(nm, e['kernel_ms'], e['roofline_hbm']['bytes_per_launch'], 2.0 * e['N'] * e['D'] * e['S'], 8))
+            for wn, k4 in (e.get('posterior_gram_K4') or {}).items():
+                kernels.append(dict(kentry('K4 k_gram+reduce N=%d D=%d %s' % (e['N'], e['D'], wn), k4['kernel_ms (gram + reduce)'],
+                                           k4['bytes_per_launch'], k4['executed_tflops'] * 1e9 * k4['kernel_ms (gram + reduce)'], 3),
+                                    sym=sig(k4['symmetry_factor'])))
+        # the beta-Cores gradient loop (BetaCoreset._optimize, bcores.py:141-150) on configs 2, 3 (logistic + Laplace sampler) and 4
+        beta_all = beta2 + beta_coreset_leg(bc, ctx, barrier, data, 'configs[3] Zellner linreg N=%d D=%d' % (N, D))
+        detail['beta_coreset'] = beta_all
+        cpu_loops = []
+        for e in beta_all:
+            if 'cpu_baseline' in e:
+                c = e['cpu_baseline']
+                cpu_loops.append({'loop': 'bcores ' + c['config'].split(' ', 1)[0], 'rows': c['rows'], 'M': c['M'], 'ms_grad': sig(c['ms_per_gradient']),
+                                  'ms_grad_scaled_to_N': sig(c['ms_per_gradient_scaled_to_N'])})
+                continue
+            bd = e['breakdown_ms']
+            samp = [v for k, v in bd.items() if k.startswith('sampler')][0]
+            call = [v for k, v in bd.items() if k.startswith('native gradient call')][0]
+            loops.append({'loop': 'bcores %s %s N=%d D=%d M=%d' % (e['config'].split(' ', 1)[0], e['model'], e['N'], e['D'], e['M']),
+                          'ms_grad': sig(e['ms_per_gradient']), 'k1_ms': sig(e['k1_store_free_kernel_ms']), 'samp_ms': sig(samp),
+                          'call_ms': sig(call), 'non_k1': sig(e['non_k1_fraction'], 3), 'mat_ms_grad': sig(e['materialising_path_ms_per_gradient']),
+                          'build_ms': sig([v for k, v in e.items() if k.startswith('build_step_ms')][0])})
+            if e['M'] == 100 and not e['model'].endswith('/bfgs'):
+                kernels.append(kentry('K1 store-free beta-%s N=%d D=%d' % (e['model'].split('/')[0], e['N'], e['D']), e['k1_store_free_kernel_ms'],
+                                      e['roofline_hbm']['bytes_per_launch'], 2.0 * e['N'] * e['D'] * e['S'], e['gradients']))
+        detail['cpu_loops'] = cpu_loops
+
+    # ---------------- the host path (hilbert.py:11 takes an ndarray): upload + K1 pipelined, wall time to the first iteration
+    Z_host = None
+    if rank == 0 and world == 1 and not args.no_host:
+        Z_host = Z.cpu().numpy()
+        out['roofline']['from_host'] = from_host_leg(bc, ctx, barrier, Z_host, theta, S, model, cls, f_tr, args)
 
     # ---------------- CPU baseline (rank 0, N=1 launch only): the NumPy oracle
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -725,7 +911,7 @@ def main():
         t0 = time.perf_counter()
         phi_ref = np.empty((N, S))
         for a in range(0, N, CHUNK):
-            zc = Z[a:a + CHUNK].cpu().numpy()
+            zc = Z_host[a:a + CHUNK] if Z_host is not None else Z[a:a + CHUNK].cpu().numpy()
             for b in range(0, zc.shape[0], 100_000):
                 blk = zc[b:b + 100_000]
                 phi_ref[a + b:a + b + blk.shape[0]] = coreset_ref.project(ll, blk, theta)
@@ -741,15 +927,15 @@ def main():
         full_match = bool(np.array_equal(rsel_full, f_tr[:len(rsel_full)]))
         out['cpu_baseline'] = {
             'value': args.cpu_full_iters / t_cit, 'unit': 'iterations/s', 'cores': int(thr), 'kind': 'port',
-            'sample': 'ALL %d rows (same data, same Theta): NumPy oracle K1 in row chunks of 100 000 (%.1f s incl. the '
-                      'device-to-host copy of Z), GIGA init (%.1f s), then %d greedy iterations (%.1f s; the oracle makes the '
-                      'reference\'s five N x S passes per iteration)' % (N, t_cproj, t_cinit, args.cpu_full_iters, t_cit),
-            'projection_points_dims_per_s': N * D / t_cproj, 'projection_s': t_cproj, 'init_s': t_cinit,
+            'sample': 'ALL %d rows, same data and Theta: oracle K1 row-chunked, GIGA init, %d greedy iterations (5 NxS passes each)'
+                      % (N, args.cpu_full_iters),
+            'projection_s': sig(t_cproj), 'init_s': sig(t_cinit), 'iters_s': sig(t_cit), 'projection_points_dims_per_s': sig(N * D / t_cproj),
+            'first_iter_s': sig(t_cproj + t_cinit + t_cit / args.cpu_full_iters),
+            'M100_s_extrapolated': sig(t_cproj + t_cinit + 100 * t_cit / args.cpu_full_iters),
             'host_cpus': os.cpu_count(), 'numpy': np.__version__,
-            'selections_equal_device_run': 'ok: the oracle\'s %d selections on all rows equal the device run\'s first %d'
-                                           % (len(rsel_full), len(rsel_full)) if full_match else 'MISMATCH',
-            'parity_on_sample': ('ok: %d selections identical, weights within 1e-5 (first %d rows, device vs oracle)'
-                                 % (len(rsel), ns)) if parity else 'MISMATCH',
+            'selections_equal_device_run': 'ok: %d of %d on all rows' % (len(rsel_full), len(rsel_full)) if full_match else 'MISMATCH',
+            'parity_on_sample': ('ok: %d selections identical, weights within 1e-5 (first %d rows)' % (len(rsel), ns)) if parity else 'MISMATCH',
+            'loops': detail.get('cpu_loops', []),
         }
         if not parity or not full_match:
             out['parity_failure'] = {'device_sample': dsel.tolist(), 'oracle_sample': rsel.tolist(),
@@ -758,8 +944,16 @@ def main():
     sys.stdout.flush()
     os.dup2(_stdout_fd, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out, separators=(',', ':')))
         sys.stdout.flush()
+        # everything the compact line leaves out (per-phase splits, every roofline object in full): a file when asked for,
+        # otherwise one tagged line on stderr -- never stdout, which carries exactly one line
+        dj = json.dumps({'line': out, 'detail': detail})
+        if args.detail:
+            with open(args.detail, 'w') as f:
+                f.write(dj + '\n')
+        else:
+            sys.stderr.write('BENCH_DETAIL ' + dj + '\n')
     os.dup2(2, 1)                         # teardown chatter goes to stderr again
     parity_failed = bool(out and 'parity_failure' in out)
     if world > 1 or force_xchg:

@@ -1,6 +1,7 @@
 // libbeta_cores: context, Phi storage (row tiles), layout kernels, K2 (column
 // sums / norms) and K3 (fused score + argmax sweep).  gfx950 only.
 #include "bc_internal.h"
+#include "bc_layout.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -349,7 +350,7 @@ int bc_phi_alloc(bc_ctx* ctx, int64_t n_rows, int32_t s, int64_t row_offset, bc_
   const size_t nt = (size_t)p->cap_tiles;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_tiles = take(stats_only ? 0 : nt * s * BC_TILE * sizeof(double));
+  const size_t o_tiles = take(stats_only ? 0 : bc_lay_phi_doubles((long long)nt, s) * sizeof(double));
   const size_t o_norms = take(stats_only ? 0 : nt * BC_TILE * sizeof(double));
   const size_t o_colsum = take((size_t)s * sizeof(double));
   const size_t o_tpart = take(nt * s * sizeof(double));

@@ -337,9 +337,10 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   if (p->prec == 8 && (phi->s + 3) / 4 > BC_IMAXG - BC_IU) p->prec = 16;      // the digit table of k_sweep_i8 holds S <= ~1260
   p->ptile = p->prec == 16 ? BC_HTILE : (p->prec == 8 ? BC_ITILE : BC_PTILE);
   p->sp = p->prec == 16 ? (phi->s + BC_HU - 1) / BC_HU * BC_HU : phi->s;
-  p->sp4 = ((phi->s + 3) / 4 + BC_IU - 1) / BC_IU * BC_IU;
+  p->sp4 = bc_lay_i8_sp4(phi->s);
   p->ptiles = (phi->n_rows + p->ptile - 1) / p->ptile;
   if (p->ptiles < 1) p->ptiles = 1;
+  static_assert(BC_ITILE == BC_LAY_ITILE && BC_IU == BC_LAY_IU && BC_TILE == BC_LAY_TILE, "bc_layout.h mirrors these");
   // one wave per tile and a grid-stride loop: size the grid so that all its waves are resident at once
   // (4 per SIMD) and every wave walks the same number of tiles -- a 2x over-subscribed grid left waves with
   // 2 or 3 tiles each (79% balance at 10M rows)
@@ -357,7 +358,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   // the fp64 tiles cover ntiles*128 rows; the unit rows cover ptiles*ptile >= that, reads past the fp64 tiles are masked by `live`
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_u = take(p->prec == 8 ? (size_t)p->ptiles * p->sp4 * BC_ITILE * sizeof(int)
+  const size_t o_u = take(p->prec == 8 ? bc_lay_i8_words(p->ptiles, p->sp4) * sizeof(int)
                                        : (size_t)p->ptiles * p->sp * p->ptile * (p->prec == 16 ? sizeof(_Float16) : sizeof(float)));
   const size_t o_ub = take(p->prec != 32 ? 0 : (size_t)p->ptiles * p->ptile * sizeof(float));
   const size_t o_rq = take(p->prec == 8 ? (size_t)p->ptiles * BC_ITILE * sizeof(bc_hq2) : 0);

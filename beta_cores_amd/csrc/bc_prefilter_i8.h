@@ -27,7 +27,8 @@
 // a tile with more than four such rows hands over all of its rows.
 #pragma once
 
-#define BC_ITILE 256
+#include "bc_layout.h"
+#define BC_ITILE 256      /* == BC_LAY_ITILE (bc_layout.h) */
 #ifndef BC_IU
 #define BC_IU 5          // k-groups per batch (5 KiB in flight per wave and buffer)
 #endif
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
   // q with |q| <= 127 is a valid digit.  (Holding the row in registers between the two passes instead of re-reading it:
   // 4.24 ms, slower.)
   const double inr = 1. / nr;
-  const double* p = tiles + (size_t)(r >> 7) * S * BC_TILE + (r & (BC_TILE - 1));
+  const double* p = tiles + bc_lay_phi_elem(r, 0, S);      // (only dereferenced for live rows)
   double mx = 0.;
   bool has_nan = false;
   if (live)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ til
   const double scale = (double)(float)hs;
   const double iscale = ok ? 1. / scale : 0.;
   double err2 = 0.;
-  int* q = u8 + (size_t)t * SP4 * BC_ITILE + threadIdx.x;
+  int* q = u8 + bc_lay_i8_word(t, 0, threadIdx.x, SP4);
   for (int g = 0; g < SP4; ++g) {
     unsigned w = 0;
 #pragma unroll
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void k_build_i8_r(const double* __restrict__ t
   const bool live = r < n_rows && norms[r < n_rows ? r : 0] != 0.;
   const double inr = live ? 1. / norms[r] : 0.;       // (one reciprocal per row: see k_build_i8)
   // rows past the end have no tile behind them when the number of 128-row tiles is odd: they read row 0 instead (and are dead)
-  const long long rr = r < n_rows ? r : 0;
-  const double* p = tiles + (size_t)(rr >> 7) * S * BC_TILE + (rr & (BC_TILE - 1));
+  const long long rr = bc_lay_i8_src_row(r, n_rows);
+  const double* p = tiles + bc_lay_phi_elem(rr, 0, S);
   double ur[SMAX];
 #pragma unroll
   for (int k = 0; k < SMAX; ++k) ur[k] = (k < S && n_rows > 0) ? p[(size_t)k * BC_TILE] : 0.;      // (uniform condition)
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void k_build_i8_r(const double* __restrict__ t
   const double scale = (double)(float)hs;
   const double iscale = ok ? 1. / scale : 0.;
   double err2 = 0.;
-  int* q = u8 + (size_t)t * SP4 * BC_ITILE + threadIdx.x;
+  int* q = u8 + bc_lay_i8_word(t, 0, threadIdx.x, SP4);
 #pragma unroll
   for (int g = 0; g < SMAX / 4; ++g) {
     if (g < SP4) {                                        // (uniform)

@@ -16,6 +16,7 @@
 //   model_linreg.py:4-10 / model_neurlinr.py:90-97,102-110 / model_lr.py:72-86 / gaussian.py:7-15,34-62
 #include "bc_internal.h"
 #include "bc_np_exp.h"
+#include "bc_layout.h"
 #include "bc_k1_math.h"
 #include <cmath>
 #include <cstdlib>
@@ -1445,10 +1446,9 @@ extern "C" int bc_project_from_host(bc_ctx* ctx, const double* z_host, int64_t n
   const int rgrid = project_r_grid(ctx, pl, phi, PROJ_FULL);
   phi->part_rows = rgrid > 0 ? (int64_t)rgrid * 8 : phi->ntiles;
   // chunk = a multiple of (8 * rgrid) 32-row groups for the resident kernel, of 128-row tiles for the staged one; ~128 MiB
-  const int64_t unit = rgrid > 0 ? (int64_t)rgrid * 8 * 32 : (int64_t)BC_TILE * 512;
-  int64_t chunk_rows = (((int64_t)128 << 20) / ((int64_t)dz * 8) + unit - 1) / unit * unit;
+  const int64_t unit = bc_lay_chunk_unit(rgrid);
   const char* env = getenv("BC_PIPE_CHUNK_ROWS");      // tests: force several chunks on small inputs
-  if (env && atoll(env) > 0) chunk_rows = (atoll(env) + unit - 1) / unit * unit;
+  const int64_t chunk_rows = bc_lay_chunk_rows(dz, unit, env ? atoll(env) : 0);
   bool first = true;
   bc_chunk_hook hook = [&](int64_t, int64_t row0, int64_t rows, hipEvent_t landed) -> int {
     if (landed) BC_HIP(hipStreamWaitEvent(ctx->stream, landed, 0));

@@ -1,17 +1,22 @@
 // bc_upload.hip -- host rows -> HBM, pipelined.
 //
 // The reference's API takes host ndarrays (hilbert.py:11, bcores.py:44), so for a drop-in user the first thing that
-// happens to a 10 GB data set is its upload.  One hipMemcpyAsync from pageable memory stages through the runtime's own
-// bounce buffer with a single copying thread and leaves the PCIe link mostly idle.  Here several host threads copy
-// disjoint row chunks into pinned staging buffers (two per thread, 8 MiB each) and queue the DMA of each sub-chunk on
-// a copy stream of their own, so the host-side memcpy of sub-chunk k+1 runs beside the DMA of sub-chunk k and the
-// link sees as many queues as there are threads.  A caller-supplied hook is called on the calling thread for every
-// chunk IN ROW ORDER as soon as the chunk's last DMA is queued, with the event that marks its arrival: K1 is launched
-// behind that event on the compute stream (bc_project_from_host, bc_project.hip) and projects chunk c while chunks
-// c+1.. are still on the wire.
+// happens to a 10 GB data set is its upload.  Rows travel in CHUNKS on a copy stream of the library's own, and a
+// caller-supplied hook is called on the calling thread for every chunk IN ROW ORDER as soon as the chunk's copy is queued,
+// with the event that marks its arrival: K1 is launched behind that event on the compute stream (bc_project_from_host,
+// bc_project.hip) and projects chunk c while chunks c+1.. are still on the wire.
 //
-// Ownership: the host pointer is only read during the call (every byte has been copied into staging when the call
-// returns); staging buffers, streams and events live in the context and are reused.
+// Two ways of moving a chunk (measured on the MI355X boxes of this pool with tools/h2d_bench.hip and
+// tools/upload_probe.py, profiles/r04_notes.md: the link delivers 56-57 GB/s from pinned memory):
+//   direct (default, BC_UPLOAD_THREADS unset or 0): hipMemcpyAsync straight from the caller's pageable memory.  The
+//     ROCm runtime of this image moves pageable memory at the link rate (50-56 GB/s for 4-10 GB arrays), so nothing is
+//     gained by staging it ourselves -- the chunking alone buys the overlap with K1.
+//   staged (BC_UPLOAD_THREADS = T >= 1): T host threads copy disjoint chunks into pinned staging buffers (two per thread,
+//     8 MiB each) and queue the DMA of each sub-chunk on a copy stream of their own.  45-52 GB/s here (the memcpy into
+//     staging competes with the DMA for the same memory controllers); kept for hosts whose pageable path is slow.
+//
+// Ownership: the host pointer is only read during the call (every byte has been handed to the runtime or copied into
+// staging when the call returns); streams, staging buffers and events live in the context and are reused.
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -37,9 +42,7 @@ static int uploader_threads() {
     const int t = atoi(env);
     return t < 0 ? 0 : (t > 32 ? 32 : t);
   }
-  unsigned hc = std::thread::hardware_concurrency();
-  int t = hc >= 16 ? 8 : (hc >= 8 ? 4 : 2);
-  return t;
+  return 0;       // direct mode (see the head of this file)
 }
 
 // chunking of a plain upload (no per-chunk consumer): enough chunks to keep every copy thread busy, none below 4 MiB
@@ -79,11 +82,11 @@ static int uploader_get(bc_ctx* ctx, int nthreads, size_t nchunks, bc_uploader**
     u->sub_bytes = (size_t)8 << 20;
     const char* env = getenv("BC_UPLOAD_SUB_MB");
     if (env && atoi(env) > 0) u->sub_bytes = (size_t)atoi(env) << 20;
-    for (int t = 0; t < nthreads; ++t) {
+    for (int t = 0; t < (nthreads > 0 ? nthreads : 1); ++t) {
       hipStream_t s;
       BC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
       u->streams.push_back(s);
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < (nthreads > 0 ? 2 : 0); ++k) {
         void* p = nullptr;
         BC_HIP(hipHostMalloc(&p, u->sub_bytes, hipHostMallocDefault));
         u->staging.push_back(p);
@@ -112,22 +115,36 @@ int bc_upload_rows(bc_ctx* ctx, const double* src, double* dst_dev, int64_t n_ro
   const size_t row_bytes = (size_t)dz * sizeof(double);
   const size_t total = (size_t)n_rows * row_bytes;
   int nthreads = uploader_threads();
-  if (nthreads == 0 || (total < ((size_t)32 << 20) && !on_chunk)) {
-    // small inputs (and BC_UPLOAD_THREADS=0): the plain copy; the hook then sees one chunk that has already landed
+  if (!on_chunk && (nthreads == 0 || total < ((size_t)32 << 20))) {
+    // nobody consumes chunks: one copy on the compute stream (the runtime moves pageable memory at the link rate)
     BC_HIP(hipMemcpyAsync(dst_dev, src, total, hipMemcpyHostToDevice, ctx->stream));
     BC_HIP(hipStreamSynchronize(ctx->stream));     // the host buffer is only borrowed for the call
-    if (on_chunk) {
-      int64_t c = 0;
-      for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows, ++c) {
-        const int64_t rows = (n_rows - r0) < chunk_rows ? (n_rows - r0) : chunk_rows;
-        int rc = (*on_chunk)(c, r0, rows, nullptr);
-        if (rc) return rc;
-      }
-    }
     return BC_OK;
   }
   if (chunk_rows <= 0) chunk_rows = n_rows;
   const int64_t nchunks = (n_rows + chunk_rows - 1) / chunk_rows;
+  if (nthreads == 0) {
+    // direct mode: chunk c goes out on the copy stream, the hook queues its consumer behind `landed`, and while that runs
+    // on the compute stream this thread is already handing chunk c+1 to the runtime
+    bc_uploader* u = nullptr;
+    int rc = uploader_get(ctx, 0, (size_t)nchunks, &u);
+    if (rc) return rc;
+    hipStream_t st = u->streams[0];
+    for (int64_t c = 0; c < nchunks; ++c) {
+      const int64_t r0 = c * chunk_rows;
+      const int64_t rows = (n_rows - r0) < chunk_rows ? (n_rows - r0) : chunk_rows;
+      hipError_t e = hipMemcpyAsync(reinterpret_cast<char*>(dst_dev) + (size_t)r0 * row_bytes,
+                                    reinterpret_cast<const char*>(src) + (size_t)r0 * row_bytes, (size_t)rows * row_bytes,
+                                    hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipEventRecord(u->landed[(size_t)c], st);
+      if (e != hipSuccess) { (void)hipStreamSynchronize(st); return bc_hip_fail(e, "chunked upload", __FILE__, __LINE__); }
+      rc = (*on_chunk)(c, r0, rows, u->landed[(size_t)c]);
+      if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    }
+    // a pageable source may still be read by the runtime until the copies have drained: the buffer is only borrowed
+    BC_HIP(hipStreamSynchronize(st));
+    return BC_OK;
+  }
   if (nthreads > nchunks) nthreads = (int)nchunks;
   bc_uploader* u = nullptr;
   {

@@ -134,16 +134,54 @@ def _lr_hess_log_joint(z, th, wts, diag):
     return np.tile(-np.eye(th.shape[1]), (th.shape[0], 1, 1)) + (wts[:, np.newaxis, np.newaxis, np.newaxis] * hl).sum(axis=0)
 
 
-def logistic_laplace(wts, Z, mu0, diag=False, rng=None):
+def _lr_mode_newton(Zw, ww, mu0, max_iter=200):
+    """The mode of the weighted log-joint by damped Newton steps.  The log-joint is strictly concave (the N(0, I) prior puts
+    its Hessian below -I), so the maximiser is unique: it is the point scipy's BFGS converges to, reached here in ~10
+    iterations of D x D linear algebra instead of hundreds of rank-two updates (410 -> ~1 ms per sampler call at M = 100,
+    D = 128 with weights N/M: the BFGS iteration count grows with the posterior's condition number)."""
+    d = mu0.shape[0]
+    mu = np.array(mu0, dtype=np.float64)
+
+    def value(th):
+        m = -Zw.dot(th)
+        return -(ww * (np.maximum(m, 0.) + np.log1p(np.exp(-np.fabs(m))))).sum() - 0.5 * d * np.log(2. * np.pi) - 0.5 * th.dot(th)
+    f = value(mu)
+    eye = np.eye(d)
+    for _ in range(max_iter):
+        m = -Zw.dot(mu)
+        p = 0.5 * (1. + np.tanh(0.5 * m))                     # e^m / (1 + e^m), overflow-free
+        g = -mu + Zw.T.dot(ww * p)
+        H = eye + (Zw * (ww * p * (1. - p))[:, np.newaxis]).T.dot(Zw)      # minus the Hessian: positive definite
+        step = sl.cho_solve(sl.cho_factor(H, lower=True, check_finite=False), g, check_finite=False)
+        t, dec = 1., g.dot(step)
+        while True:                                           # backtracking: Newton's full step once near the mode
+            cand = mu + t * step
+            fc = value(cand)
+            if fc >= f + 1e-4 * t * dec or t < 1e-10:
+                break
+            t *= 0.5
+        mu, f = cand, fc
+        if np.fabs(t * step).max() <= 1e-13 * (1. + np.fabs(mu).max()) or dec <= 1e-24 * (1. + abs(f)):
+            break
+    return mu
+
+
+def logistic_laplace(wts, Z, mu0, diag=False, rng=None, solver='bfgs'):
     """`get_laplace` (examples/zellner_logreg/main.py:86-111 == bayesiancoresets/util/opt.py:9-33): (mu, LSig, LSigInv) of
     the Laplace approximation N(mu, LSig LSig^T) to the posterior of the rows Z with weights wts; the mode comes from
     scipy.optimize.minimize's default method started at mu0 (third-party arithmetic, shared with the reference, not
     restated), a failing optimisation restarts from a perturbed mu0 up to ten times.  diag=True returns the driver's
-    diagonal MATRICES (main.py:105-108; util/opt.py:27-29 has vectors, which its own caller cannot multiply with)."""
+    diagonal MATRICES (main.py:105-108; util/opt.py:27-29 has vectors, which its own caller cannot multiply with).
+    solver='newton' (not the reference's call, same unique mode): see _lr_mode_newton; BFGS stops at a gradient norm of
+    1e-5, i.e. ~1e-6 from the mode in theta, which is how far the two answers are apart."""
     trials = 10
     Zw = Z[wts > 0, :]
     ww = wts[wts > 0]
-    while True:
+    if solver == 'newton':
+        mu = _lr_mode_newton(Zw, ww, mu0)
+    elif solver != 'bfgs':
+        raise ValueError("solver must be 'bfgs' (the reference's scipy.optimize.minimize call) or 'newton'")
+    while solver == 'bfgs':
         try:
             res = minimize(lambda mu: -_lr_log_joint(Zw, mu, ww)[0], mu0, jac=lambda mu: -_lr_grad_log_joint(Zw, mu, ww)[0, :])
         except Exception:
@@ -153,12 +191,19 @@ def logistic_laplace(wts, Z, mu0, diag=False, rng=None):
             if trials <= 0:
                 raise RuntimeError('logistic_laplace: the mode search failed ten times')     # (the reference dies on `res` here)
             continue
+        mu = res.x
         break
-    mu = res.x
     if diag:
         sq = np.sqrt(-_lr_hess_log_joint(Zw, mu, ww, True)[0, :])
         return mu, np.diag(1. / sq), np.diag(sq)
-    LSigInv = np.linalg.cholesky(-_lr_hess_log_joint(Zw, mu, ww, False)[0, :, :])
+    if solver == 'newton':
+        # (the reference's Hessian expression builds M x D x D temporaries -- 13 MB and ~10 ms at M = 100, D = 128; the same
+        # matrix as one BLAS product, equal to rounding)
+        m = -Zw.dot(mu)
+        p = 0.5 * (1. + np.tanh(0.5 * m))
+        LSigInv = np.linalg.cholesky(np.eye(mu.shape[0]) + (Zw * (ww * p * (1. - p))[:, np.newaxis]).T.dot(Zw))
+    else:
+        LSigInv = np.linalg.cholesky(-_lr_hess_log_joint(Zw, mu, ww, False)[0, :, :])
     LSig = sl.solve_triangular(LSigInv, np.eye(LSigInv.shape[0]), lower=True, overwrite_b=True, check_finite=False)
     return mu, LSig, LSigInv
 
@@ -168,9 +213,9 @@ class LogisticLaplaceSampler(_PosteriorSampler):
     (mu_w, LSig_w) the Laplace fit of the weighted coreset rows pts = y*x (model_lr.py:29); an empty coreset gives the
     prior N(0, I).  `mu0` is the optimiser's starting point (the drivers pass the prior mean), `diag` their `graddiag`."""
 
-    def __init__(self, mu0, diag=False, rng=None):
+    def __init__(self, mu0, diag=False, rng=None, solver='bfgs'):
         super().__init__(rng)
-        self.mu0, self.diag = np.asarray(mu0, dtype=np.float64), bool(diag)
+        self.mu0, self.diag, self.solver = np.asarray(mu0, dtype=np.float64), bool(diag), solver
         self._shape = None
 
     def _dim(self):
@@ -180,5 +225,6 @@ class LogisticLaplaceSampler(_PosteriorSampler):
         d = self.mu0.shape[0]
         if pts.shape[0] == 0:
             wts, pts = np.zeros(1), np.zeros((1, d))
-        muw, LSigw, _ = logistic_laplace(np.asarray(wts, dtype=np.float64), np.atleast_2d(pts), self.mu0, self.diag, rng=self._rng)
+        muw, LSigw, _ = logistic_laplace(np.asarray(wts, dtype=np.float64), np.atleast_2d(pts), self.mu0, self.diag, rng=self._rng,
+                                         solver=self.solver)
         return muw + self._normals(n, d).dot(LSigw.T)

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
                   (void*)bc_snnls_set_flags, (void*)bc_snnls_trace, (void*)bc_weighted_gram, (void*)bc_comm_load, (void*)bc_comm_unique_id, (void*)bc_comm_create,
                   (void*)bc_comm_destroy, (void*)bc_comm_info, (void*)bc_comm_all_gather, (void*)bc_comm_selftest, (void*)bc_comm_precheck, (void*)bc_comm_abort, (void*)bc_comm_sum_doubles, (void*)bc_phi_colsum_all,
                   (void*)bc_project_colsum, (void*)bc_vi_gradient, (void*)bc_vi_gradient_begin, (void*)bc_vi_gradient_end, (void*)bc_ctx_phase_times, (void*)bc_comm_rank_order_sum_selftest, (void*)bc_weighted_gram_host, (void*)bc_ctx_timing_classes,
-                  (void*)bc_snnls_bind_comm};
+                  (void*)bc_snnls_bind_comm, (void*)bc_project_from_host};
   printf("abi %d, %d entry points\n", bc_version(), (int)(sizeof(syms) / sizeof(syms[0])));
   if (bc_ctx_sync(NULL) != BC_INVALID_ARGUMENT || bc_snnls_build(NULL, 1, NULL) != BC_INVALID_ARGUMENT) return 2;
   if (argc < 2 || strcmp(argv[1], "run") != 0) return 0;
@@ -59,6 +59,17 @@ int main(int argc, char** argv) {
   double b2[S];
   CHECK(bc_project_colsum(ctx, data, BC_MODEL_LINREG_LL, theta, S, sig, 1, NULL, b2));    /* store-free K1: the same bits */
   if (memcmp(b, b2, sizeof(b)) != 0) { printf("store-free column sums differ from the materialised ones\n"); return 4; }
+  {
+    /* the host-array entry point (upload + K1 pipelined): the same column sums, bit for bit */
+    bc_data* data3 = NULL;
+    bc_phi* phi3 = NULL;
+    double b3[S];
+    CHECK(bc_project_from_host(ctx, z, N, D + 1, BC_MODEL_LINREG_LL, theta, S, sig, 1, 0, &data3, &phi3));
+    CHECK(bc_phi_colsum(phi3, b3));
+    if (memcmp(b, b3, sizeof(b)) != 0) { printf("bc_project_from_host column sums differ from bc_project's\n"); return 5; }
+    CHECK(bc_phi_destroy(phi3));
+    CHECK(bc_data_destroy(data3));
+  }
   double nsum = 0.0;
   int64_t nzero = 0;
   CHECK(bc_phi_norm_stats(phi, &nzero, &nsum));

@@ -62,3 +62,29 @@ def test_logistic_beta_constant_at_zero_is_numpys():
             np.testing.assert_array_equal(row[0], g['S%d_b%g_phi_const' % (S, beta)][0])
     p = LogisticRegression().params(0.1)
     assert p.shape == (2,) and p[0] == 0.1 and p[1] == LogisticRegression.beta_value_at_zero(0.1)
+
+
+@pytest.mark.parametrize('S', [37, 100])
+def test_newton_mode_is_the_reference_mode(S):
+    """solver='newton' reaches the same (unique) mode as the reference's BFGS call: within BFGS's own stopping tolerance of
+    the golden, and with a smaller gradient than the golden's point has."""
+    from beta_cores_amd.samplers import logistic_laplace, _lr_grad_log_joint
+    g = load_golden('f19_logistic_greedy_vi')
+    tag = 'S%d_' % S
+    Z = g[tag + 'Z']
+    w, rows = g[tag + 'lap_w'], Z[g[tag + 'lap_rows']]
+    mu, L, Li = logistic_laplace(w, rows, np.zeros(Z.shape[1]), False, solver='newton')
+    np.testing.assert_allclose(mu, g[tag + 'lap0_mu'], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(L, g[tag + 'lap0_L'], rtol=1e-4, atol=2e-6)
+    gn = np.abs(_lr_grad_log_joint(rows[w > 0], mu, w[w > 0])).max()
+    gb = np.abs(_lr_grad_log_joint(rows[w > 0], g[tag + 'lap0_mu'], w[w > 0])).max()
+    assert gn <= 1e-12 and gn <= gb
+    # a peaked posterior (weights N/M, the shape of a pre-initialised coreset): Newton still lands on BFGS's answer
+    rng = np.random.RandomState(5)
+    Zb = rng.randn(60, 12) * np.where(rng.rand(60) < 0.5, 1., -1.)[:, None]
+    wb = np.full(60, 1e4)
+    mu_n = logistic_laplace(wb, Zb, np.zeros(12), False, solver='newton')[0]
+    mu_b = logistic_laplace(wb, Zb, np.zeros(12), False, solver='bfgs')[0]
+    np.testing.assert_allclose(mu_n, mu_b, rtol=1e-4, atol=1e-6)
+    with pytest.raises(ValueError):
+        logistic_laplace(w, rows, np.zeros(Z.shape[1]), False, solver='lbfgs')

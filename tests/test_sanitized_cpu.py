@@ -1,0 +1,102 @@
+"""Sanitized CPU leg (`-fsanitize=address,undefined` for the host-side unit tests): the host-compiled
+restatements (NumPy's pairwise sum, SVML exp, the K1 epilogue's table-driven bodies) run under ASan + UBSan, and so does a
+host model of the ragged-end index arithmetic (tests/layout_harness.c over csrc/bc_layout.h, which the kernels and the
+allocation code use too): every address the int8 mirror builders and the chunked projection form for
+n in 1..1025, odd tile counts and the row shards of shard_bounds(10M, 1/2/4/8) must stay inside allocations of exactly the
+device sizes -- the class of round 3's GPU fault, caught here without a GPU."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ['-fsanitize=address,undefined', '-fno-sanitize-recover=all', '-fno-omit-frame-pointer', '-g']
+ENV = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+
+
+def build(tmp_path, src, extra=()):
+    exe = str(tmp_path / (os.path.splitext(src)[0] + '_san'))
+    cmd = ['gcc', '-O1', '-mfma', '-ffp-contract=off', '-Wall', '-Werror'] + SAN + list(extra) + \
+          ['-I', os.path.join(ROOT, 'beta_cores_amd', 'csrc'), os.path.join(ROOT, 'tests', src), '-o', exe, '-lm']
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def run_clean(exe, args, timeout=600):
+    res = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=timeout, env=ENV)
+    assert 'AddressSanitizer' not in res.stderr and 'runtime error' not in res.stderr, res.stderr[-3000:]
+    return res
+
+
+def test_k1_math_bodies_under_asan_ubsan(tmp_path):
+    """bc_k1_math.h incl. NaNs with payloads: their mantissa bits must not index past the 257-entry log table."""
+    res = run_clean(build(tmp_path, 'k1_math_harness.c'), ['200000'])
+    assert res.returncode == 0 and 'special ok' in res.stdout, res.stdout + res.stderr
+
+
+def test_np_sum_restatement_under_asan_ubsan(tmp_path):
+    import numpy as np
+    rng = np.random.RandomState(4)
+    ns = list(range(1, 600)) + [4096, 4097, 8191, 8192, 8193, 65_537, 100_000, 300_007]
+    rows = [(float(n), c, float(np.full(n, c).sum())) for n in ns for c in (rng.randn(), -0.6931471805599453)]
+    t = np.array(rows)
+    path = str(tmp_path / 't.bin')
+    t.tofile(path)
+    res = run_clean(build(tmp_path, 'np_sum_harness.c'), [path, str(t.shape[0])])
+    assert res.returncode == 0 and 'mismatches=0' in res.stdout, res.stdout + res.stderr
+
+
+def test_np_exp_restatement_under_asan_ubsan(tmp_path):
+    """(bit equality with np.exp is test_np_exp_cpu's business and needs an AVX-512 NumPy; here only: no out-of-range table
+    index, shift or conversion for any argument class, specials included)"""
+    import numpy as np
+    rng = np.random.RandomState(1)
+    x = np.concatenate([rng.uniform(-745, 710, 50_000), rng.normal(0, 1e-3, 10_000),
+                        np.array([0., -0., 1e-300, -1e-300, -707.7, 707.7, -745., 800., -1e308, 1e308, np.inf, -np.inf, np.nan])])
+    with np.errstate(over='ignore'):
+        y = np.exp(x)
+    path = str(tmp_path / 'd.bin')
+    with open(path, 'wb') as f:
+        f.write(x.tobytes())
+        f.write(y.tobytes())
+    res = run_clean(build(tmp_path, 'np_exp_harness.c'), [path, str(x.shape[0])])
+    assert 'mismatches=' in res.stdout, res.stdout + res.stderr
+
+
+def shard_sizes():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bc_dist', os.path.join(ROOT, 'beta_cores_amd', 'dist.py'))
+    src = open(os.path.join(ROOT, 'beta_cores_amd', 'dist.py')).read()
+    # shard_bounds is pure Python; pick it out without importing the package (no GPU library here)
+    ns = {}
+    start = src.index('def shard_bounds')
+    end = src.index('\ndef ', start + 10) if '\ndef ' in src[start + 10:] else len(src)
+    end2 = src.index('\nclass ', start) if '\nclass ' in src[start:] else len(src)
+    exec('import numpy as np\nTILE_ROWS = 128\n' + src[start:min(end, end2)], ns)
+    sizes = set()
+    for N in (10_000_000, 1_000_000, 2_000_000, 1234567):
+        for G in (1, 2, 3, 4, 8):
+            b = ns['shard_bounds'](N, G)
+            assert b[0] == 0 and b[-1] == N and all(b[i] <= b[i + 1] for i in range(G))
+            assert all(b[i] % 128 == 0 for i in range(G)), 'shards start on tile boundaries'
+            sizes.update(int(b[i + 1] - b[i]) for i in range(G))
+    return sorted(sizes)
+
+
+def test_index_arithmetic_host_model(tmp_path):
+    exe = build(tmp_path, 'layout_harness.c')
+    small = list(range(0, 300)) + [128 * k + j for k in (3, 4, 5, 6, 7, 8, 9, 15, 234, 235) for j in (-1, 0, 1)] + [1025, 65537]
+    res = subprocess.run([exe] + [str(n) for n in small], capture_output=True, text=True, timeout=900, env=ENV)
+    assert res.returncode == 0 and res.stdout.startswith('ok '), (res.stdout + res.stderr)[-3000:]
+    big = [n for n in shard_sizes() if n > 70000] + [262144, 262145, 300003, 327697, 600001]
+    res = subprocess.run([exe] + [str(n) for n in big], capture_output=True, text=True, timeout=900, env=ENV)
+    assert res.returncode == 0 and res.stdout.startswith('ok '), (res.stdout + res.stderr)[-3000:]
+
+
+def test_model_catches_the_round3_fault(tmp_path):
+    """The same replay with the clamp of bc_lay_i8_src_row removed (what the first one-pass builder did) must trip ASan on an
+    odd tile count: the model is only worth something if it fails when the arithmetic is wrong."""
+    exe = build(tmp_path, 'layout_harness.c', extra=['-DBC_LAY_TEST_NO_CLAMP'])
+    res = subprocess.run([exe, str(128 * 234 + 1)], capture_output=True, text=True, timeout=300, env=ENV)
+    assert res.returncode != 0 and 'AddressSanitizer' in res.stderr
