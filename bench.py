@@ -377,6 +377,7 @@ def beta_coreset_leg(bc, ctx, barrier, data, name, sizes=(10, 100), grads=50, op
 
         class TimedSampler:
             prefetch = staticmethod(base_sampler.prefetch)
+            scope = staticmethod(base_sampler.scope)
 
             def __call__(self, k, wts, pts_):
                 t0 = time.perf_counter()

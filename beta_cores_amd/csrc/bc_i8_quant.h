@@ -1,0 +1,106 @@
+// bc_i8_quant.h -- quantisation of the int8 pre-filter's sweep vector(s), shared by the two places that can do it:
+//   * the single-block step kernels (bc_snnls.hip: dev_prep), which PRODUCE the vectors of the next sweep and now also
+//     leave their digits behind -- once per step, 1.3 KB;
+//   * the prologue of k_sweep_i8 (bc_prefilter_i8.h), where every block of every sweep used to redo the job (two block
+//     reductions, two barriers, a few divisions before the first dot4): still the path of standalone argmax sweeps, whose
+//     vector does not come out of a step kernel.
+// Same arithmetic in both (so the bounds, and with them the candidate counts, do not depend on who quantised).
+//
+// Record layout (ints): [SP4][4] packed digits of k-group g = {v0 digit 0, v0 digit 1, v1 digit, 0}, then BC_I8Q_HDR floats:
+//   fvs0, fvs1 (steps), fev0, fev1 (||v^ - v|| bounds, rounded up), fvn (||v||, rounded up), vbad (1.0: NaN / inf in v)
+#pragma once
+
+#define BC_I8Q_HDR 8
+#define BC_I8Q_INTS(sp4) (4 * (sp4) + BC_I8Q_HDR)
+
+// running max of |x| in which a NaN element counts as +inf (fmax alone would drop it): either makes the vector "bad"
+__device__ __forceinline__ double bc_i8q_absmax(double m, double x) { return (x != x) ? INFINITY : fmax(m, fabs(x)); }
+
+struct bc_i8q_scalars {
+  double vstep0, vstep1;
+  bool vbad;
+};
+
+__device__ __forceinline__ bc_i8q_scalars bc_i8q_steps(double vmax0, double vmax1) {
+  bc_i8q_scalars q;
+  // a NaN / inf in v makes every score NaN in the fp64 kernel: hand all rows over (delta = inf in the sweep)
+  q.vbad = !(vmax0 < INFINITY) || !(vmax1 < INFINITY) || vmax0 != vmax0 || vmax1 != vmax1;
+  q.vstep0 = vmax0 / 16256.;          // v0: 14 bits + sign in two digits
+  q.vstep1 = vmax1 / 127.;            // v1: one digit
+  return q;
+}
+
+// the four packed words of k-group g (samples 4g .. 4g+3)
+template <int MODE>
+__device__ __forceinline__ void bc_i8q_group(const double* __restrict__ v, int S, int g, const bc_i8q_scalars& q, unsigned (&w)[4]) {
+  w[0] = w[1] = w[2] = w[3] = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = 4 * g + j;
+    if (k < S && !q.vbad) {
+#pragma unroll
+      for (int vv = 0; vv < (MODE == 0 ? 2 : 1); ++vv) {
+        const double val = (MODE == 0) ? v[2 * k + vv] : v[k];
+        const double st = vv == 0 ? q.vstep0 : q.vstep1;
+        int Q = st > 0. ? (int)rint(val / st) : 0;
+        if (vv == 0) {
+          Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
+          const int d0 = (int)rint((double)Q / 128.);
+          const int d1 = Q - 128 * d0;
+          w[0] |= ((unsigned)d0 & 0xffu) << (8 * j);
+          w[1] |= ((unsigned)d1 & 0xffu) << (8 * j);
+        } else {
+          Q = Q > 127 ? 127 : (Q < -127 ? -127 : Q);
+          w[2] |= ((unsigned)Q & 0xffu) << (8 * j);
+        }
+      }
+    }
+  }
+}
+
+struct bc_i8q_hdr {
+  float fvs0, fvs1, fev0, fev1, fvn;
+  bool vbad;
+};
+
+// fp32 copies, each rounded UP where it enters a bound
+__device__ __forceinline__ bc_i8q_hdr bc_i8q_header(const bc_i8q_scalars& q, int S, double vn) {
+  const double rs = sqrt((double)S) * 0.5;
+  bc_i8q_hdr h;
+  h.fvn = __double2float_ru(vn);
+  h.fev0 = __double2float_ru(rs * q.vstep0);
+  h.fev1 = __double2float_ru(rs * q.vstep1);
+  h.fvs0 = (float)q.vstep0;
+  h.fvs1 = (float)q.vstep1;
+  h.vbad = q.vbad;
+  return h;
+}
+
+// One full wave (all 64 lanes active) quantises v into the record `qv`; vn = ||v|| (1 for GIGA's unit vectors).
+// v must be visible to the calling lanes (the step kernels call this from the wave that has just written it, lane-strided
+// the same way, behind a wave-level fence).
+template <int MODE>
+__device__ __forceinline__ void bc_i8q_wave(const double* __restrict__ v, int S, int SP4, double vn, int* __restrict__ qv, int lane) {
+  double m0 = 0., m1 = 0.;
+  for (int k = lane; k < S; k += 64) {
+    if (MODE == 0) {
+      m0 = bc_i8q_absmax(m0, v[2 * k]);
+      m1 = bc_i8q_absmax(m1, v[2 * k + 1]);
+    } else {
+      m0 = bc_i8q_absmax(m0, v[k]);
+    }
+  }
+  m0 = bc_wave_max_all(m0);
+  m1 = bc_wave_max_all(m1);
+  const bc_i8q_scalars q = bc_i8q_steps(m0, m1);
+  for (int g = lane; g < SP4; g += 64) {
+    unsigned w[4];
+    bc_i8q_group<MODE>(v, S, g, q, w);
+    reinterpret_cast<int4*>(qv)[g] = make_int4((int)w[0], (int)w[1], (int)w[2], (int)w[3]);
+  }
+  if (lane == 0) {
+    const bc_i8q_hdr h = bc_i8q_header(q, S, vn);
+    float* f = reinterpret_cast<float*>(qv + 4 * SP4);
+    f[0] = h.fvs0; f[1] = h.fvs1; f[2] = h.fev0; f[3] = h.fev1; f[4] = h.fvn; f[5] = h.vbad ? 1.f : 0.f; f[6] = 0.f; f[7] = 0.f;
+  }
+}

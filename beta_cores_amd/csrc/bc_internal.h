@@ -192,6 +192,15 @@ __device__ __forceinline__ double bc_wave_sum_all(double v) {
 
 __device__ __forceinline__ double bc_wave_sum(double v) { return bc_wave_sum_all(v); }
 
+// wave-wide fmax of a double, the maximum in every lane (all 64 lanes active): the same rotation butterfly
+__device__ __forceinline__ double bc_wave_max_all(double v) {
+  v = fmax(v, bc_dpp_mov<0x128>(v));   // row_ror:8
+  v = fmax(v, bc_dpp_mov<0x124>(v));   // row_ror:4
+  v = fmax(v, bc_dpp_mov<0x122>(v));   // row_ror:2
+  v = fmax(v, bc_dpp_mov<0x121>(v));   // row_ror:1
+  return fmax(fmax(bc_readlane(v, 0), bc_readlane(v, 16)), fmax(bc_readlane(v, 32), bc_readlane(v, 48)));
+}
+
 // Wave-wide fmaxf, the maximum in every lane (all 64 lanes active): the same rotation butterfly on one register.
 template <int CTRL>
 __device__ __forceinline__ float bc_dpp_mov_f32(float v) {

@@ -73,10 +73,12 @@ BC_KM double bc_exp_tab(double x, const double* tab) {
   return (x != x) ? x : r;
 }
 
-// log(1 + exp(-a)) for 0 <= a <= 2e4 (a NaN gives a NaN)
-BC_KM double bc_log1p_exp_neg_tab(double a, const double* tab) {
+// log(1 + exp(-a)) for 0 <= a <= 2e4 (a NaN gives a NaN); also hands out u = exp(-a) and f = 1 + u (rounded)
+BC_KM double bc_log1p_exp_neg_tab_uf(double a, const double* tab, double* u_out, double* f_out) {
   const double u = bc_exp_tab_core(-a, tab);
   const double f = 1. + u;
+  *u_out = u;
+  *f_out = f;
   const double fm1 = f - 1.;                           // exact
   // nearest c_i = 1 + i/256, i in 0..256, from the low mantissa bits of fm1 * 256 + 1.5 * 2^52 (fm1 in [0, 1]: the low
   // word IS i; the unsigned min only matters for a NaN, whose arbitrary payload bits must not index past the 257 table
@@ -93,6 +95,48 @@ BC_KM double bc_log1p_exp_neg_tab(double a, const double* tab) {
   const double s = fma(q, t, t);                       // log1p(t)
   const double c = (u - fm1) * rc;                     // d/df ln f * (rounding error of 1 + u)
   return lc + (s + c);
+}
+
+BC_KM double bc_log1p_exp_neg_tab(double a, const double* tab) {
+  double u, f;
+  return bc_log1p_exp_neg_tab_uf(a, tab, &u, &f);
+}
+
+// 1/f for f in [1, 2]: the hardware's approximate reciprocal (v_rcp_f64; on the host a float division stands in for it)
+// and two Newton steps -- five instructions, no scaling or fix-up cases in this range
+BC_KM double bc_rcp_1_2(double f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(f);
+#else
+  double r = (double)(1.0f / (float)f);
+#endif
+  double e = fma(-f, r, 1.);
+  r = fma(r, e, r);
+  e = fma(-f, r, 1.);
+  return fma(r, e, r);
+}
+
+// The logistic beta-likelihood (model_lr.py:81-86):  -( (b+1)/b (1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) ),
+// c0 = (b+1)/b, c1 = -b, c2 = -b-1.  The reference evaluates two exp and three pow per element; here, with
+//   L1 = log(1+e^m),  L2 = log(1+e^-m) = L1 - m   (the smaller of the two is Ls = log1p(e^-|m|), the other one adds |m|):
+//   (1+e^m)^-b      = exp(c1 L1)                                   exp #1
+//   (1+e^-m)^(-b-1) = exp(c2 L2)                                   exp #2
+//   (1+e^m)^(-b-1)  = exp(c1 L1) / (1+e^m) = exp(c1 L1) * w / f,   w = 1 (m <= 0) or u = e^-|m| (m > 0),  f = 1 + u
+// i.e. exp(-|m|), one log1p, two exp and one reciprocal of f in [1, 2] (round 3 took a third exp for the last line).
+// Same saturation as the reference's IEEE overflow semantics (m -> +inf: +1, m -> -inf: -1/b exactly as -(c0 - 1)); where
+// the reference flushes (1+inf)^a to exactly 0 this gives < 1e-30: far below the 1e-11 of the parity tolerance.  NaN in, NaN out.
+BC_KM double bc_logistic_beta_value(double m, double c0, double c1, double c2, const double* tab) {
+  const double am = fmin(fabs(m), 800.);              // beyond that every term has saturated (fmin drops a NaN: restored below)
+  double u, f;
+  const double Ls = bc_log1p_exp_neg_tab_uf(am, tab, &u, &f);    // log(1 + e^-|m|)
+  const double Ll = Ls + am;                          // log(1 + e^+|m|)
+  const int neg = m <= 0.;
+  const double L1 = neg ? Ls : Ll, L2 = neg ? Ll : Ls;
+  const double e1 = bc_exp_tab_core(c1 * L1, tab);    // arguments in [-(b+1) * 801, 0]
+  const double e3 = bc_exp_tab_core(c2 * L2, tab);
+  const double e2 = e1 * ((neg ? 1. : u) * bc_rcp_1_2(f));
+  const double v = -((c0 * e1) - (e2 + e3));
+  return (m != m) ? m : v;
 }
 
 #endif  // BC_K1_MATH_H

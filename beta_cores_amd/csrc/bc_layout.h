@@ -25,6 +25,7 @@
 #define BC_LAY_TILE 128      /* == BC_TILE_ROWS */
 #define BC_LAY_ITILE 256     /* == BC_ITILE */
 #define BC_LAY_IU 5          /* == BC_IU */
+#define BC_LAY_IMAXG 320     /* == BC_IMAXG: k-groups the sweep's digit table holds */
 
 BC_LAY long long bc_lay_tiles(long long n_rows) { return (n_rows + BC_LAY_TILE - 1) / BC_LAY_TILE; }
 BC_LAY size_t bc_lay_phi_doubles(long long tiles, int S) { return (size_t)tiles * (size_t)S * BC_LAY_TILE; }

@@ -39,6 +39,7 @@ struct bc_pref {
   float* u32 = nullptr;       // fp32: [ptiles][S][256]
   _Float16* u16 = nullptr;    // fp16: [ptiles][SP][512]
   unsigned char* live = nullptr;   // fp16: [ptiles][64] live-row mask
+  const int* qv = nullptr;    // int8: the owner's pre-quantised sweep vector (bc_i8_quant.h), or nullptr
   int* u8 = nullptr;          // int8: [ptiles][sp4][256] dwords (bc_prefilter_i8.h)
   bc_hq2* rowq = nullptr;     // int8: (scale, delta) per row, two halfs
   float2* tile_cand = nullptr;   // int8: [ptiles][4]
@@ -340,7 +341,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->sp4 = bc_lay_i8_sp4(phi->s);
   p->ptiles = (phi->n_rows + p->ptile - 1) / p->ptile;
   if (p->ptiles < 1) p->ptiles = 1;
-  static_assert(BC_ITILE == BC_LAY_ITILE && BC_IU == BC_LAY_IU && BC_TILE == BC_LAY_TILE, "bc_layout.h mirrors these");
+  static_assert(BC_ITILE == BC_LAY_ITILE && BC_IU == BC_LAY_IU && BC_TILE == BC_LAY_TILE && BC_IMAXG == BC_LAY_IMAXG, "bc_layout.h mirrors these");
   // one wave per tile and a grid-stride loop: size the grid so that all its waves are resident at once
   // (4 per SIMD) and every wave walks the same number of tiles -- a 2x over-subscribed grid left waves with
   // 2 or 3 tiles each (79% balance at 10M rows)
@@ -453,6 +454,7 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
     ia.u8 = p->u8;
     ia.rowq = p->rowq;
     ia.v = v_dev;
+    ia.qv = p->qv;
     ia.skip_flag = skip_flag;
     ia.v_norm = v_norm_dev;
     ia.tile_u = p->tile_u;
@@ -505,6 +507,11 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
   r.ptile = p->ptile;
   return BC_OK;
 }
+
+// The owner's step kernels keep a quantised copy of v_dev up to date (bc_snnls.hip: dev_prep -> bc_i8q_wave): the sweep
+// then skips its own quantisation prologue.  Only valid while EVERY launch of this pre-filter sweeps that same v.
+void bc_pref_set_qv(bc_pref* p, const int* qv_dev) { p->qv = (p->prec == 8) ? qv_dev : nullptr; }
+int bc_pref_sp4(const bc_pref* p) { return p->sp4; }
 
 // passes A, B, C: sweep, then the rescoring as its own one-block launch (record into rec_dev)
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,

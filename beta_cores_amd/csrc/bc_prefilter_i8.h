@@ -28,6 +28,7 @@
 #pragma once
 
 #include "bc_layout.h"
+#include "bc_i8_quant.h"
 #define BC_ITILE 256      /* == BC_LAY_ITILE (bc_layout.h) */
 #ifndef BC_IU
 #define BC_IU 5          // k-groups per batch (5 KiB in flight per wave and buffer)
@@ -41,6 +42,7 @@ struct I8Args {
   const int* u8;            // [ptiles][sp4][256]
   const bc_hq2* rowq;       // [ptiles*256] (scale, delta) halfs; delta < 0: dead row (padding or zero norm), NaN: uncertain row
   const double* v;
+  const int* qv;            // v already quantised (bc_i8_quant.h record) or nullptr: the prologue quantises v itself
   const int* skip_flag;
   const double* v_norm;     // dot mode: ||v|| from the solver state
   float* tile_u;            // [ptiles]
@@ -247,60 +249,47 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
       for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p0 + (size_t)u * 64);
       rq = reinterpret_cast<const bc_hq8*>(a.rowq + t * BC_ITILE)[lane];
     }
-    // ---- prologue: quantise the sweep vector(s) of this launch (every block does the same tiny job)
-    double m0 = 0., m1 = 0.;
-    for (int k = threadIdx.x; k < S; k += blockDim.x) {
-      if (MODE == 0) {
-        m0 = fmax(m0, fabs(a.v[2 * k]));
-        m1 = fmax(m1, fabs(a.v[2 * k + 1]));
-      } else {
-        m0 = fmax(m0, fabs(a.v[k]));
-      }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      m0 = fmax(m0, __shfl_down(m0, d, BC_WAVE));
-      m1 = fmax(m1, __shfl_down(m1, d, BC_WAVE));
-    }
-    if (lane == 0) { vmx[0][wave] = m0; vmx[1][wave] = m1; }
-    __syncthreads();
-    const double vmax0 = fmax(fmax(vmx[0][0], vmx[0][1]), fmax(vmx[0][2], vmx[0][3]));
-    const double vmax1 = fmax(fmax(vmx[1][0], vmx[1][1]), fmax(vmx[1][2], vmx[1][3]));
-    // a NaN / inf in v makes every score NaN in the fp64 kernel: hand all rows over (delta = inf below)
-    const bool vbad = !(vmax0 < INFINITY) || !(vmax1 < INFINITY) || vmax0 != vmax0 || vmax1 != vmax1;
-    const double vstep0 = vmax0 / 16256., vstep1 = vmax1 / 127.;      // v1: one digit
-    for (int g = threadIdx.x; g < SP4; g += blockDim.x) {
-      unsigned w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = 4 * g + j;
-        if (k < S && !vbad) {
-#pragma unroll
-          for (int vv = 0; vv < (MODE == 0 ? 2 : 1); ++vv) {
-            const double val = (MODE == 0) ? a.v[2 * k + vv] : a.v[k];
-            const double st = vv == 0 ? vstep0 : vstep1;
-            int Q = st > 0. ? (int)rint(val / st) : 0;
-            if (vv == 0) {
-              Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
-              const int d0 = (int)rint((double)Q / 128.);
-              const int d1 = Q - 128 * d0;
-              w[0] |= ((unsigned)d0 & 0xffu) << (8 * j);
-              w[1] |= ((unsigned)d1 & 0xffu) << (8 * j);
-            } else {
-              Q = Q > 127 ? 127 : (Q < -127 ? -127 : Q);
-              w[2] |= ((unsigned)Q & 0xffu) << (8 * j);
-            }
-          }
+    // ---- prologue.  With a.qv (the step kernel that produced v left its digits behind, bc_i8_quant.h): copy 1.3 KB into
+    // LDS, one barrier.  Without (standalone argmax sweeps): quantise v here, every block the same tiny job.
+    float fvn, fev0, fev1, fvs0, fvs1;
+    bool vbad;
+    if (a.qv != nullptr) {
+      for (int g = threadIdx.x; g < SP4; g += blockDim.x)
+        *reinterpret_cast<bc_i4*>(&dig[g][0]) = reinterpret_cast<const bc_i4*>(a.qv)[g];
+      const float* hf = reinterpret_cast<const float*>(a.qv + 4 * SP4);
+      fvs0 = hf[0]; fvs1 = hf[1]; fev0 = hf[2]; fev1 = hf[3]; fvn = hf[4];
+      vbad = hf[5] != 0.f;
+      __syncthreads();
+    } else {
+      double m0 = 0., m1 = 0.;
+      for (int k = threadIdx.x; k < S; k += blockDim.x) {
+        if (MODE == 0) {
+          m0 = bc_i8q_absmax(m0, a.v[2 * k]);
+          m1 = bc_i8q_absmax(m1, a.v[2 * k + 1]);
+        } else {
+          m0 = bc_i8q_absmax(m0, a.v[k]);
         }
       }
-      dig[g][0] = (int)w[0]; dig[g][1] = (int)w[1]; dig[g][2] = (int)w[2]; dig[g][3] = (int)w[3];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        m0 = fmax(m0, __shfl_down(m0, d, BC_WAVE));
+        m1 = fmax(m1, __shfl_down(m1, d, BC_WAVE));
+      }
+      if (lane == 0) { vmx[0][wave] = m0; vmx[1][wave] = m1; }
+      __syncthreads();
+      const bc_i8q_scalars q = bc_i8q_steps(fmax(fmax(vmx[0][0], vmx[0][1]), fmax(vmx[0][2], vmx[0][3])),
+                                            fmax(fmax(vmx[1][0], vmx[1][1]), fmax(vmx[1][2], vmx[1][3])));
+      for (int g = threadIdx.x; g < SP4; g += blockDim.x) {
+        unsigned w[4];
+        bc_i8q_group<MODE>(a.v, S, g, q, w);
+        dig[g][0] = (int)w[0]; dig[g][1] = (int)w[1]; dig[g][2] = (int)w[2]; dig[g][3] = (int)w[3];
+      }
+      __syncthreads();
+      const bc_i8q_hdr h = bc_i8q_header(q, S, (MODE == 0) ? 1. : *a.v_norm);
+      fvn = h.fvn; fev0 = h.fev0; fev1 = h.fev1; fvs0 = h.fvs0; fvs1 = h.fvs1;
+      vbad = h.vbad;
     }
-    __syncthreads();
-    const double vn = (MODE == 0) ? 1. : *a.v_norm;
-    const double rs = sqrt((double)S) * 0.5;
-    // fp32 copies, each rounded UP where it enters a bound
-    const float fvn = __double2float_ru(vn), fev0 = __double2float_ru(rs * vstep0), fev1 = __double2float_ru(rs * vstep1);   // ||v||, ||v^ - v||
-    const float fvs0 = (float)vstep0, fvs1 = (float)vstep1, fpd = (float)a.post_div;
+    const float fpd = (float)a.post_div;
 
     // Continuous pipeline: while the last batch of a tile is consumed and its rows are evaluated, the first batch
     // (and the row constants) of the wave's NEXT tile are already in flight.

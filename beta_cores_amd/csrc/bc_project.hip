@@ -78,29 +78,13 @@ constexpr bool bc_model_uses_tables() {
          MODEL == BC_MODEL_GAUSS_BETA || MODEL == BC_MODEL_GAUSS_BETA_GRAD;
 }
 
-// model_lr.py:81-86 evaluates two exp and three pow per element; here the powers go through
-//   L1 = log(1+e^m),  L2 = log(1+e^-m) = L1 - m   (the smaller of the two is log1p(e^-|m|), the other one adds |m|)
-//   (1+e^m)^a = exp(a L1),  (1+e^-m)^a = exp(a L2)          (a < 0, L >= 0: arguments <= 0)
-// i.e. one log1p(exp) and three exp.  Same saturation as the reference's IEEE overflow semantics (m -> +inf: +1,
-// m -> -inf: -1/b); where the reference flushes (1+inf)^a to exactly 0 this gives e^(a m) < 1e-30: far below the
-// 1e-11 of the parity tolerance.
+// (the logistic beta-likelihood's body, bc_logistic_beta_value, lives in bc_k1_math.h: compiled for the host too, where
+// tests/k1_math_harness.c measures it against 80-bit arithmetic)
 // BC_K1_GROUP (build-time): how many elements of a row the epilogue lets the scheduler interleave (see the S = 100
 // epilogue); the beta-logistic element is four transcendental bodies by itself
 #ifndef BC_K1_GROUP
 #define BC_K1_GROUP 2
 #endif
-__device__ __forceinline__ double bc_logistic_beta_value(double m, double c0, double c1, double c2, const double* tab) {
-  const double am = fmin(fabs(m), 800.);              // beyond that every term has saturated (fmin drops a NaN: restored below)
-  const double Ls = bc_log1p_exp_neg_tab(am, tab);    // log(1 + e^-|m|)
-  const double Ll = Ls + am;                          // log(1 + e^+|m|)
-  const double L1 = (m <= 0.) ? Ls : Ll, L2 = (m <= 0.) ? Ll : Ls;
-  const double e1 = bc_exp_tab_core(c1 * L1, tab);    // arguments in [-(b+1) * 801, 0]
-  const double e2 = bc_exp_tab_core(c2 * L1, tab);
-  const double e3 = bc_exp_tab_core(c2 * L2, tab);
-  const double v = -((c0 * e1) - (e2 + e3));
-  return (m != m) ? m : v;
-}
-
 template <int MODEL>
 __device__ __forceinline__ double bc_model_value(double p, double ra, double sa, const double* c, const double* tab) {
   switch (MODEL) {

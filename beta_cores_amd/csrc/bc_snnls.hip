@@ -18,6 +18,8 @@ extern "C" int bc_debug_fin_stamps(unsigned long long* out) {
 }
 #endif
 #include "bc_rescore_dev.h"
+#include "bc_layout.h"
+#include "bc_i8_quant.h"
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -36,6 +38,8 @@ int bc_pref_precision(const bc_pref* p);
 void bc_pref_destroy(bc_pref* p);
 void bc_pref_set_cap(bc_pref* p, int cap);
 const int* bc_pref_ctrl(const bc_pref* p);
+void bc_pref_set_qv(bc_pref* p, const int* qv_dev);
+int bc_pref_sp4(const bc_pref* p);
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
                    const int* skip_flag, double* rec_dev);
 int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
@@ -75,6 +79,8 @@ struct SnnlsDev {
   double* xw;
   double* xw_prev;
   double* v;          // sweep vectors: GIGA [s][2], else [s]
+  int* qv;            // the same, quantised for the int8 pre-filter's sweep (bc_i8_quant.h record) -- or nullptr
+  int sp4;            // k-groups of that record
   double* xf;         // picked column
   const double* cand_all;
   const double* tiles;
@@ -252,6 +258,7 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
   const int s = P.s;
   if (threadIdx.x < BC_WAVE) {
     const int lane = threadIdx.x;
+    double vnorm = 1.;                  // ||v|| of the sweep vector (GIGA's are unit vectors)
     if (ALG == BC_ALG_GIGA) {
       double nw = sqrt(S.xw_sq);
       nw = (nw == 0.) ? 1. : nw;
@@ -282,12 +289,21 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
         vn = fma(r, r, vn);
       }
       vn = bc_wave_sum(vn);
+      vnorm = sqrt(vn);
       if (lane == 0) {
         S.select_fail = 0;
-        S.v_norm = sqrt(vn);
+        S.v_norm = vnorm;
       }
     }
     if (lane == 0) S.skip = S.select_fail | S.reached_limit | S.pf_overflow;
+    if (P.qv != nullptr) {
+      // the int8 pre-filter's sweep reads v as int8 digits: leave them behind here, once, instead of letting every block of
+      // the sweep recompute them in its prologue (this wave wrote v itself: a wave-level fence makes the stores visible)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (ALG == BC_ALG_GIGA) bc_i8q_wave<0>(P.v, s, P.sp4, 1., P.qv, lane);
+      else bc_i8q_wave<1>(P.v, s, P.sp4, vnorm, P.qv, lane);
+    }
   }
   __syncthreads();
 }
@@ -1118,7 +1134,7 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_st = 0, o_b = up(sizeof(SnnlsState)), o_bn = o_b + up(s * 8), o_xw = o_bn + up(s * 8), o_xwp = o_xw + up(s * 8),
                  o_xf = o_xwp + up(s * 8), o_rec = o_xf + up(s * 8), o_v = o_rec + up(d.rec_len * 8),
-                 total = o_v + up(2 * (s + BC_V_PAD) * 8);
+                 o_qv = o_v + up(2 * (s + BC_V_PAD) * 8), total = o_qv + up((size_t)BC_I8Q_INTS(bc_lay_i8_sp4(s)) * sizeof(int));
     char* slab = nullptr;
     hipError_t e0 = hipMalloc((void**)&slab, total);
     if (e0 == hipSuccess) e0 = hipMemsetAsync(slab, 0, total, ctx->stream);
@@ -1132,6 +1148,15 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
     d.xf = (double*)(slab + o_xf);
     h->cand_send = (double*)(slab + o_rec);
     d.v = (double*)(slab + o_v);
+    // the int8 pre-filter (created below, after k_reset has produced the first sweep vector) reads v as digits: the step
+    // kernels keep that record current from the start when such a pre-filter is going to exist
+    const char* penv = getenv("BC_PREFILTER");
+    const int preq = penv ? atoi(penv) : -1;
+    const bool pwant = penv ? preq != 0 : phi->n_rows >= 163840;
+    const int pprec = (preq == 8 || preq == 16 || preq == 32) ? preq : BC_PREF_DEFAULT_PREC;
+    const char* qenv = getenv("BC_I8_QV");               // =0: sweeps quantise in their own prologue (A/B, tests)
+    d.sp4 = bc_lay_i8_sp4(s);
+    d.qv = (pwant && pprec == 8 && phi->n_rows > 0 && (s + 3) / 4 <= BC_LAY_IMAXG - BC_LAY_IU && !(qenv && atoi(qenv) == 0)) ? (int*)(slab + o_qv) : nullptr;
   }
   hipError_t e = hipSuccess;
   d.cand_all = h->cand_send;
@@ -1163,6 +1188,7 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
     if (rc) { bc_snnls_destroy(h); return rc; }
     const char* cap = getenv("BC_PREFILTER_CAP");
     if (cap) bc_pref_set_cap(h->pref, atoi(cap));
+    if (d.qv && bc_pref_sp4(h->pref) == d.sp4) bc_pref_set_qv(h->pref, d.qv);
   }
   *out = h;
   return BC_OK;

@@ -225,6 +225,9 @@ class LogisticLaplaceSampler(_PosteriorSampler):
         d = self.mu0.shape[0]
         if pts.shape[0] == 0:
             wts, pts = np.zeros(1), np.zeros((1, d))
-        muw, LSigw, _ = logistic_laplace(np.asarray(wts, dtype=np.float64), np.atleast_2d(pts), self.mu0, self.diag, rng=self._rng,
-                                         solver=self.solver)
-        return muw + self._normals(n, d).dot(LSigw.T)
+        # (D x D and M x D linear algebra, thousands of tiny BLAS calls inside the mode search: one thread -- a 128-thread
+        # pool spends milliseconds synchronising on each; re-entrant, the optimisation loop usually holds the scope already)
+        with small_lapack_scope(d):
+            muw, LSigw, _ = logistic_laplace(np.asarray(wts, dtype=np.float64), np.atleast_2d(pts), self.mu0, self.diag, rng=self._rng,
+                                             solver=self.solver)
+            return muw + self._normals(n, d).dot(LSigw.T)

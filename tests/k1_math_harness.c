@@ -44,8 +44,30 @@ int main(int argc, char** argv) {
   const double l0 = bc_log1p_exp_neg_tab(0.0, tab);
   printf("exp: max %.3f ulp (at %.17g) mean %.3f | log1p_exp_neg: max %.3f ulp (at %.17g) mean %.3f | at0 %s\n", emax, xe, esum / n, lmax, xl,
          lsum / n, l0 == 0.6931471805599453 ? "exact-ln2" : "NOT-ln2");
+  /* the logistic beta-likelihood body against the reference's formula in 80-bit arithmetic (model_lr.py:85) */
+  double bmax = 0.;
+  const double betas[3] = {0.1, 0.5, 1.0};
+  for (int bi = 0; bi < 3; ++bi) {
+    const double b = betas[bi], c0 = (b + 1.) / b, c1 = -b, c2 = -b - 1.;
+    for (long i = 0; i < n / 4; ++i) {
+      const double r = rnd();
+      const double m = (i & 3) == 0 ? (r - 0.5) * 1800. : ((i & 3) == 1 ? (r - 0.5) * 8. : (r - 0.5) * 80.);
+      const double got = bc_logistic_beta_value(m, c0, c1, c2, tab);
+      const long double em = expl((long double)m), enm = expl(-(long double)m);
+      const long double want = -(((long double)c0) * powl(1.L + em, (long double)c1) - (powl(1.L + em, (long double)c2) + powl(1.L + enm, (long double)c2)));
+      const double err = (double)fabsl((long double)got - want);
+      if (err > bmax) bmax = err;
+    }
+    /* saturation: exactly the reference's limits */
+    if (bc_logistic_beta_value(900., c0, c1, c2, tab) != 1.0) { printf("beta-lik +inf limit BAD\n"); return 1; }
+    if (bc_logistic_beta_value(-900., c0, c1, c2, tab) != -(c0 - 1.0)) { printf("beta-lik -inf limit BAD\n"); return 1; }
+    if (bc_logistic_beta_value(-47., c0, c1, c2, tab) != -(c0 - 1.0)) { printf("beta-lik saturated row not constant\n"); return 1; }
+  }
+  printf("logistic_beta_value: max abs err %.3g (values are O(1..1/beta))\n", bmax);
+  if (!(bmax < 1e-14)) return 1;
   /* special values */
   int ok = 1;
+  ok &= isnan(bc_logistic_beta_value(NAN, 11., -0.1, -1.1, tab));
   ok &= bc_exp_tab(0.0, tab) == 1.0;
   ok &= bc_exp_tab(-1000.0, tab) == 0.0;
   ok &= isinf(bc_exp_tab(1000.0, tab));

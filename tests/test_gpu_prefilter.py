@@ -300,3 +300,40 @@ def test_int8_sweep_many_tiles_per_wave(bc, monkeypatch):
         out.append((sv._eng.trace(), sv._eng.sparse_weights(), sv.error()))
     (ta, wa, ea), (tb, wb, eb) = out
     assert np.array_equal(ta[0], tb[0]) and np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and ea == eb
+
+
+@pytest.mark.parametrize('alg', ['giga', 'fw', 'omp'])
+@pytest.mark.parametrize('n,s', [(30000, 100), (5000, 37), (300, 5), (70000, 300)])
+def test_sweep_vector_quantised_once_per_step_changes_nothing(bc, alg, n, s):
+    """Round 4: the step kernels leave the int8 digits of the next sweep vector behind (bc_i8_quant.h) and the sweep blocks
+    copy them instead of quantising the vector in every block's prologue.  Same arithmetic on both routes: traces, weights,
+    errors AND the candidate statistics of the pre-filter (sweeps, rows rescored, fallbacks) are identical to BC_I8_QV=0."""
+    rng = np.random.RandomState(n + 3 * s)
+    phi = correlated(rng, n, s)
+    cls = dict(giga=bc.snnls.GIGA, fw=bc.snnls.FrankWolfe, omp=bc.snnls.OrthoPursuit)[alg]
+    steps = 40 if alg != 'omp' else 15
+    res, stats = [], []
+    for qv in ('1', '0'):
+        old = os.environ.get('BC_I8_QV')
+        os.environ['BC_I8_QV'] = qv
+        try:
+            with prefilter(8):
+                sv = cls(phi.T, phi.sum(axis=0))
+        finally:
+            if old is None:
+                os.environ.pop('BC_I8_QV', None)
+            else:
+                os.environ['BC_I8_QV'] = old
+        assert sv._eng.prefilter == 8
+        if alg == 'omp':
+            sv.build_stepwise(steps)
+            tr = None
+        else:
+            sv.build(steps)
+            tr = sv._eng.trace()
+        idx, val = sv._eng.sparse_weights()
+        res.append((tr, idx, val, sv.error()))
+        stats.append(tuple(sv._eng.prefilter_stats()))
+    same(res[0], res[1])
+    assert stats[0] == stats[1] and stats[0][0] >= steps - 1
+    same(res[0], run(bc, cls, phi, steps, 0, stepwise=(alg == 'omp')))      # and both equal the fp64 sweep
