@@ -18,6 +18,7 @@ __device__ __forceinline__ double bc_i8q_absmax(double m, double x) { return (x 
 
 struct bc_i8q_scalars {
   double vstep0, vstep1;
+  double inv0, inv1;      // reciprocals of the steps (0 for a zero step): one division per vector instead of one per element
   bool vbad;
 };
 
@@ -27,6 +28,11 @@ __device__ __forceinline__ bc_i8q_scalars bc_i8q_steps(double vmax0, double vmax
   q.vbad = !(vmax0 < INFINITY) || !(vmax1 < INFINITY) || vmax0 != vmax0 || vmax1 != vmax1;
   q.vstep0 = vmax0 / 16256.;          // v0: 14 bits + sign in two digits
   q.vstep1 = vmax1 / 127.;            // v1: one digit
+  // digits are rint(val * inv): against rint(val / step) the product carries one more rounding (relative 2^-53), i.e. the
+  // digit is the nearest integer of a value within 1e-12 of val / step -- |Q step - val| <= step / 2 * (1 + 1e-11), far
+  // inside the 1.00001 the sweep's error bound is inflated by
+  q.inv0 = (q.vstep0 > 0. && !q.vbad) ? 1. / q.vstep0 : 0.;
+  q.inv1 = (q.vstep1 > 0. && !q.vbad) ? 1. / q.vstep1 : 0.;
   return q;
 }
 
@@ -41,11 +47,10 @@ __device__ __forceinline__ void bc_i8q_group(const double* __restrict__ v, int S
 #pragma unroll
       for (int vv = 0; vv < (MODE == 0 ? 2 : 1); ++vv) {
         const double val = (MODE == 0) ? v[2 * k + vv] : v[k];
-        const double st = vv == 0 ? q.vstep0 : q.vstep1;
-        int Q = st > 0. ? (int)rint(val / st) : 0;
+        int Q = (int)rint(val * (vv == 0 ? q.inv0 : q.inv1));
         if (vv == 0) {
           Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
-          const int d0 = (int)rint((double)Q / 128.);
+          const int d0 = (int)rint((double)Q * 0.0078125);       // Q / 128, exact
           const int d1 = Q - 128 * d0;
           w[0] |= ((unsigned)d0 & 0xffu) << (8 * j);
           w[1] |= ((unsigned)d1 & 0xffu) << (8 * j);
@@ -77,25 +82,20 @@ __device__ __forceinline__ bc_i8q_hdr bc_i8q_header(const bc_i8q_scalars& q, int
 }
 
 // One full wave (all 64 lanes active) quantises v into the record `qv`; vn = ||v|| (1 for GIGA's unit vectors).
-// v must be visible to the calling lanes (the step kernels call this from the wave that has just written it, lane-strided
-// the same way, behind a wave-level fence).
+// m0 / m1: this lane's partial maxima of |v0| / |v1| (bc_i8q_absmax over the elements it produced) -- the wave that writes
+// v has every element in a register once, so the maximum costs it one instruction per element and no second pass.
+// vsrc: where the digits' pass reads the elements from -- a copy in LDS when the caller has one (a re-read from global
+// memory is a round trip to the L2 behind the stores: ~1 us in a single-block kernel), else v itself; either way the
+// calling wave wrote it, lane-strided, and has passed a wave-level fence.
 template <int MODE>
-__device__ __forceinline__ void bc_i8q_wave(const double* __restrict__ v, int S, int SP4, double vn, int* __restrict__ qv, int lane) {
-  double m0 = 0., m1 = 0.;
-  for (int k = lane; k < S; k += 64) {
-    if (MODE == 0) {
-      m0 = bc_i8q_absmax(m0, v[2 * k]);
-      m1 = bc_i8q_absmax(m1, v[2 * k + 1]);
-    } else {
-      m0 = bc_i8q_absmax(m0, v[k]);
-    }
-  }
+__device__ __forceinline__ void bc_i8q_wave(const double* __restrict__ vsrc, int S, int SP4, double vn, int* __restrict__ qv, int lane,
+                                            double m0, double m1) {
   m0 = bc_wave_max_all(m0);
   m1 = bc_wave_max_all(m1);
   const bc_i8q_scalars q = bc_i8q_steps(m0, m1);
   for (int g = lane; g < SP4; g += 64) {
     unsigned w[4];
-    bc_i8q_group<MODE>(v, S, g, q, w);
+    bc_i8q_group<MODE>(vsrc, S, g, q, w);
     reinterpret_cast<int4*>(qv)[g] = make_int4((int)w[0], (int)w[1], (int)w[2], (int)w[3]);
   }
   if (lane == 0) {

@@ -253,12 +253,20 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
 }
 
 // vectors for the next sweep.  GIGA: giga.py:21-30 ; FW / OMP: residual b - A.w          (wave 0 + one barrier)
+// With an int8 pre-filter (P.qv) the same wave also leaves the vectors' int8 digits behind (bc_i8_quant.h): the maxima are
+// taken while the elements are in registers, and the digits' pass reads them back from a 4 KB LDS copy (S <= BC_VQ_MAX;
+// larger S re-reads v from global memory).
+#define BC_VQ_MAX 256
 template <int ALG>
 __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
+  __shared__ double vq[2 * BC_VQ_MAX];
   const int s = P.s;
   if (threadIdx.x < BC_WAVE) {
     const int lane = threadIdx.x;
+    const bool quant = P.qv != nullptr;
+    const bool lds_copy = quant && s <= BC_VQ_MAX;
     double vnorm = 1.;                  // ||v|| of the sweep vector (GIGA's are unit vectors)
+    double m0 = 0., m1 = 0.;            // this lane's max |v0|, |v1|
     if (ALG == BC_ALG_GIGA) {
       double nw = sqrt(S.xw_sq);
       nw = (nw == 0.) ? 1. : nw;
@@ -266,6 +274,8 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       for (int k = lane; k < s; k += BC_WAVE) {
         const double xn = P.xw[k] / nw;
         P.v[2 * k + 1] = xn;
+        if (lds_copy) vq[2 * k + 1] = xn;
+        m1 = bc_i8q_absmax(m1, xn);
         bd = fma(P.bn[k], xn, bd);
       }
       bd = bc_wave_sum_all(bd);
@@ -278,7 +288,10 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       const bool fail = cn < P.tol;
       for (int k = lane; k < s; k += BC_WAVE) {
         const double c = P.bn[k] - bd * (P.xw[k] / nw);
-        P.v[2 * k] = fail ? c : c / cn;
+        const double v0 = fail ? c : c / cn;
+        P.v[2 * k] = v0;
+        if (lds_copy) vq[2 * k] = v0;
+        m0 = bc_i8q_absmax(m0, v0);
       }
       if (lane == 0) S.select_fail = fail ? 1 : 0;
     } else {
@@ -286,6 +299,8 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       for (int k = lane; k < s; k += BC_WAVE) {
         const double r = P.b[k] - P.xw[k];
         P.v[k] = r;
+        if (lds_copy) vq[k] = r;
+        m0 = bc_i8q_absmax(m0, r);
         vn = fma(r, r, vn);
       }
       vn = bc_wave_sum(vn);
@@ -296,13 +311,13 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       }
     }
     if (lane == 0) S.skip = S.select_fail | S.reached_limit | S.pf_overflow;
-    if (P.qv != nullptr) {
-      // the int8 pre-filter's sweep reads v as int8 digits: leave them behind here, once, instead of letting every block of
-      // the sweep recompute them in its prologue (this wave wrote v itself: a wave-level fence makes the stores visible)
+    if (quant) {
+      // this wave wrote v (and its LDS copy) itself: a wave-level fence orders the digits' reads behind those stores
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (ALG == BC_ALG_GIGA) bc_i8q_wave<0>(P.v, s, P.sp4, 1., P.qv, lane);
-      else bc_i8q_wave<1>(P.v, s, P.sp4, vnorm, P.qv, lane);
+      const double* vsrc = lds_copy ? vq : P.v;
+      if (ALG == BC_ALG_GIGA) bc_i8q_wave<0>(vsrc, s, P.sp4, 1., P.qv, lane, m0, m1);
+      else bc_i8q_wave<1>(vsrc, s, P.sp4, vnorm, P.qv, lane, m0, m1);
     }
   }
   __syncthreads();
@@ -1306,7 +1321,7 @@ static bool fused_rescore_ok(const bc_snnls* h) {
   const size_t lds = ((size_t)5 * h->d.s + h->d.rec_len + 2 * (size_t)(h->nnz_upper + 1)) * sizeof(double);
   // static LDS of the fused kernel (rescoring strips 32 KB, current / best row 16 KB, tile list 4 KB, ...) + the dynamic part
   // must fit the device's per-block limit (160 KB on gfx950; the two-launch path is taken otherwise)
-  return lds <= BC_RS_MAX_DYN_LDS && lds + 56 * 1024 <= (size_t)h->ctx->max_lds;
+  return lds <= BC_RS_MAX_DYN_LDS && lds + 62 * 1024 <= (size_t)h->ctx->max_lds;      // (61.5 KB static, of which 4 KB dev_prep copy of the sweep vectors)
 }
 
 static int launch_sweep(bc_snnls* h, bool with_record, bool allow_fused) {

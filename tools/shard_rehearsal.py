@@ -42,11 +42,14 @@ def run(rows, qv, steps=300, warmup=120):
 
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r04_shard_rehearsal.json')
+    only = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (2, 4, 8)
     sys.path.insert(0, ROOT)
     res = {'what': 'REHEARSAL on ONE GPU, one rank, RCCL all-gather with world = 1: the per-step fixed cost of a row shard; not a scaling curve',
            'workload': 'bench.py synthetic Zellner linreg, D = 128, S = 100, GIGA; rows = the shard one of G GPUs holds at N = 10M',
            'runs': []}
     for G, rows in ((2, 5_000_064), (4, 2_500_096), (8, 1_250_048)):
+        if G not in only:
+            continue
         for qv in (1, 0, 1):
             r = run(rows, qv)
             r['shard_of_G'] = G
