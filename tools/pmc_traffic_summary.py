@@ -44,7 +44,7 @@ def per_launch(rs, counter, name_part, min_grid, max_grid=1 << 60):
 def main():
     fetch, write = rows(sys.argv[1]), rows(sys.argv[2])
     out = {'config': {'N': N, 'D': D, 'S': S, 'n_gpus': 1},
-           'command': 'rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace -- python3 bench.py --no-cpu --no-extra --steps 20 --warmup 5',
+           'command': 'rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace -- python3 bench.py --no-cpu --no-extra --no-host --steps 20 --warmup 5',
            'units': 'FETCH_SIZE / WRITE_SIZE are reported in KB (x1024 bytes); per-launch means over the launches at N = 10M'}
     f, n, kn = per_launch(fetch, 'FETCH_SIZE', 'k_sweep_i8', 100000)
     w, _, _ = per_launch(write, 'WRITE_SIZE', 'k_sweep_i8', 100000)
