@@ -166,7 +166,7 @@ def _lr_mode_newton(Zw, ww, mu0, max_iter=200):
     return mu
 
 
-def logistic_laplace(wts, Z, mu0, diag=False, rng=None, solver='bfgs'):
+def logistic_laplace(wts, Z, mu0, diag=False, rng=None, solver='bfgs', newton_start=None):
     """`get_laplace` (examples/zellner_logreg/main.py:86-111 == bayesiancoresets/util/opt.py:9-33): (mu, LSig, LSigInv) of
     the Laplace approximation N(mu, LSig LSig^T) to the posterior of the rows Z with weights wts; the mode comes from
     scipy.optimize.minimize's default method started at mu0 (third-party arithmetic, shared with the reference, not
@@ -178,7 +178,8 @@ def logistic_laplace(wts, Z, mu0, diag=False, rng=None, solver='bfgs'):
     Zw = Z[wts > 0, :]
     ww = wts[wts > 0]
     if solver == 'newton':
-        mu = _lr_mode_newton(Zw, ww, mu0)
+        # (newton_start: where to begin -- the maximiser is unique, so the start only decides how many steps it takes)
+        mu = _lr_mode_newton(Zw, ww, mu0 if newton_start is None else newton_start)
     elif solver != 'bfgs':
         raise ValueError("solver must be 'bfgs' (the reference's scipy.optimize.minimize call) or 'newton'")
     while solver == 'bfgs':
@@ -217,6 +218,8 @@ class LogisticLaplaceSampler(_PosteriorSampler):
         super().__init__(rng)
         self.mu0, self.diag, self.solver = np.asarray(mu0, dtype=np.float64), bool(diag), solver
         self._shape = None
+        self._mode = None             # solver='newton': the previous call's mode, the next call's starting point (consecutive
+                                      # gradients move the weights a little: 2-3 Newton steps instead of 10-20 from mu0)
 
     def _dim(self):
         return self.mu0.shape[0]
@@ -229,5 +232,7 @@ class LogisticLaplaceSampler(_PosteriorSampler):
         # pool spends milliseconds synchronising on each; re-entrant, the optimisation loop usually holds the scope already)
         with small_lapack_scope(d):
             muw, LSigw, _ = logistic_laplace(np.asarray(wts, dtype=np.float64), np.atleast_2d(pts), self.mu0, self.diag, rng=self._rng,
-                                             solver=self.solver)
+                                             solver=self.solver, newton_start=self._mode if self.solver == 'newton' else None)
+            if self.solver == 'newton' and np.all(np.isfinite(muw)):
+                self._mode = muw.copy()
             return muw + self._normals(n, d).dot(LSigw.T)

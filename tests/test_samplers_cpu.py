@@ -88,3 +88,22 @@ def test_newton_mode_is_the_reference_mode(S):
     np.testing.assert_allclose(mu_n, mu_b, rtol=1e-4, atol=1e-6)
     with pytest.raises(ValueError):
         logistic_laplace(w, rows, np.zeros(Z.shape[1]), False, solver='lbfgs')
+
+
+def test_newton_warm_start_reaches_the_same_mode():
+    """LogisticLaplaceSampler(solver='newton') starts each mode search at the previous call's mode; the maximiser is unique, so
+    the samples are the cold-start ones to rounding."""
+    from beta_cores_amd.samplers import LogisticLaplaceSampler
+    rng = np.random.RandomState(9)
+    D, M, S = 10, 40, 6
+    Z = rng.randn(M, D) * np.where(rng.rand(M) < 0.5, 1., -1.)[:, None]
+
+    class E:
+        def randn(self, n, d):
+            return np.ones((n, d))
+    warm = LogisticLaplaceSampler(np.zeros(D), rng=E(), solver='newton')
+    for k in range(4):
+        w = np.full(M, 50.) + 5. * k * rng.rand(M)
+        cold = LogisticLaplaceSampler(np.zeros(D), rng=E(), solver='newton')
+        np.testing.assert_allclose(warm(S, w, Z), cold(S, w, Z), rtol=1e-10, atol=1e-12)
+    assert warm._mode is not None and cold._mode is not None
