@@ -188,3 +188,12 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert 'entry points' in out.stdout
     n = int(out.stdout.split(',')[1].split()[0])
     assert n == len(header_functions())
+
+
+def test_every_entry_point_refuses_null_arguments():
+    """tests/abi_null_sweep.py against the shipped library (the same sweep runs on a host-sanitized build in
+    tests/test_sanitized_cpu.py and, with a live context, in the -m gpu suite)."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'abi_null_sweep.py')], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and 'swept 7' in res.stdout, res.stdout + res.stderr[-2000:]

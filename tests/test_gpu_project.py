@@ -600,3 +600,13 @@ def test_theta_resident_kernel_matches_staged_and_oracle(bc, n, d, s):
 def res_const(rows, pick, zero_rows):
     """the rows of `rows` (gathered at indices `pick`) that belong to the constant (zero-feature) data rows"""
     return rows[np.isin(pick, zero_rows)]
+
+
+def test_abi_null_sweep_with_a_live_context():
+    """Every entry point refuses NULL arguments, and a live context refuses malformed sizes (tests/abi_null_sweep.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tests', 'abi_null_sweep.py')], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and 'live-context checks ok' in res.stdout and 'swept 7' in res.stdout, res.stdout + res.stderr[-2000:]
