@@ -161,7 +161,11 @@ def _lr_mode_newton(Zw, ww, mu0, max_iter=200):
                 break
             t *= 0.5
         mu, f = cand, fc
-        if np.fabs(t * step).max() <= 1e-13 * (1. + np.fabs(mu).max()) or dec <= 1e-24 * (1. + abs(f)):
+        # stop after a FULL Newton step whose decrement g.H^-1.g (twice the distance of f from its maximum) was already at
+        # the rounding floor of f: the point before it was within sqrt(2 dec) <= 2e-6 of the mode, the step squares that.
+        # (The gradient cannot be driven below ~ max(w) * eps -- with weights N/M a criterion on |step| alone would spin in
+        # rounding noise for the remaining iterations.)
+        if (t == 1. and dec <= 64. * np.finfo(np.float64).eps * (1. + abs(f))) or np.fabs(t * step).max() <= 1e-13 * (1. + np.fabs(mu).max()):
             break
     return mu
 
