@@ -16,6 +16,7 @@
 //   model_linreg.py:4-10 / model_neurlinr.py:90-97,102-110 / model_lr.py:72-86 / gaussian.py:7-15,34-62
 #include "bc_internal.h"
 #include "bc_np_exp.h"
+#include "bc_np_pow2.h"
 #include "bc_layout.h"
 #include "bc_k1_math.h"
 #include <cmath>
@@ -962,13 +963,23 @@ static int model_constants(int model, const double* p, int np, int d, double* c,
       return np == 0 ? BC_OK : BC_INVALID_ARGUMENT;
     case BC_MODEL_LOGISTIC_BETA: {
       // params = [beta] or [beta, value of the beta-likelihood at m = 0 with the caller's np.power bits] (see
-      // bc_model_value_np): without the second one the constant of a z = 0 row is the device's own (within 2 ulp)
+      // bc_model_value_np); without the second one the library evaluates that value itself with the restated np.power
       if (np != 1 && np != 2) return BC_INVALID_ARGUMENT;
       const double beta = p[0];
       c[0] = (beta + 1.) / beta;
       c[1] = -beta;
       c[2] = -beta - 1.;
-      c[3] = (np == 2) ? p[1] : NAN;
+      if (np == 2) {
+        c[3] = p[1];
+      } else {
+        // no constant from the caller: the reference's expression at m = 0 with np.power's bits at base 2 restated
+        // (bc_np_pow2.h: what NumPy computes on AVX-512 hosts, the hosts the goldens come from)
+        int cov1 = 0, cov2 = 0;
+        double p1 = bc_np_pow2(-beta, &cov1), p2 = bc_np_pow2(-beta - 1., &cov2);
+        if (!cov1) p1 = pow(2., -beta);
+        if (!cov2) p2 = pow(2., -beta - 1.);
+        c[3] = -(((beta + 1.) / beta) * p1 - (p2 + p2));
+      }
       return BC_OK;
     }
     case BC_MODEL_GAUSS_LL: {

@@ -61,7 +61,8 @@ extern "C" {
 #define BC_MODEL_LOGISTIC_LL 2   /* model_lr.py:72-79                               ; params = {}               ; Z = y*x (D)   */
 #define BC_MODEL_LOGISTIC_BETA 3 /* model_lr.py:81-86                               ; params = {beta[, c0]}     ; Z = y*x (D)   */
 /*   c0 (optional): the formula's value at m = 0 carrying the caller's np.power bits; K1 uses it for the constant projection row of
- *   a data row z = 0 (whether that row centres to exactly 0 hangs on its last bit).  Omitted: the device's own value, within 2 ulp. */
+ *   a data row z = 0 (whether that row centres to exactly 0 hangs on its last bit).  Omitted: the library evaluates it with its
+ *   restatement of np.power at base 2 (csrc/bc_np_pow2.h: NumPy's bits on AVX-512 hosts). */
 #define BC_MODEL_GAUSS_LL 4      /* gaussian.py:7-15  ; params = {logdetSig, Siginv[d*d]}        ; Z = x (d) */
 #define BC_MODEL_GAUSS_BETA 5    /* gaussian.py:34-44 ; params = {beta, logdetSig, Siginv[d*d]}  ; Z = x (d) */
 #define BC_MODEL_GAUSS_BETA_GRAD 6 /* gaussian.py:46-62 ; params as GAUSS_BETA (d/dbeta, projector.py:56-61) */

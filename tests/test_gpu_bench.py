@@ -57,7 +57,7 @@ def test_bench_line_contract():
     assert all(e['ms_grad'] > 0 and e['k1_ms'] > 0 and 0 <= e['non_k1'] < 1 and e['build_ms'] > 0 for e in lp)
     bf = [e for e in lp if 'logistic/bfgs' in e['loop']][0]
     nw = [e for e in lp if 'logistic/newton' in e['loop'] and 'M=100' in e['loop']][0]
-    assert abs(bf['k1_ms'] / nw['k1_ms'] - 1) < 0.2 and nw['samp_ms'] < bf['samp_ms']
+    assert nw['samp_ms'] < bf['samp_ms'] and nw['ms_grad'] < bf['ms_grad']      # (K1 times differ with the clock the GPU holds: idle gaps between BFGS gradients)
     fh = r['from_host']
     assert fh['same_trace_as_resident_run'] is True and fh['first_iter_ms'] >= fh['construct_ms'] > 0 and fh['M100_ms'] >= fh['first_iter_ms']
     assert fh['upload_GBps'] > 0 and fh['copy_direct_GBps'] > 0 and fh['copy_staged8_GBps'] > 0

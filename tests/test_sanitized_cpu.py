@@ -64,6 +64,21 @@ def test_np_exp_restatement_under_asan_ubsan(tmp_path):
     assert 'mismatches=' in res.stdout, res.stdout + res.stderr
 
 
+def test_np_pow2_restatement_under_asan_ubsan(tmp_path):
+    import numpy as np
+    rng = np.random.RandomState(7)
+    y = np.concatenate([-rng.uniform(0, 4, 40_000), rng.uniform(-1021, 1021, 20_000), -np.arange(0, 64) / 16.,
+                        np.array([0., -0., 1021.5, -1021.5, 1021.6, 1e300, -1e300, np.inf, -np.inf, np.nan])])
+    with np.errstate(over='ignore', under='ignore'):
+        w = np.power(np.full(y.shape, 2.0), y)
+    path = str(tmp_path / 'p.bin')
+    with open(path, 'wb') as f:
+        f.write(y.tobytes())
+        f.write(w.tobytes())
+    res = run_clean(build(tmp_path, 'np_pow2_harness.c'), [path, str(y.shape[0])])
+    assert 'mismatches=' in res.stdout, res.stdout + res.stderr
+
+
 def shard_sizes():
     import importlib.util
     spec = importlib.util.spec_from_file_location('bc_dist', os.path.join(ROOT, 'beta_cores_amd', 'dist.py'))
