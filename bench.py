@@ -8,7 +8,14 @@ total N is fixed), one process per GPU, one candidate-record all-gather (RCCL) p
 
 A "step" = one greedy iteration of SparseNNLS.build (select + reweight + monotone guard)
 over Phi resident in HBM.  The one-off K1 projection is timed separately and reported
-as points*dims/s.  Prints ONE JSON line on rank 0.
+as points*dims/s.  Prints ONE JSON line on rank 0 -- kept short (~5 KB) so that the driver's
+record holds all of it; the evidence sits inside the two objects that record keeps whole:
+  roofline.kernels    one entry per timed kernel (avg ms by HIP events, GB / GF per launch, fractions of the HBM / fp64-MFMA peaks)
+  roofline.loops      the beta-Cores gradient loops of configs 2, 3 (logistic + Laplace sampler) and 4, per-phase split
+  roofline.from_host  ndarray -> resident rows / first iteration / M = 100 coreset (upload + K1 pipelined); never part of `value`
+  cpu_baseline        the NumPy oracle on the same host: greedy loop on ALL rows, and the gradient loops (`loops`)
+Everything verbose (full roofline objects, phase timers, solver_init parts) goes to --detail FILE, or to one stderr
+line tagged BENCH_DETAIL.
 
   python bench.py [--gpus 1 --steps 100 --warmup 10]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
