@@ -1076,6 +1076,44 @@ def f20_logistic_beta_constant_rows():
     save('f20_logistic_beta_constant_rows', **out)
 
 
+# ---------------------------------------------------------------- F21: the logistic drivers' ACTUAL wiring: sub-sampled tangent spaces
+def f21_logistic_subsampled():
+    """examples/zellner_logreg/main.py:152-160 builds its coresets with n_subsample_opt / n_subsample_select and the Laplace
+    sampler on the global NumPy stream: BetaCoreset (beta-likelihood) and SparseVICoreset (log-likelihood) in that mode --
+    selections, weights and the stream position after 6 builds (the sampler's randn is drawn BEFORE the randint of the
+    sub-sample, bcores.py:39 then :53)."""
+    rng = np.random.RandomState(2100)
+    N, D, S = 700, 8, 40
+    Z, ths, _ = logistic_problem(rng, N, D, S)
+    mu0 = np.zeros(D)
+
+    def sampler_w(sz, w, pts):
+        if pts.shape[0] == 0:
+            w = np.zeros(1)
+            pts = np.zeros((1, Z.shape[1]))
+        muw, LSigw, _ = R.opt.get_laplace(w, pts, mu0, False)
+        return muw + np.random.randn(sz, muw.shape[0]).dot(LSigw.T)
+    fresh = lambda: dict(wts=np.array([]), idcs=np.array([], dtype=np.int64), pts=np.array([]))
+    out = dict(Z=Z)
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        for nm in ('bcores', 'svi'):
+            np.random.seed(210)
+            if nm == 'bcores':
+                prj = R.projector.BetaBlackBoxProjector(sampler_w, S, R.lr.beta_likelihood, R.lr.log_likelihood, None)
+                alg = R.bcores.BetaCoreset(Z, prj, opt_itrs=8, n_subsample_opt=60, n_subsample_select=150,
+                                           step_sched=lambda i: 0.5 / (1. + i), beta=.1, learn_beta=False, **fresh())
+            else:
+                prj = R.projector.BlackBoxProjector(sampler_w, S, R.lr.log_likelihood)
+                alg = R.sparsevi.SparseVICoreset(Z, prj, opt_itrs=8, n_subsample_opt=60, n_subsample_select=150,
+                                                 step_sched=lambda i: 0.5 / (1. + i), **fresh())
+            for m in range(6):
+                quiet(alg.build, 1, m + 1)
+                out['%s_allw_%d' % (nm, m)] = alg.wts.copy()
+                out['%s_allidcs_%d' % (nm, m)] = alg.idcs.copy()
+            out['%s_rng_after' % nm] = np.array(np.random.rand())
+    save('f21_logistic_subsampled', **out)
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])
     if only:
@@ -1102,3 +1140,4 @@ if __name__ == '__main__':
     f18_zellner_gaussian_bpsvi_rand()
     f19_logistic_greedy_vi()
     f20_logistic_beta_constant_rows()
+    f21_logistic_subsampled()

@@ -408,3 +408,26 @@ def test_f20_logistic_beta_constant_rows(bc, S, constant_from):
             alg.build(1, m + 1)
             np.testing.assert_array_equal(alg.idcs, g['S%d_b%g_allidcs_%d' % (S, beta, m)])
             np.testing.assert_allclose(alg.wts, g['S%d_b%g_allw_%d' % (S, beta, m)], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+def test_f21_logistic_subsampled_goldens(bc, nm):
+    """The logistic drivers' actual wiring (zellner_logreg/main.py:152-160): n_subsample_opt / n_subsample_select with the Laplace
+    sampler on the global NumPy stream -- selections, weights and the stream position after six builds equal the reference's."""
+    g = load_golden('f21_logistic_subsampled')
+    Z = g['Z']
+    D, S = Z.shape[1], 40
+    model = bc.likelihoods.LogisticRegression()
+    np.random.seed(210)
+    sampler = bc.samplers.LogisticLaplaceSampler(np.zeros(D))
+    if nm == 'bcores':
+        alg = bc.BetaCoreset(Z, bc.DeviceBetaProjector(sampler, S, model), opt_itrs=8, n_subsample_opt=60, n_subsample_select=150,
+                             step_sched=lambda i: 0.5 / (1. + i), beta=.1, learn_beta=False)
+    else:
+        alg = bc.SparseVICoreset(Z, bc.DeviceProjector(sampler, S, model), opt_itrs=8, n_subsample_opt=60, n_subsample_select=150,
+                                 step_sched=lambda i: 0.5 / (1. + i))
+    for m in range(6):
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+        np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-5, atol=1e-12)
+    assert np.random.rand() == float(g['%s_rng_after' % nm])

@@ -582,3 +582,31 @@ def test_f20_logistic_beta_constant_rows(S):
                 alg.build(1, m + 1)
                 np.testing.assert_array_equal(alg.idcs, g['S%d_b%g_allidcs_%d' % (S, beta, m)])
                 np.testing.assert_allclose(alg.wts, g['S%d_b%g_allw_%d' % (S, beta, m)], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize('nm', ['bcores', 'svi'])
+def test_f21_logistic_subsampled(nm):
+    """The logistic drivers' actual wiring (zellner_logreg/main.py:152-160): sub-sampled tangent spaces, Laplace sampler on the
+    global NumPy stream (its randn before the sub-sample's randint, bcores.py:39 then :53)."""
+    g = load_golden('f21_logistic_subsampled')
+    Z = g['Z']
+    D, S = Z.shape[1], 40
+
+    def sampler(wts, pts):
+        if pts.shape[0] == 0:
+            wts, pts = np.zeros(1), np.zeros((1, D))
+        mu, L, _ = M.logistic_laplace(wts, pts, np.zeros(D), False)
+        return mu + np.random.randn(S, D).dot(L.T)
+    if nm == 'bcores':
+        proj = lambda pts, th: C.project_f(M.logistic_beta_lik, pts, th, 0.1)
+    else:
+        proj = lambda pts, th: C.project(M.logistic_loglik, pts, th)
+    np.random.seed(210)
+    with np.errstate(all='ignore'):
+        sampler(np.array([]), np.array([]))                 # the projector constructor draws once (projector.py:18,46)
+        alg = C.RefGreedyVI(Z, proj, sampler, 8, lambda i: 0.5 / (1. + i), n_subsample_select=150, n_subsample_opt=60)
+        for m in range(6):
+            alg.build(1, m + 1)
+            np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
+            np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-9, atol=1e-13)
+    assert np.random.rand() == float(g['%s_rng_after' % nm])
