@@ -83,3 +83,21 @@ def test_sharded_solver_protocol_matches_single_rank_oracle(tmp_path, mode):
         np.testing.assert_allclose(r['w_dense'], ref.w, rtol=1e-9, atol=1e-15)
         np.testing.assert_allclose(float(r['err']), ref.error(), rtol=1e-9)
     assert np.array_equal(r0['val'], r1['val'])                       # replicated state is bit-identical
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_sharded_solver_protocol_at_more_ranks(tmp_path, world):
+    """The same exchange protocol at the world sizes the scaling bench runs (4, 8): every rank ends with the single-rank oracle's
+    coreset, the replicated state bit-identical on all of them (and therefore independent of the world size)."""
+    from dist_worker import problem
+    from oracle import RefGIGA
+    phi = problem()
+    ref = RefGIGA(phi.T, phi.sum(axis=0))
+    ref.build(30)
+    ridx = np.where(ref.w > 0)[0]
+    res = launch('fake_giga', tmp_path, world=world, timeout=400)
+    for r in res:
+        np.testing.assert_array_equal(r['idx'], ridx)
+        np.testing.assert_allclose(r['val'], ref.w[ridx], rtol=1e-9)
+        np.testing.assert_allclose(float(r['err']), ref.error(), rtol=1e-9)
+        assert np.array_equal(r['val'], res[0]['val'])

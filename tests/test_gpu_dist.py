@@ -41,6 +41,28 @@ def test_two_ranks_one_gpu_hilbert(tmp_path, mode):
     assert np.array_equal(pts, Z[ref.idcs])
 
 
+def test_four_ranks_one_gpu_hilbert(tmp_path):
+    """World size 4 (four ranks sharing GPU 0 over gloo; the pool allows six processes on a card): each rank sweeps a quarter
+    of the rows with the real kernels, the replicated finish picks among FOUR records per step -- the same coreset as the
+    single-rank device run and the oracle, bit-identical state on all ranks."""
+    import beta_cores_amd as bc
+    Z, th = linreg_problem()
+    ref = C.RefHilbert(Z, lambda z, t: M.linreg_loglik(z, t, 1.0), th, RefGIGA)
+    ref.build(25, 25)
+    single = bc.HilbertCoreset(Z, bc.DeviceProjector(lambda n, w, p: th, th.shape[0], bc.likelihoods.LinearRegression(1.0)))
+    single.build(25, 25)
+    res = launch('gpu_hilbert', tmp_path, world=4, timeout=400)
+    for r in res:
+        np.testing.assert_array_equal(r['idx'], ref.idcs)
+        np.testing.assert_allclose(r['val'], single.wts, rtol=1e-9)
+        np.testing.assert_array_equal(r['trace_f'], single.snnls._eng.trace()[0])
+        assert np.array_equal(r['val'], res[0]['val'])
+    pts = res[0]['pts']
+    for r in res[1:]:
+        pts = np.where(np.isnan(pts), r['pts'], pts)
+    assert np.array_equal(pts, Z[ref.idcs])
+
+
 def test_two_ranks_one_gpu_beta_coreset(tmp_path):
     import beta_cores_amd as bc
     Z, th = linreg_problem()
