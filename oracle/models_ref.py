@@ -6,6 +6,8 @@ BLAS, results are bit-identical:
   examples/common/model_linreg.py:4-10,25-34      linreg log-lik, weighted_post
   examples/common/model_neurlinr.py:90-97,102-110 same log-lik, beta-likelihood
   examples/common/model_lr.py:72-86               logistic log-lik, beta-likelihood
+  examples/common/model_lr.py:88-153              log-prior / log-joint and its theta-gradient, Hessian, diagonal Hessian
+  bayesiancoresets/util/opt.py:9-33               get_laplace (== examples/zellner_logreg/main.py:86-111), the logistic drivers' sampler
   examples/common/gaussian.py:7-15,28-62          Gaussian-location model
 """
 import numpy as np
