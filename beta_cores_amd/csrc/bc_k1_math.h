@@ -123,8 +123,11 @@ BC_KM double bc_rcp_1_2(double f) {
 //   (1+e^-m)^(-b-1) = exp(c2 L2)                                   exp #2
 //   (1+e^m)^(-b-1)  = exp(c1 L1) / (1+e^m) = exp(c1 L1) * w / f,   w = 1 (m <= 0) or u = e^-|m| (m > 0),  f = 1 + u
 // i.e. exp(-|m|), one log1p, two exp and one reciprocal of f in [1, 2] (round 3 took a third exp for the last line).
-// Same saturation as the reference's IEEE overflow semantics (m -> +inf: +1, m -> -inf: -1/b exactly as -(c0 - 1)); where
-// the reference flushes (1+inf)^a to exactly 0 this gives < 1e-30: far below the 1e-11 of the parity tolerance.  NaN in, NaN out.
+// Same saturation as the reference's IEEE overflow semantics (m -> +inf: +1, m -> -inf: -1/b exactly as -(c0 - 1)).  Where
+// np.exp overflows the reference's powers flush to EXACTLY 0: for the two powers with exponent -b-1 <= -1 the smooth value is
+// below 1e-308 there, but (1+e^m)^-b at m = 709.78 is exp(-709.78 b) -- 1e-31 at b = 0.1 and 8e-4 at b = 0.01 (times c0 = 101) --
+// so the first power takes the reference's cutoff: exactly 0 for m > log(DBL_MAX) (golden F22).  NaN in, NaN out.
+#define BC_EXP_OVERFLOW_ARG 709.782712893384          // largest m with finite exp(m) (0x40862E42FEFA39EF)
 BC_KM double bc_logistic_beta_value(double m, double c0, double c1, double c2, const double* tab) {
   const double am = fmin(fabs(m), 800.);              // beyond that every term has saturated (fmin drops a NaN: restored below)
   double u, f;
@@ -132,7 +135,8 @@ BC_KM double bc_logistic_beta_value(double m, double c0, double c1, double c2, c
   const double Ll = Ls + am;                          // log(1 + e^+|m|)
   const int neg = m <= 0.;
   const double L1 = neg ? Ls : Ll, L2 = neg ? Ll : Ls;
-  const double e1 = bc_exp_tab_core(c1 * L1, tab);    // arguments in [-(b+1) * 801, 0]
+  const double e1s = bc_exp_tab_core(c1 * L1, tab);   // arguments in [-(b+1) * 801, 0]
+  const double e1 = (m > BC_EXP_OVERFLOW_ARG) ? 0. : e1s;          // (1 + inf)^-b == 0 in the reference (model_lr.py:85)
   const double e3 = bc_exp_tab_core(c2 * L2, tab);
   const double e2 = e1 * ((neg ? 1. : u) * bc_rcp_1_2(f));
   const double v = -((c0 * e1) - (e2 + e3));

@@ -58,15 +58,45 @@ int64_t bc_upload_default_chunk_rows(int64_t n_rows, int32_t dz) {
   return rows < 1 ? 1 : rows;
 }
 
+static void uploader_destroy(bc_uploader* u);
+
 void bc_uploader_free(bc_ctx* ctx) {
   bc_uploader* u = ctx->upl;
   if (!u) return;
+  uploader_destroy(u);
+  ctx->upl = nullptr;
+}
+
+// all the resources of an uploader, or none: a failure part-way frees what exists and leaves ctx->upl untouched, so that a
+// later call never meets an uploader whose streams / staging buffers / events are fewer than its nthreads promises
+static void uploader_destroy(bc_uploader* u) {
   for (auto s : u->streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   for (auto p : u->staging) (void)hipHostFree(p);
   for (auto e : u->stg_ev) (void)hipEventDestroy(e);
   for (auto e : u->landed) (void)hipEventDestroy(e);
   delete u;
-  ctx->upl = nullptr;
+}
+
+static int uploader_build(bc_uploader* u, int nthreads) {
+  u->nthreads = nthreads;
+  u->sub_bytes = (size_t)8 << 20;
+  const char* env = getenv("BC_UPLOAD_SUB_MB");
+  if (env && atoi(env) > 0) u->sub_bytes = (size_t)atoi(env) << 20;
+  for (int t = 0; t < (nthreads > 0 ? nthreads : 1); ++t) {
+    hipStream_t s;
+    BC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    u->streams.push_back(s);
+    for (int k = 0; k < (nthreads > 0 ? 2 : 0); ++k) {
+      void* p = nullptr;
+      BC_HIP(hipHostMalloc(&p, u->sub_bytes, hipHostMallocDefault));
+      u->staging.push_back(p);
+      hipEvent_t e;
+      BC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+      u->stg_ev.push_back(e);
+      u->stg_used.push_back(0);
+    }
+  }
+  return BC_OK;
 }
 
 static int uploader_get(bc_ctx* ctx, int nthreads, size_t nchunks, bc_uploader** out) {
@@ -77,25 +107,12 @@ static int uploader_get(bc_ctx* ctx, int nthreads, size_t nchunks, bc_uploader**
   }
   if (!u) {
     u = new bc_uploader();
-    ctx->upl = u;
-    u->nthreads = nthreads;
-    u->sub_bytes = (size_t)8 << 20;
-    const char* env = getenv("BC_UPLOAD_SUB_MB");
-    if (env && atoi(env) > 0) u->sub_bytes = (size_t)atoi(env) << 20;
-    for (int t = 0; t < (nthreads > 0 ? nthreads : 1); ++t) {
-      hipStream_t s;
-      BC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-      u->streams.push_back(s);
-      for (int k = 0; k < (nthreads > 0 ? 2 : 0); ++k) {
-        void* p = nullptr;
-        BC_HIP(hipHostMalloc(&p, u->sub_bytes, hipHostMallocDefault));
-        u->staging.push_back(p);
-        hipEvent_t e;
-        BC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
-        u->stg_ev.push_back(e);
-        u->stg_used.push_back(0);
-      }
+    const int rc = uploader_build(u, nthreads);
+    if (rc != BC_OK) {
+      uploader_destroy(u);
+      return rc;
     }
+    ctx->upl = u;
   }
   while (u->landed.size() < nchunks) {
     hipEvent_t e;

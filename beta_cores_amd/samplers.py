@@ -228,6 +228,13 @@ class LogisticLaplaceSampler(_PosteriorSampler):
     def _dim(self):
         return self.mu0.shape[0]
 
+    def prefetch(self):
+        """No look-ahead with the reference's mode search: a failing `minimize` draws its restart perturbation `randn(D)`
+        BEFORE the sample normals (main.py:96-101, then :144), so a block drawn ahead would come from the wrong place in the
+        stream on such a call.  The Newton search draws nothing, and prefetching stays on for it."""
+        if self.solver != 'bfgs':
+            super().prefetch()
+
     def __call__(self, n, wts, pts):
         d = self.mu0.shape[0]
         if pts.shape[0] == 0:

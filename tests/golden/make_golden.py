@@ -1114,6 +1114,29 @@ def f21_logistic_subsampled():
     save('f21_logistic_subsampled', **out)
 
 
+# ---------------------------------------------------------------- F22: np.exp's overflow inside the logistic beta-likelihood
+def f22_logistic_beta_overflow():
+    """model_lr.py:81-86 at |m| around log(DBL_MAX) = 709.78 with SMALL beta: past it np.exp(m) is inf and the reference's
+    (1 + inf)**(-beta) is exactly 0 -- a jump of c0 * exp(-beta * 709.78) (0.08 at beta = 0.01) that a smooth evaluation
+    misses.  Rows whose sample-0 margin is forced to the listed values; beta in {0.01, 0.05, 0.1}."""
+    rng = np.random.RandomState(22)
+    N, D, S = 40, 8, 20
+    X = rng.randn(N, D)
+    th = rng.randn(S, D) / np.sqrt(D)
+    y = np.where(rng.rand(N) < 0.5, 1., -1.)
+    Z = y[:, None] * X
+    mags = (700., 709., 709.7, 709.78, 709.79, 710., 720., 745.2, 760., 799., 801., 1500.,      # (none within rounding of the jump)
+            -700., -709.79, -710., -745.2, -746., -1500.)
+    for r, mag in enumerate(mags):
+        Z[r] = -mag * th[0] / (th[0] ** 2).sum()
+    out = dict(Z=Z, th=th, mags=np.array(mags))
+    with np.errstate(over='ignore'):
+        for beta in (0.01, 0.05, 0.1):
+            out['bl_b%g' % beta] = R.lr.beta_likelihood(Z, th, beta)
+    out['m'] = -Z.dot(th.T)
+    save('f22_logistic_beta_overflow', **out)
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])
     if only:
@@ -1141,3 +1164,4 @@ if __name__ == '__main__':
     f19_logistic_greedy_vi()
     f20_logistic_beta_constant_rows()
     f21_logistic_subsampled()
+    f22_logistic_beta_overflow()

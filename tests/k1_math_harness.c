@@ -63,6 +63,16 @@ int main(int argc, char** argv) {
     if (bc_logistic_beta_value(-900., c0, c1, c2, tab) != -(c0 - 1.0)) { printf("beta-lik -inf limit BAD\n"); return 1; }
     if (bc_logistic_beta_value(-47., c0, c1, c2, tab) != -(c0 - 1.0)) { printf("beta-lik saturated row not constant\n"); return 1; }
   }
+  {
+    /* np.exp's overflow (golden F22): past log(DBL_MAX) the reference's (1 + inf)^-b is exactly 0 and the value exactly 1;
+       just below it the smooth formula holds -- at b = 0.01 the two differ by 0.083 */
+    const double b = 0.01, c0 = (b + 1.) / b, c1 = -b, c2 = -b - 1.;
+    if (bc_logistic_beta_value(709.79, c0, c1, c2, tab) != 1.0 || bc_logistic_beta_value(745., c0, c1, c2, tab) != 1.0 ||
+        bc_logistic_beta_value(5000., c0, c1, c2, tab) != 1.0) { printf("beta-lik exp-overflow cutoff BAD\n"); return 1; }
+    const double below = bc_logistic_beta_value(709.78, c0, c1, c2, tab);
+    const long double wantb = -(((long double)c0) * powl(1.L + expl(709.78L), (long double)c1) - (powl(1.L + expl(709.78L), (long double)c2) + 1.L));
+    if (fabsl((long double)below - wantb) > 1e-14L || below > 0.92) { printf("beta-lik below the cutoff BAD %.17g\n", below); return 1; }
+  }
   printf("logistic_beta_value: max abs err %.3g (values are O(1..1/beta))\n", bmax);
   if (!(bmax < 1e-14)) return 1;
   /* special values */

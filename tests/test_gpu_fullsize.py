@@ -232,14 +232,17 @@ def test_config4_headline_size(env, shard):
 
 def test_config4_all_rows_vs_oracle(env):
     """The headline workload with NOTHING sampled: all 10M rows of bench.py's data recipe through the NumPy oracle on the
-    host (its own K1 in row chunks, then GIGA) and through the device path; the selections of the first greedy iterations
-    are identical and the weights agree.  (bench.py's cpu_baseline leg makes the same comparison inside the driver's run;
-    here a difference is a red test.)  ~35 s of host work, 8 GB of host memory for the oracle's Phi."""
+    host (its own K1 in row chunks, then the solver) and through the device path; the selections of the first greedy
+    iterations are identical and the weights agree -- GIGA (giga.py:20-64), FrankWolfe (frankwolfe.py:15-40) and
+    OrthoPursuit (orthopursuit.py:17-42) on the same 8 GB `phi_ref`.  (bench.py's cpu_baseline leg makes the GIGA comparison
+    inside the driver's run; here a difference is a red test.)  ~60 s of host work, 8 GB of host memory for the oracle's Phi."""
     import sys
     sys.path.insert(0, ROOT)
     import bench
+    from oracle import RefFrankWolfe, RefOrthoPursuit
     bc, torch, ctx = env
-    N, D, S, ITERS = 10_000_000, 128, 100, 6
+    N, D, S = 10_000_000, 128, 100
+    ITERS = {'giga': 6, 'fw': 5, 'omp': 4}
     dev = torch.device('cuda', ctx.device)
     g0 = torch.Generator(device=dev)
     g0.manual_seed(39)
@@ -250,13 +253,20 @@ def test_config4_all_rows_vs_oracle(env):
     mu, L, _ = bc.weighted_post(np.zeros(D), np.eye(D), 1.0, data, None)
     theta = mu + np.random.default_rng(41).standard_normal((S, D)).dot(L.T)
     model = bc.likelihoods.LinearRegression(1.0)
-    h = bc.HilbertCoreset(data, bc.DeviceProjector(lambda k, w, p: theta, S, model, ctx=ctx))
-    h.build(ITERS, ITERS)
-    dsel = h.snnls._eng.trace()[0][:ITERS]
-    didx, dwts = h.idcs.copy(), h.wts.copy()
-    derr = h.error()
-    del h
-    torch.cuda.empty_cache()
+    dev_out = {}
+    for nm, cls in (('giga', bc.snnls.GIGA), ('fw', bc.snnls.FrankWolfe), ('omp', bc.snnls.OrthoPursuit)):
+        h = bc.HilbertCoreset(data, bc.DeviceProjector(lambda k, w, p: theta, S, model, ctx=ctx), snnls=cls)
+        if nm == 'omp':
+            sel = []
+            for m in range(ITERS[nm]):            # OrthoPursuit runs the step-wise protocol (NNLS refit on the host)
+                h.build(1, m + 1)
+                sel.append(h.idcs.copy())
+        else:
+            h.build(ITERS[nm], ITERS[nm])
+            sel = h.snnls._eng.trace()[0][:ITERS[nm]]
+        dev_out[nm] = (sel, h.idcs.copy(), h.wts.copy(), h.error())
+        del h
+        torch.cuda.empty_cache()
     ll = lambda z, t: M.linreg_loglik(z, t, 1.0)
     phi_ref = np.empty((N, S))
     CH = 1_000_000
@@ -267,14 +277,116 @@ def test_config4_all_rows_vs_oracle(env):
             phi_ref[a + b:a + b + blk.shape[0]] = C.project(ll, blk, theta)
     del Z, data
     torch.cuda.empty_cache()
-    ref = RefGIGA(phi_ref.T, phi_ref.sum(axis=0))
-    ref.build(ITERS)
-    rsel = np.array([t[0] for t in ref.trace])
-    np.testing.assert_array_equal(dsel, rsel)
-    ridx = np.where(ref.w > 0)[0]
-    np.testing.assert_array_equal(didx, ridx)
-    np.testing.assert_allclose(dwts, ref.w[ridx], rtol=1e-5)
-    assert abs(derr - ref.error()) <= 1e-6 * max(1., ref.error())
+    bsum = phi_ref.sum(axis=0)
+    for nm, cls in (('giga', RefGIGA), ('fw', RefFrankWolfe), ('omp', RefOrthoPursuit)):
+        dsel, didx, dwts, derr = dev_out[nm]
+        ref = cls(phi_ref.T, bsum)
+        if nm == 'omp':
+            for m in range(ITERS[nm]):
+                ref.build(1)
+                np.testing.assert_array_equal(dsel[m], np.where(ref.w > 0)[0], err_msg=nm)
+        else:
+            ref.build(ITERS[nm])
+            np.testing.assert_array_equal(dsel, np.array([t[0] for t in ref.trace]), err_msg=nm)
+        ridx = np.where(ref.w > 0)[0]
+        np.testing.assert_array_equal(didx, ridx, err_msg=nm)
+        np.testing.assert_allclose(dwts, ref.w[ridx], rtol=1e-5, err_msg=nm)
+        assert abs(derr - ref.error()) <= 1e-6 * max(1., ref.error()), nm
+        del ref
+
+
+# ------------------------------------------------------------------ the beta-Cores loop itself at configs[1] / configs[2] size
+_BCORES_ORACLE = {}
+_BCORES_CFGS = ['linreg_1M_64', 'logistic_1M_128', 'logistic_1M_128_laplace']
+
+
+def _bcores_case(bc, torch, cfg):
+    """Data, beta-likelihood and sampler of one stated-size BetaCoreset case.  The samplers are host closures
+    (projector.py:37,66 calls them with the <= M coreset rows) and the SAME closure serves the oracle and the device run."""
+    S, beta, opt_itrs = 100, 0.1, 3
+    if cfg == 'linreg_1M_64':
+        n, d, kind = 1_000_000, 64, 'linreg'
+        Z, thstar = gen(torch, n, d, 20, kind)
+        E = np.random.default_rng(8).standard_normal((S, d))
+
+        def sampler(sz, wts, pts):
+            # the drivers' sampler_w (zellner_neural_linear/main.py:119-124) with fixed normals: Theta follows the CURRENT
+            # coreset, so every gradient projects all rows under a different Theta
+            if pts.shape[0] == 0:
+                wts, pts = np.zeros(1), np.zeros((1, d + 1))
+            mu, L, _ = M.linreg_weighted_post(np.zeros(d), np.eye(d), 1.0, pts, wts)
+            return mu + E.dot(L.T)
+        blik = lambda z, t, b: M.linreg_beta_lik(z, t, b, 1.0)
+    else:
+        n, d, kind = 1_000_000, 128, 'logistic'
+        Z, thstar = gen(torch, n, d, 30, kind)
+        E = np.random.default_rng(9).standard_normal((S, d))
+        if cfg == 'logistic_1M_128':
+            theta = thstar.cpu().numpy() + 0.1 * E
+            sampler = lambda sz, wts, pts: theta
+        else:
+            # the logistic drivers' sampler_w (zellner_logreg/main.py:139-144) with fixed normals and the Newton mode search
+            # (converged to the rounding floor: a smooth function of (wts, pts), unlike BFGS's stopping point) -- bench.py's
+            # fast config-3 loop
+            class FixedNormals:
+                def randn(self, a, b):
+                    return E
+            sampler = bc.samplers.LogisticLaplaceSampler(np.zeros(d), rng=FixedNormals(), solver='newton')
+        blik = M.logistic_beta_lik
+    return Z, S, beta, opt_itrs, kind, sampler, blik
+
+
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('cfg', _BCORES_CFGS)
+def test_beta_coreset_steps_at_stated_size_vs_oracle(env, cfg, fused):
+    """`BetaCoreset.build(2, 2)` with `opt_itrs = 3` at BASELINE configs[1] (N = 1M, D = 64, beta-likelihood of the linear
+    regression, model_neurlinr.py:102-110; Theta follows the coreset posterior) and configs[2] (N = 1M, D = 128, logistic
+    beta-likelihood, model_lr.py:81-86; once with a fixed Theta, once with the Laplace sampler) against
+    `oracle.coreset_ref.RefGreedyVI` (bcores.py:74-150) on ALL rows (its K1 in row chunks on the host, ~20-40 s per case): the
+    selected rows are identical and the weights agree within 1e-5 after every build, through the fused store-free gradient
+    (bc_vi_gradient) and through the materialising one.  Step sizes of 2e5 / (1 + i) take the weights to the N / M scale
+    the drivers reach, so that the second selection sees a residual the first point has changed."""
+    from concurrent.futures import ThreadPoolExecutor
+    bc, torch, ctx = env
+    Z, S, beta, opt_itrs, kind, sampler, blik = _bcores_case(bc, torch, cfg)
+    sched = lambda i: 2e5 / (1. + i)
+    if cfg not in _BCORES_ORACLE:
+        Zh = Z.cpu().numpy()
+        CH = 50_000
+        pool = ThreadPoolExecutor(8)
+
+        def one(args):
+            with np.errstate(over='ignore'):
+                return C.project_f(blik, args[0], args[1], beta)
+
+        def proj(pts, th):                       # rows are independent (projector.py:53-55 centres per row)
+            if pts.shape[0] <= CH:
+                return one((pts, th))
+            return np.concatenate(list(pool.map(one, [(pts[a:a + CH], th) for a in range(0, pts.shape[0], CH)])))
+        if hasattr(sampler, '_mode'):
+            sampler._mode = None                 # the oracle's run starts the mode search where the device run will
+        ref = C.RefGreedyVI(Zh, proj, lambda w, p: sampler(S, w, p), opt_itrs, sched)
+        out = []
+        for m in range(2):
+            ref.build(1, m + 1)
+            out.append((ref.idcs.copy(), ref.wts.copy()))
+        _BCORES_ORACLE[cfg] = out
+        pool.shutdown()
+        del ref, Zh
+    if hasattr(sampler, '_mode'):
+        sampler._mode = None
+    data = bc.DeviceData.from_torch(Z, ctx=ctx)
+    model = bc.likelihoods.LogisticRegression() if kind == 'logistic' else bc.likelihoods.LinearRegression(1.0)
+    alg = bc.BetaCoreset(data, bc.DeviceBetaProjector(sampler, S, model, ctx=ctx), opt_itrs=opt_itrs, step_sched=sched, beta=beta,
+                         learn_beta=False, fused_gradient=fused)
+    for m in range(2):
+        alg.build(1, m + 1)
+        ridx, rw = _BCORES_ORACLE[cfg][m]
+        np.testing.assert_array_equal(alg.idcs, ridx)
+        np.testing.assert_allclose(alg.wts, rw, rtol=1e-5, atol=1e-12)
+    np.testing.assert_array_equal(alg.pts, data.rows(alg.idcs))
+    del alg, data, Z
+    torch.cuda.empty_cache()
 
 
 def test_config1_stated_size_giga_vs_oracle():

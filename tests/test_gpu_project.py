@@ -64,6 +64,16 @@ def test_f2_logistic_incl_overflow_branches(bc):
         check_phi(prj.project_f(Z, beta), g['log_bl_b%g' % beta])   # exp overflow -> inf -> pow(inf, -b) = 0, no NaN
 
 
+def test_f22_logistic_beta_exp_overflow_with_small_beta(bc):
+    """Past np.exp's overflow (m > 709.78) the reference's (1 + inf)**(-beta) is exactly 0: at beta = 0.01 the value jumps by
+    0.083 there, which the library's first power reproduces with the same cutoff (csrc/bc_k1_math.h); golden F22, rows with
+    margins 700 ... 1500 and -700 ... -1500 on both sides of the jump, beta in {0.01, 0.05, 0.1}."""
+    g = load_golden('f22_logistic_beta_overflow')
+    Z, th = g['Z'], g['th']
+    prj = bc.DeviceBetaProjector(fixed(th), th.shape[0], bc.likelihoods.LogisticRegression())
+    for beta in (0.01, 0.05, 0.1):
+        check_phi(prj.project_f(Z, beta), g['bl_b%g' % beta])
+
 def test_f2_gaussian_location(bc):
     g = load_golden('f2_formulas')
     X, th = g['gau_X'], g['gau_th']

@@ -610,3 +610,14 @@ def test_f21_logistic_subsampled(nm):
             np.testing.assert_array_equal(alg.idcs, g['%s_allidcs_%d' % (nm, m)])
             np.testing.assert_allclose(alg.wts, g['%s_allw_%d' % (nm, m)], rtol=1e-9, atol=1e-13)
     assert np.random.rand() == float(g['%s_rng_after' % nm])
+
+
+def test_f22_logistic_beta_exp_overflow():
+    """model_lr.py:85 past np.exp's overflow with small beta: (1 + inf)**(-beta) == 0 exactly, the value jumps to 1."""
+    g = load_golden('f22_logistic_beta_overflow')
+    with np.errstate(over='ignore'):
+        for beta in (0.01, 0.05, 0.1):
+            got = M.logistic_beta_lik(g['Z'], g['th'], beta)
+            np.testing.assert_array_equal(got, g['bl_b%g' % beta])
+    i709, i710 = list(g['mags']).index(709.78), list(g['mags']).index(709.79)
+    assert g['bl_b0.01'][i710, 0] == 1.0 and 0.916 < g['bl_b0.01'][i709, 0] < 0.917

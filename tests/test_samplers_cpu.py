@@ -26,7 +26,7 @@ def test_logistic_laplace_sampler_prior_and_stream():
     per call, and a prefetched block is the one the next call uses."""
     from beta_cores_amd.samplers import LogisticLaplaceSampler
     D, S = 5, 7
-    smp = LogisticLaplaceSampler(np.zeros(D), rng=np.random.RandomState(3))
+    smp = LogisticLaplaceSampler(np.zeros(D), rng=np.random.RandomState(3), solver='newton')
     th = smp(S, np.array([]), np.array([]))
     ref = np.random.RandomState(3)
     e0 = ref.randn(S, D)
@@ -41,11 +41,41 @@ def test_logistic_laplace_sampler_prior_and_stream():
 
 def test_prefetched_block_of_another_shape_is_an_error():
     from beta_cores_amd.samplers import LogisticLaplaceSampler
-    smp = LogisticLaplaceSampler(np.zeros(4), rng=np.random.RandomState(0))
+    smp = LogisticLaplaceSampler(np.zeros(4), rng=np.random.RandomState(0), solver='newton')
     smp(6, np.array([]), np.array([]))
     smp.prefetch()
     with pytest.raises(RuntimeError, match='prefetched'):
         smp(9, np.array([]), np.array([]))
+
+
+def test_no_look_ahead_with_the_reference_mode_search(monkeypatch):
+    """With solver='bfgs' a failing minimize() draws its restart perturbation BEFORE the sample normals (main.py:96-101, :144):
+    prefetch() must not take the normals from the stream ahead of it.  A mode search that fails once, then succeeds: the
+    stream is consumed as perturbation-then-normals, exactly like the reference's closure."""
+    import beta_cores_amd.samplers as SM
+    D, S = 4, 3
+    rng = np.random.RandomState(11)
+    Z = rng.randn(9, D)
+    w = np.full(9, 2.)
+    real = SM.minimize
+    fails = [1]
+
+    def flaky(*a, **k):
+        if fails[0] > 0:
+            fails[0] -= 1
+            raise FloatingPointError('injected')
+        return real(*a, **k)
+    monkeypatch.setattr(SM, 'minimize', flaky)
+    smp = SM.LogisticLaplaceSampler(np.full(D, 0.3), rng=np.random.RandomState(5))
+    smp._shape = (S, D)
+    smp.prefetch()                                                  # must be a no-op for 'bfgs'
+    assert smp._ahead is None
+    th = smp(S, w, Z)
+    ref = np.random.RandomState(5)
+    mu0 = np.full(D, 0.3)
+    mu0 = mu0 + np.sqrt((mu0 ** 2).sum()) * 0.1 * ref.randn(D)     # the restart's draw comes first
+    mu, L, _ = SM.logistic_laplace(w, Z, mu0)
+    np.testing.assert_allclose(th, mu + ref.randn(S, D).dot(L.T), rtol=1e-9, atol=1e-12)
 
 
 def test_logistic_beta_constant_at_zero_is_numpys():
@@ -107,3 +137,41 @@ def test_newton_warm_start_reaches_the_same_mode():
         cold = LogisticLaplaceSampler(np.zeros(D), rng=E(), solver='newton')
         np.testing.assert_allclose(warm(S, w, Z), cold(S, w, Z), rtol=1e-10, atol=1e-12)
     assert warm._mode is not None and cold._mode is not None
+
+
+@pytest.mark.parametrize('S,sn,nm', [(37, 'laplace', 'svi'), (100, 'laprng', 'bcores'), (37, 'lapdiag', 'bcores')])
+def test_newton_sampler_in_the_oracle_loop_against_the_goldens(S, sn, nm):
+    """What solver='newton' does to the coreset, asked of the reference's goldens on the host alone (the oracle's greedy-VI
+    loop + the product's sampler): selections exact, weights within 1e-5 -- 1.76e-5 for one weight of the first case, whose
+    golden value carries BFGS's stopping noise (tests/test_gpu_coresets.py runs all ten cases through the device)."""
+    from oracle import models_ref as M, coreset_ref as C
+    from beta_cores_amd.samplers import LogisticLaplaceSampler
+    g = load_golden('f19_logistic_greedy_vi')
+    tag = 'S%d_' % S
+    Z, E = g[tag + 'Z'], g[tag + 'E']
+    beta, opt_itrs = float(g['beta']), int(g['opt_itrs'])
+
+    class FixedNormals:
+        def randn(self, n, d):
+            return E
+    smp = LogisticLaplaceSampler(np.zeros(Z.shape[1]), diag=(sn == 'lapdiag'), rng=None if sn == 'laprng' else FixedNormals(),
+                                 solver='newton')
+    if nm == 'bcores':
+        proj = lambda pts, th: C.project_f(M.logistic_beta_lik, pts, th, beta)
+    else:
+        proj = lambda pts, th: C.project(M.logistic_loglik, pts, th)
+    np.random.seed(190)
+    worst = 0.
+    with np.errstate(all='ignore'):
+        smp(S, np.array([]), np.zeros((0, Z.shape[1])))       # the projector constructor draws once (projector.py:18,46)
+        alg = C.RefGreedyVI(Z, proj, lambda w, p: smp(S, w, p), opt_itrs, lambda i: 0.5 / (1. + i))
+        for m in range(5):
+            alg.build(1, m + 1)
+            np.testing.assert_array_equal(alg.idcs, g['%s%s_%s_allidcs_%d' % (tag, sn, nm, m)])
+            gw = g['%s%s_%s_allw_%d' % (tag, sn, nm, m)]
+            np.testing.assert_allclose(alg.wts, gw, rtol=2.5e-5, atol=1e-12)
+            big = np.abs(gw) > 1e-9
+            worst = max(worst, float(np.max(np.abs(alg.wts[big] - gw[big]) / np.abs(gw[big]), initial=0.)))
+    assert worst <= 1e-5 or (S, sn, nm) == (37, 'laplace', 'svi')
+    if sn == 'laprng':
+        assert np.random.rand() == float(g['%s%s_%s_rng_after' % (tag, sn, nm)])
