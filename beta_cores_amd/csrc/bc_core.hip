@@ -202,8 +202,10 @@ extern "C" int bc_data_from_host(bc_ctx* ctx, const double* z, int64_t n_rows, i
     hipError_t e = hipMalloc((void**)&d->z, bytes);
     if (e != hipSuccess) { delete d; return bc_hip_fail(e, "hipMalloc(data)", __FILE__, __LINE__); }
     d->cap_rows = n_rows;
-    // pipelined through pinned staging on several copy streams (bc_upload.hip); ctx->stream waits for every chunk, and the
-    // host buffer is only borrowed for the call (every byte has left it when bc_upload_rows returns)
+    // default: ONE hipMemcpyAsync from the caller's array on ctx->stream, waited for (bc_upload.hip, direct mode: the runtime
+    // moves pageable memory at the link rate here); BC_UPLOAD_THREADS = T >= 1 opts into T host threads copying through
+    // pinned staging on copy streams of their own, with ctx->stream waiting for every chunk.  Either way the host buffer is
+    // only borrowed for the call (every byte has left it when bc_upload_rows returns)
     int rc = bc_upload_rows(ctx, z, d->z, n_rows, dz, bc_upload_default_chunk_rows(n_rows, dz), nullptr);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d->z); delete d; return rc; }
   }

@@ -1379,14 +1379,21 @@ static int launch_chunk(bc_ctx* ctx, const ProjPlan& pl, const bc_data* data, bc
   a.dz = data->dz;
   a.s_total = phi->s;
   a.s_off = 0;
+  // timer class 1 (K1), one span per chunk launch: recorded on ctx->stream behind the wait for the chunk's arrival, so the
+  // span is the kernel, not the transfer it waited for
+  int rc = bc_timer_begin(ctx, 1);
+  if (rc) return rc;
   if (rgrid > 0) {
     a.tile_part = phi->tile_part;                 // one row per wave, shared by all chunks
     a.part_init = first ? 0 : 1;
     a.ngroups = (rows + 31) / 32;
-    return launch_project_r_model<true>(ctx, a, rgrid, pl.model, pl.ntsel);
+    rc = launch_project_r_model<true>(ctx, a, rgrid, pl.model, pl.ntsel);
+  } else {
+    a.tile_part = phi->tile_part + (size_t)tile0 * phi->s;
+    rc = launch_project_model<true>(ctx, a, ntiles, pl.model, pl.ntsel);
   }
-  a.tile_part = phi->tile_part + (size_t)tile0 * phi->s;
-  return launch_project_model<true>(ctx, a, ntiles, pl.model, pl.ntsel);
+  if (!rc) rc = bc_timer_end(ctx, 1);
+  return rc;
 }
 
 extern "C" int bc_project_from_host(bc_ctx* ctx, const double* z_host, int64_t n_rows, int32_t dz, int model, const double* theta,

@@ -311,6 +311,7 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       }
     }
     if (lane == 0) S.skip = S.select_fail | S.reached_limit | S.pf_overflow;
+    FSTAMP(15);
     if (quant) {
       // this wave wrote v (and its LDS copy) itself: a wave-level fence orders the digits' reads behind those stores
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

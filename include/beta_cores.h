@@ -158,8 +158,12 @@ int bc_project(bc_ctx* ctx, const bc_data* data, int model, const double* theta,
                const double* params, int32_t n_params, int64_t row_offset, bc_phi** inout);
 /* K1 straight from a HOST array, upload and projection pipelined: what `HilbertCoreset(data_ndarray, projector)` does at
  * hilbert.py:11 (`ll_projector.project(data)`, projector.py:23-26) and the greedy-VI classes at bcores.py:44.  The rows go
- * to HBM in chunks through pinned staging on copy streams (several host threads; bc_data_from_host uses the same
- * uploader) and K1 runs on chunk c while chunk c+1.. are on the wire.  Phi, norms AND column sums are bit-identical to
+ * to HBM in ~128 MiB chunks, each one `hipMemcpyAsync` straight from the caller's (pageable) array on a copy stream of the
+ * library's own, and K1 runs on chunk c -- behind the event of its arrival -- while chunk c+1.. are on the wire.  (Opt-in,
+ * BC_UPLOAD_THREADS = T >= 1: T host threads copy the chunks through pinned 8 MiB staging buffers, each on its own copy
+ * stream -- for hosts whose pageable copies are slow; bc_data_from_host / bc_data_upload then use the same uploader, by
+ * default they issue one plain hipMemcpyAsync on the context's stream and wait for it.)  K1 launches made here count in
+ * timer class 1 like bc_project's (one span per chunk).  Phi, norms AND column sums are bit-identical to
  * bc_data_from_host + bc_project (the chunks keep the column partials' order of additions).  *out_data: the resident rows
  * (caller destroys); *inout as for bc_project.  z_host is only read during the call. */
 int bc_project_from_host(bc_ctx* ctx, const double* z_host, int64_t n_rows, int32_t dz, int model, const double* theta, int32_t s,

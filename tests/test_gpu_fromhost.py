@@ -128,3 +128,29 @@ def test_from_host_argument_errors(bc):
     prj = bc.DeviceProjector(lambda k, w, p: th, 20, bc.likelihoods.LinearRegression(1.0))
     with pytest.raises(ValueError):
         prj.project(Z)
+
+
+def test_pipelined_k1_launches_count_in_the_k1_timer(bc):
+    """K1 launches made by bc_project_from_host are bracketed like bc_project's (timer class 1): one span per chunk."""
+    rng = np.random.default_rng(6)
+    n, d, S = 300_000, 16, 64
+    Z = linreg(rng, n, d)
+    th = rng.standard_normal((S, d)) * 0.2
+    prj = bc.DeviceProjector(lambda k, w, p: th, S, bc.likelihoods.LinearRegression(1.0))
+    ctx = bc.default_context()
+    with env(BC_PIPE_CHUNK_ROWS=65536):
+        prj.project(Z)                                    # (first use of this kernel instantiation: code-object load, not timed)
+    ctx.enable_timing(1)
+    try:
+        ctx.kernel_time_reset()
+        with env(BC_PIPE_CHUNK_ROWS=65536):
+            prj.project(Z)
+        ms, launches = ctx.kernel_time(1)
+        assert launches == -(-n // 65536) and ms > 0.
+        ctx.kernel_time_reset()
+        prj.project(bc.DeviceData(Z))
+        ms1, launches1 = ctx.kernel_time(1)
+        assert launches1 == 1 and 0.2 * ms1 < ms < 20. * ms1      # five chunk launches ~ one launch over all rows
+    finally:
+        ctx.enable_timing(0)
+        ctx.kernel_time_reset()
