@@ -106,6 +106,18 @@ def posterior_samples(bc, data, d, s, comm):
     return mu + E.dot(L.T)
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return ' '.join(line.split(':', 1)[1].split())
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def sig(x, n=4):
     """n significant digits (the JSON line is meant to be short enough to survive in the driver's record)"""
     if x is None or isinstance(x, (bool, str)):
@@ -852,6 +864,10 @@ def main():
                                    f64['avg_launch_ms'], f64['bytes_per_launch'], 0, f64['steps']),
                             it_s=sig(f64['iterations_per_s']), same_sel=f64['same_selections_as_prefiltered_run']))
         detail['fp64_sweep'] = f64
+        # ... and as an object of its own: SURVEY 8(d)'s formulation (fp64 Phi streamed once per step) timed in this very run
+        out['roofline']['fp64_formulation'] = {'ms': sig(f64['avg_launch_ms']), 'frac': sig(f64['frac_of_hbm_peak']),
+                                               'it_s': sig(f64['iterations_per_s']), 'GB': sig(f64['bytes_per_launch'] / 1e9),
+                                               'same_sel': f64['same_selections_as_prefiltered_run']}
         oc, beta2 = other_configs(torch, bc, ctx, dev, barrier, no_cpu=args.no_cpu)
         detail['other_configs'] = oc
         for e in oc:
@@ -887,7 +903,10 @@ def main():
     Z_host = None
     if rank == 0 and world == 1 and not args.no_host:
         Z_host = Z.cpu().numpy()
-        out['roofline']['from_host'] = from_host_leg(bc, ctx, barrier, Z_host, theta, S, model, cls, f_tr, args)
+        fh = from_host_leg(bc, ctx, barrier, Z_host, theta, S, model, cls, f_tr, args)
+        out['roofline']['from_host'] = fh
+        # the survey's M = 100 run: steps 2..100 of the coreset built from the host array (list lengths 1..100, wall clock)
+        out['ms_per_step_M100'] = sig((fh['M100_ms'] - fh['first_iter_ms']) / 99.0)
 
     # ---------------- CPU baseline (rank 0, N=1 launch only): the NumPy oracle
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -932,6 +951,21 @@ def main():
         t_cit = time.perf_counter() - t0
         # the device run selected the same rows over those first iterations (same Theta, same data, all N rows)
         rsel_full = np.array([t[0] for t in ref.trace])
+        # ... and ONE thread: the same loop from a fresh solver state with the BLAS pool limited to one
+        # thread, capped at two iterations (NumPy's element-wise passes are single-threaded either way)
+        one_thread = None
+        try:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=1):
+                ref1 = Ref(phi_ref.T, ref.b)
+                t0 = time.perf_counter()
+                ref1.build(2)
+                t_1t = time.perf_counter() - t0
+            one_thread = {'value': sig(2.0 / t_1t), 'unit': 'iterations/s', 'cores': 1, 'iters': 2,
+                          'same_selections': bool(np.array_equal([t[0] for t in ref1.trace], rsel_full[:2]))}
+            del ref1
+        except Exception as e:       # no threadpoolctl: say so instead of reporting a pool-sized number as one thread
+            one_thread = {'value': None, 'note': 'threadpoolctl unavailable: %s' % type(e).__name__}
         full_match = bool(np.array_equal(rsel_full, f_tr[:len(rsel_full)]))
         out['cpu_baseline'] = {
             'value': args.cpu_full_iters / t_cit, 'unit': 'iterations/s', 'cores': int(thr), 'kind': 'port',
@@ -940,7 +974,7 @@ def main():
             'projection_s': sig(t_cproj), 'init_s': sig(t_cinit), 'iters_s': sig(t_cit), 'projection_points_dims_per_s': sig(N * D / t_cproj),
             'first_iter_s': sig(t_cproj + t_cinit + t_cit / args.cpu_full_iters),
             'M100_s_extrapolated': sig(t_cproj + t_cinit + 100 * t_cit / args.cpu_full_iters),
-            'host_cpus': os.cpu_count(), 'numpy': np.__version__,
+            'host_cpus': os.cpu_count(), 'cpu_model': cpu_model(), 'numpy': np.__version__, 'one_thread': one_thread,
             'selections_equal_device_run': 'ok: %d of %d on all rows' % (len(rsel_full), len(rsel_full)) if full_match else 'MISMATCH',
             'parity_on_sample': ('ok: %d selections identical, weights within 1e-5 (first %d rows)' % (len(rsel), ns)) if parity else 'MISMATCH',
             'loops': detail.get('cpu_loops', []),

@@ -62,6 +62,12 @@ def test_bench_line_contract():
     assert fh['same_trace_as_resident_run'] is True and fh['first_iter_ms'] >= fh['construct_ms'] > 0 and fh['M100_ms'] >= fh['first_iter_ms']
     assert fh['upload_GBps'] > 0 and fh['copy_direct_GBps'] > 0 and fh['copy_staged8_GBps'] > 0
     assert len(c['loops']) == 2 and all(e['ms_grad'] > 0 for e in c['loops'])
+    # round 5: the SURVEY 8(d) formulation as an object of its own, the M = 100 step time, and the baseline's host description
+    f64 = r['fp64_formulation']
+    assert f64['ms'] > 0 and 0 < f64['frac'] < 1 and f64['it_s'] > 0 and f64['same_sel'] is True
+    assert d['ms_per_step_M100'] > 0 and abs(d['ms_per_step_M100'] - (fh['M100_ms'] - fh['first_iter_ms']) / 99.) < 1e-3
+    assert isinstance(c['cpu_model'], str) and c['cpu_model'] and c['one_thread']['cores'] == 1
+    assert c['one_thread']['value'] > 0 and c['one_thread']['same_selections'] is True
     st = d['step_stages']
     assert st['transport'].startswith('none') and st['sweep'] > 0 and st['finish'] > 0
     assert abs(sum(d['solver_init'].values()) - d['solver_init_ms']) <= 0.05 * d['solver_init_ms'] + 0.5
