@@ -75,6 +75,7 @@ _SIGNATURES = {
     'bc_phi_colsum_all': [vp, vp, vp],
     'bc_snnls_bind_comm': [vp, vp],
     'bc_snnls_prefilter_active': [vp, c_ip],
+    'bc_snnls_prefilter_form': [vp, c_ip],
     'bc_snnls_prefilter_fallbacks': [vp, C.POINTER(C.c_int64)],
     'bc_snnls_prefilter_stats': [vp, c_i64p, c_i64p, c_i64p],
     'bc_snnls_bind_exchange': [vp, C.c_int, vp, vp],

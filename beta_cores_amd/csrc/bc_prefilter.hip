@@ -52,6 +52,12 @@ struct bc_pref {
   float* tile_u = nullptr;    // [ptiles] per-tile maximum of the upper bounds
   double* blk_l = nullptr;    // [grid] block maxima of the lower bounds
   float* blk_u = nullptr;     // [grid] block maxima of the upper bounds (lets the selection skip whole blocks of tiles)
+  // int8, branch-and-bound form (bc_prefilter_bb.h): the sweep rescores its candidates itself and leaves one record per block
+  bool bb = false;
+  unsigned bb_seq = 0;             // sweep sequence number: validates the device-wide bound without ever resetting it
+  unsigned long long* bb_theta = nullptr;
+  BbRec* bb_rec = nullptr;         // [grid]
+  double* bb_col = nullptr;        // [grid][S]
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
   int* ctrl = nullptr;        // [1] the last rescoring overflowed, [3] overflows so far,
                               // [4..5] sweeps so far (u64), [6..7] candidates rescored so far (u64)
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
 
 
 #include "bc_prefilter_i8.h"
+#include "bc_prefilter_bb.h"
 
 // ---- fp16 variant.  Tile = 512 rows, [S][512] halfs: one sample of a tile = 1 KiB = 64 lanes x 8 halfs.
 typedef _Float16 bc_h8 __attribute__((ext_vector_type(8)));
@@ -356,6 +363,13 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->grid = (int)((waves + 3) / 4);
   if (p->grid < 1) p->grid = 1;
   if (p->grid > 1024) p->grid = 1024;       // k_rescore keeps the block bounds in 4 registers per thread
+  // branch-and-bound form of the int8 sweep: worth it when a wave walks enough tiles for the in-sweep rescoring to hide behind
+  // the stream (the posts of a wave's last tile cannot); BC_I8_BB = 1 / 0 forces it on / off
+  if (p->prec == 8 && phi->s <= 256 && (long long)p->ptiles * BC_ITILE < 2147483647LL) {
+    const long long tile_rounds = (p->ptiles + 4LL * p->grid - 1) / (4LL * p->grid);
+    const char* benv = getenv("BC_I8_BB");
+    p->bb = benv ? atoi(benv) != 0 : tile_rounds >= 6;
+  }
   // the fp64 tiles cover ntiles*128 rows; the unit rows cover ptiles*ptile >= that, reads past the fp64 tiles are masked by `live`
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -371,6 +385,8 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const size_t o_bu = take((size_t)p->grid * sizeof(float));
   const size_t o_c = take((size_t)p->cap * sizeof(long long));
   const size_t o_ctrl = take(256);
+  const size_t o_bbr = take(p->bb ? (size_t)p->grid * sizeof(BbRec) : 0);
+  const size_t o_bbc = take(p->bb ? (size_t)p->grid * phi->s * sizeof(double) : 0);
   hipError_t e = hipMalloc(&p->slab, off);
   if (e != hipSuccess) { delete p; return bc_hip_fail(e, "hipMalloc(prefilter)", __FILE__, __LINE__); }
   char* base = (char*)p->slab;
@@ -389,6 +405,11 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->blk_u = (float*)(base + o_bu);
   p->cand = (long long*)(base + o_c);
   p->ctrl = (int*)(base + o_ctrl);
+  if (p->bb) {
+    p->bb_theta = reinterpret_cast<unsigned long long*>(p->ctrl + 16);      // inside the zeroed control block (sequence 0 = "none")
+    p->bb_rec = (BbRec*)(base + o_bbr);
+    p->bb_col = (double*)(base + o_bbc);
+  }
   e = hipMemsetAsync(p->ctrl, 0, 256, ctx->stream);
   if (e == hipSuccess) {
     if (p->prec == 8)
@@ -466,7 +487,22 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
     ia.post_div = post_div;
     ia.s = phi->s;
     ia.sp4 = p->sp4;
-    if (mode == 0) hipLaunchKernelGGL(k_sweep_i8<0>, dim3(p->grid), dim3(256), 0, ctx->stream, ia);
+    if (p->bb) {
+      I8BbArgs ba;
+      ba.a = ia;
+      ba.tiles = phi->tiles;
+      ba.norms = phi->norms;
+      ba.row_offset = phi->row_offset;
+      ba.theta = p->bb_theta;
+      if (++p->bb_seq == 0u) p->bb_seq = 1u;       // (2^32 sweeps later: the word still holds a larger sequence number -- start over)
+      if (p->bb_seq == 1u) BC_HIP(hipMemsetAsync(p->bb_theta, 0, sizeof(unsigned long long), ctx->stream));
+      ba.seq = p->bb_seq;
+      ba.blk_rec = p->bb_rec;
+      ba.blk_col = p->bb_col;
+      ba.max_res = p->cap < BC_BB_MAXRES ? p->cap : BC_BB_MAXRES;
+      if (mode == 0) hipLaunchKernelGGL(k_sweep_i8_bb<0>, dim3(p->grid), dim3(BC_BB_THREADS), 0, ctx->stream, ba);
+      else hipLaunchKernelGGL(k_sweep_i8_bb<1>, dim3(p->grid), dim3(BC_BB_THREADS), 0, ctx->stream, ba);
+    } else if (mode == 0) hipLaunchKernelGGL(k_sweep_i8<0>, dim3(p->grid), dim3(256), 0, ctx->stream, ia);
     else hipLaunchKernelGGL(k_sweep_i8<1>, dim3(p->grid), dim3(256), 0, ctx->stream, ia);
   } else if (p->prec == 16) {
     if (mode == 0) hipLaunchKernelGGL(k_sweep_f16<0>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
@@ -479,6 +515,9 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
   rc = bc_timer_end(ctx, 0);
   if (rc) return rc;
   RescoreArgs& r = *r_out;
+  r.bb.rec = p->bb ? p->bb_rec : nullptr;
+  r.bb.col = p->bb_col;
+  r.bb.nblk = p->grid;
   r.tiles = phi->tiles;
   r.norms = phi->norms;
   r.v = v_dev;
@@ -512,6 +551,7 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
 // then skips its own quantisation prologue.  Only valid while EVERY launch of this pre-filter sweeps that same v.
 void bc_pref_set_qv(bc_pref* p, const int* qv_dev) { p->qv = (p->prec == 8) ? qv_dev : nullptr; }
 int bc_pref_sp4(const bc_pref* p) { return p->sp4; }
+int bc_pref_bb(const bc_pref* p) { return p->bb ? 1 : 0; }
 
 // passes A, B, C: sweep, then the rescoring as its own one-block launch (record into rec_dev)
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
@@ -521,7 +561,8 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   if (rc) return rc;
   rc = bc_timer_begin(p->ctx, 3);
   if (rc) return rc;
-  if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
+  if (p->bb) hipLaunchKernelGGL(k_bb_winner, dim3(1), dim3(256), 0, p->ctx->stream, r.bb, r.s, r.skip_flag, r.ctrl, r.rec);
+  else if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
   else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
   BC_HIP(hipGetLastError());
   return bc_timer_end(p->ctx, 3);

@@ -46,7 +46,10 @@ __device__ __forceinline__ void bc_score_interval(double s0, double s1, double d
 }
 
 
+#include "bc_bb_pick.h"
+
 struct RescoreArgs {
+  BbArgs bb;                 // branch-and-bound sweep (bc_prefilter_bb.h): per-block records instead of per-tile bounds
   const double* tiles;
   const double* norms;
   const double* v;

@@ -715,7 +715,9 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish(SnnlsDev P0, int
 // RS: the pre-filter's rescoring stage (bc_rescore_dev.h) runs INSIDE this launch, between the up-front loads and
 // the step: its record goes straight into LDS (single rank, no exchange).  One launch per greedy step besides the
 // sweep instead of two (k_rescore 11.7 us + k_step_finish_pf 12.6 us in round 1).
-template <int ALG, bool RS>
+// RS = 2: the branch-and-bound sweep (bc_prefilter_bb.h) already rescored its candidates: the "rescoring stage" is the argmax
+// over its per-block records (bc_bb_pick), one round of loads that travels with the other up-front loads.
+template <int ALG, int RS>
 __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, int nnz_hint, RescoreArgs ra, long long n_rows) {
   extern __shared__ double pf_lds[];
   __shared__ SnnlsState S;
@@ -746,7 +748,9 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
     l_idx[j] = P0.idx[j];
   }
   RescorePre pre;
-  if (RS) pre = bc_rescore_prefetch(ra);             // the sweep blocks' bounds travel with the other up-front loads
+  BbPre bbpre;
+  if (RS == 1) pre = bc_rescore_prefetch(ra);        // the sweep blocks' bounds travel with the other up-front loads
+  if (RS == 2) bbpre = bc_bb_prefetch(ra.bb);        // ... or their records
   const int G = blockDim.x / s;
   const int g = threadIdx.x / s, kk = threadIdx.x - g * s;
   double c16[BC_PF_NC];
@@ -774,7 +778,11 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
   if (S.reached_limit || S.pf_overflow) return;      // snnls.py:32-34 / :73-74; a pending exact redo consumes nothing
   bool pf_ovf = false;
   if (RS) {
-    if (!S.skip) pf_ovf = bc_rescore_block<(ALG == BC_ALG_GIGA) ? 0 : 1>(ra, n_rows, l_rec, &pre) != 0;
+    if (RS == 2) {
+      if (!S.skip) pf_ovf = bc_bb_pick(ra.bb, bbpre, s, ra.ctrl, l_rec) != 0;
+    } else if (!S.skip) {
+      pf_ovf = bc_rescore_block<(ALG == BC_ALG_GIGA) ? 0 : 1>(ra, n_rows, l_rec, &pre) != 0;
+    }
     __syncthreads();
     FSTAMP(2);
   } else if (!P.fuse_winner && !S.select_fail) {
@@ -1216,6 +1224,13 @@ extern "C" int bc_snnls_prefilter_active(const bc_snnls* h, int* on) {
   return BC_OK;
 }
 
+int bc_pref_bb(const bc_pref* p);
+extern "C" int bc_snnls_prefilter_form(const bc_snnls* h, int* form) {
+  if (!h || !form) { bc_set_error("bc_snnls_prefilter_form: bad argument"); return BC_INVALID_ARGUMENT; }
+  *form = !h->pref ? 0 : (bc_pref_bb(h->pref) ? 2 : 1);
+  return BC_OK;
+}
+
 extern "C" int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n) {
   if (!h || !n) return BC_INVALID_ARGUMENT;
   *n = 0;
@@ -1396,21 +1411,29 @@ extern "C" int bc_snnls_step_finish(bc_snnls* h) {
       static unsigned attr_done_mask = 0;  // 42 KB static + up to 48 KB dynamic LDS: above the 64 KB default limit; per device
       const bool attr_done = (attr_done_mask >> (h->ctx->device & 31)) & 1u;
       if (!attr_done) {
-        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_GIGA, true>),
+        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_GIGA, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
-        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_FW, true>),
+        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_FW, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
+        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_GIGA, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
+        BC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_finish_pf<BC_ALG_FW, 2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BC_RS_MAX_DYN_LDS));
         attr_done_mask |= 1u << (h->ctx->device & 31);
       }
-      if (h->alg == BC_ALG_GIGA)
-        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, true>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
-      else
-        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_FW, true>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+      const bool bb = h->rs.bb.rec != nullptr;      // the sweep in flight was the branch-and-bound one (bc_prefilter_bb.h)
+      if (h->alg == BC_ALG_GIGA) {
+        if (bb) hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, 2>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+        else hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, 1>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+      } else {
+        if (bb) hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_FW, 2>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+        else hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_FW, 1>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+      }
     } else {
       if (h->alg == BC_ALG_GIGA)
-        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, false>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_GIGA, 0>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
       else
-        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_FW, false>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
+        hipLaunchKernelGGL((k_step_finish_pf<BC_ALG_FW, 0>), dim3(1), dim3(BC_FIN_THREADS), lds, h->ctx->stream, d, hint, h->rs, n_rows);
     }
     BC_HIP(hipGetLastError());
     h->nnz_upper += 1;

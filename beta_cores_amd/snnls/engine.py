@@ -55,6 +55,9 @@ class HipEngine:
         self.set_tolerance(tol)
         on = C.c_int()
         N.call('bc_snnls_prefilter_active', h, C.byref(on))
+        form = C.c_int()
+        N.call('bc_snnls_prefilter_form', h, C.byref(form))
+        self.prefilter_form = int(form.value)    # 0 fp64 sweeps, 1 two-pass pre-filter, 2 branch-and-bound int8 sweep
         self.prefilter = int(on.value)           # 0, or the storage precision (16 / 32) of the mirror of Phi the sweeps
                                                  # stream; candidates are rescored in fp64, selections are unchanged
         self.world = 1 if comm is None else comm.world
