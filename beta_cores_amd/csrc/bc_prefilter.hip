@@ -363,12 +363,16 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->grid = (int)((waves + 3) / 4);
   if (p->grid < 1) p->grid = 1;
   if (p->grid > 1024) p->grid = 1024;       // k_rescore keeps the block bounds in 4 registers per thread
-  // branch-and-bound form of the int8 sweep: worth it when a wave walks enough tiles for the in-sweep rescoring to hide behind
-  // the stream (the posts of a wave's last tile cannot); BC_I8_BB = 1 / 0 forces it on / off
+  // branch-and-bound form of the int8 sweep (bc_prefilter_bb.h): OPT-IN, BC_I8_BB=1.  Measured at N = 10M (profiles/r05_notes.md):
+  // the step kernel's tail drops by 4.6 us, the sweep grows by 7-14 us (posts of a wave's last tile are rescored after the
+  // stream has ended; every sharing of the bound across blocks costs more than it saves) -- the two-pass form stays the default.
   if (p->prec == 8 && phi->s <= 256 && (long long)p->ptiles * BC_ITILE < 2147483647LL) {
-    const long long tile_rounds = (p->ptiles + 4LL * p->grid - 1) / (4LL * p->grid);
     const char* benv = getenv("BC_I8_BB");
-    p->bb = benv ? atoi(benv) != 0 : tile_rounds >= 6;
+    p->bb = benv ? atoi(benv) != 0 : false;
+    if (p->bb) {                               // BC_BB_SW streaming waves (+ the rescoring wave) per block, one block per CU
+      p->grid = (int)((waves + BC_BB_SW - 1) / BC_BB_SW);
+      if (p->grid < 1) p->grid = 1;
+    }
   }
   // the fp64 tiles cover ntiles*128 rows; the unit rows cover ptiles*ptile >= that, reads past the fp64 tiles are masked by `live`
   size_t off = 0;

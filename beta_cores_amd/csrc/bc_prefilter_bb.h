@@ -6,7 +6,7 @@
 // candidate's fp64 row (a cold TLB miss into the 8 GB Phi: ~3 us) -> the sequential fma chain -> winner.  In-kernel stamps
 // (tools/fin_stamps.py, profiles/r05_notes.md) put that chain at 20k of the 45k cycles of a greedy step's tail.
 //
-// Here every sweep block carries a fifth wave.  A streaming wave that finishes a tile POSTS the rows whose upper bound
+// Here every sweep block carries one wave more than it has streaming waves.  A streaming wave that finishes a tile POSTS the rows whose upper bound
 // reaches theta -- a running lower bound on the best exact score anywhere -- into an LDS mailbox and streams on; the fifth
 // wave takes the posts, fetches the fp64 row, runs exactly the chain of k_sweep (bc_exact_score_wave: the bits of the fp64
 // sweep) and keeps the block's best (score, row, norm, column).  theta = max of every lower bound L_i seen so far and of
@@ -20,14 +20,26 @@
 //     wave would post its own first-tile best); afterwards posts are immediate.
 //   * Overflow (more than BC_BB_QCAP posts or `max_res` exact rescorings in one block: thousands of duplicated rows) sets
 //     a flag in the block record; the consumer turns it into the existing "redo this step with the exact fp64 sweep".
-// Taken when a wave walks enough tiles for the rescoring to hide behind the stream (bc_prefilter.hip: tile rounds >= 6, i.e.
-// shards of ~3M rows and more; BC_I8_BB=1 / 0 forces it on / off): with two or three tiles per wave every post lands at the
-// end of the block and the two-pass form is as good.
+// MEASURED (round 5, N = 10M, S = 100, profiles/r05_notes.md) and NOT the default: the step kernel's tail drops from 45k to
+// 34k cycles (-4.6 us) as intended, but the sweep itself grows from 157 us to 165 us with blocks that share nothing but exact
+// scores (one rescoring per block and sweep), to 172 us when they also forward their lower bounds, and to 205-224 us when
+// they poll the device-wide word -- posts of a wave's last tile are rescored after the stream has ended, and every form of
+// sharing the bound costs more than it saves.  Opt-in: BC_I8_BB=1; covered by tests/test_gpu_prefilter.py ('bb').
 #pragma once
 
 #define BC_BB_QCAP 256         // posts a block can take per sweep
 #define BC_BB_MAXRES 48        // exact rescorings a block may run per sweep
-#define BC_BB_THREADS 320      // four streaming waves + the rescoring wave
+#ifndef BC_BB_SW
+#define BC_BB_SW 8             // streaming waves per block: with the rescoring wave nine waves, ONE block per CU (3 + 2 + 2 + 2 on its
+                               // SIMDs at 161 VGPRs; two five-wave blocks do not fit side by side and the sweep ran at half rate)
+#endif
+#define BC_BB_THREADS (64 * (BC_BB_SW + 1))
+#ifndef BC_BB_MINWAVES
+#define BC_BB_MINWAVES 1
+#endif
+#ifndef BC_BB_STAGGER
+#define BC_BB_STAGGER 0
+#endif
 
 struct I8BbArgs {
   I8Args a;                    // mirror, digits, v, skip flag (the per-tile outputs are unused)
@@ -59,11 +71,11 @@ __device__ __forceinline__ void bc_bb_theta_push(unsigned long long* theta, unsi
 }
 
 template <int MODE>
-__global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
+__global__ __launch_bounds__(BC_BB_THREADS, BC_BB_MINWAVES) void k_sweep_i8_bb(I8BbArgs b) {
   const I8Args& a = b.a;
   constexpr int NV = (MODE == 0) ? 3 : 2;
   __shared__ __attribute__((aligned(16))) int dig[BC_IMAXG][4];
-  __shared__ double vmx[2][5];
+  __shared__ double vmx[2][BC_BB_SW + 1];
   __shared__ int2 mbox[BC_BB_QCAP];            // (upper bound bits, local row); row < 0: not written yet
   __shared__ int q_head, done_cnt, q_ovf;
   __shared__ unsigned s_theta;
@@ -74,9 +86,9 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
   if (skip) return;
   const int S = a.s, SP4 = a.sp4;
   constexpr int U = BC_IU;
-  const bool streamer = wave < 4;
+  const bool streamer = wave < BC_BB_SW;
   // the first tile's loads do not depend on the prologue: put them in flight before it
-  long long t = (long long)blockIdx.x * 4 + wave;
+  long long t = (long long)blockIdx.x * BC_BB_SW + wave;
   bc_i4 x[U], y[U];
   bc_hq8 rq = {(_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f};
   if (streamer && t < a.ptiles) {
@@ -114,8 +126,10 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
     }
     if (lane == 0) { vmx[0][wave] = m0; vmx[1][wave] = m1; }
     __syncthreads();
-    const bc_i8q_scalars q = bc_i8q_steps(fmax(fmax(fmax(vmx[0][0], vmx[0][1]), fmax(vmx[0][2], vmx[0][3])), vmx[0][4]),
-                                          fmax(fmax(fmax(vmx[1][0], vmx[1][1]), fmax(vmx[1][2], vmx[1][3])), vmx[1][4]));
+    double vm0 = vmx[0][0], vm1 = vmx[1][0];
+#pragma unroll
+    for (int w = 1; w <= BC_BB_SW; ++w) { vm0 = fmax(vm0, vmx[0][w]); vm1 = fmax(vm1, vmx[1][w]); }
+    const bc_i8q_scalars q = bc_i8q_steps(vm0, vm1);
     for (int g = threadIdx.x; g < SP4; g += blockDim.x) {
       unsigned w[4];
       bc_i8q_group<MODE>(a.v, S, g, q, w);
@@ -129,13 +143,26 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
 
   if (!streamer) {
     // ------------------------------------------------------------ the rescoring wave
+    // It is also the block's only link to the device-wide bound.  Measured (profiles/r05_notes.md): a load of that word in the
+    // streaming waves' tile loop drains their loads in flight (vmcnt retires in order), and 256 rescoring waves POLLING the
+    // one line (agent-scope loads bypass the L2s) make its memory channel the slowest of the stream -- 157 -> 205-224 us per
+    // sweep.  So: the streamers talk to the block's LDS word alone; this wave forwards that word upwards whenever it grew
+    // (a fire-and-forget atomic max), and READS the device's word only when it is about to spend a rescoring on a row.
     int tail = 0, nres = 0, flags = 0;
     double bv = -INFINITY, bnorm = 0.;
     long long bi = LLONG_MAX;
+    unsigned pushed = 0u;                                    // the largest key this block has sent up
     for (;;) {
-      const int done = *(volatile int*)&done_cnt;           // BEFORE the head: once all four streamers are done it is final
+      const int done = *(volatile int*)&done_cnt;           // BEFORE the head: once all streamers are done it is final
       int head = *(volatile int*)&q_head;
       head = head < BC_BB_QCAP ? head : BC_BB_QCAP;
+      {
+        const unsigned lk = *(volatile unsigned*)&s_theta;
+        if (lk > pushed) {
+          pushed = lk;
+          if (lane == 0) bc_bb_theta_push(b.theta, b.seq, lk);
+        }
+      }
       if (tail < head) {
         const int row = *(volatile int*)&mbox[tail].y;
         if (row < 0) { __builtin_amdgcn_s_sleep(1); continue; }      // slot reserved, entry not written yet
@@ -161,13 +188,14 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
         }
         if (sc == sc && fabs(sc) < INFINITY) {                // an exact score is a lower bound on the maximum
           const float fl = __double2float_rd(sc);
+          const unsigned key = bc_f32_key(fl);
           if (lane == 0) {
-            const unsigned key = bc_f32_key(fl);
             atomicMax(&s_theta, key);
             if (fl > th) bc_bb_theta_push(b.theta, b.seq, key);
           }
+          if (fl > th && key > pushed) pushed = key;
         }
-      } else if (done == 4) {
+      } else if (done == BC_BB_SW) {
         break;
       } else {
         __builtin_amdgcn_s_sleep(8);
@@ -188,9 +216,12 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
     return;
   }
 
-  // -------------------------------------------------------------- the four streaming waves
+  // -------------------------------------------------------------- the streaming waves
+#if BC_BB_STAGGER > 0
+  for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(BC_BB_STAGGER);      // (experiment: take the block's waves out of lock-step)
+#endif
   const float fpd = (float)a.post_div;
-  const long long tstride = (long long)gridDim.x * 4;
+  const long long tstride = (long long)gridDim.x * BC_BB_SW;
   float best_l = -INFINITY;                            // this wave's best lower bound so far (what it has pushed)
   float pU[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // the first tile's upper bounds, held back one tile
   long long pt = -1;
@@ -213,8 +244,6 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
   };
   for (; t < a.ptiles; t += tstride) {
     const bc_i4* __restrict__ p = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
-    // what the rest of the device knew when this tile started (consumed at its end: the load hides behind the stream)
-    const float gth = bc_bb_theta_load(b.theta, b.seq);
     int acc[4][NV];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -265,15 +294,11 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
       }
     }
     tl = bc_wave_max_f32_all(tl);
-    if (tl > best_l) {                                   // (wave-uniform) a better lower bound: tell the block and the device
-      best_l = tl;
-      if (lane == 0) {
-        const unsigned key = bc_f32_key(tl);
-        atomicMax(&s_theta, key);
-        if (tl > gth) bc_bb_theta_push(b.theta, b.seq, key);
-      }
+    if (tl > best_l) {                                   // (wave-uniform) a better lower bound: tell the block (its rescoring wave
+      best_l = tl;                                       // passes it on to the device)
+      if (lane == 0) atomicMax(&s_theta, bc_f32_key(tl));
     }
-    float th = fmaxf(fmaxf(best_l, gth), bc_key_f32(*(volatile unsigned*)&s_theta));
+    const float th = fmaxf(best_l, bc_key_f32(*(volatile unsigned*)&s_theta));
     if (pt < 0) {
       // the wave's first tile: theta has seen nothing but this tile -- hold its rows back until the next tile ends
       pt = t;
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(BC_BB_THREADS) void k_sweep_i8_bb(I8BbArgs b) {
   }
   if (pt >= 0 && pt != LLONG_MAX) {
     // a wave with a single tile: nothing more to wait for
-    const float th = fmaxf(fmaxf(best_l, bc_bb_theta_load(b.theta, b.seq)), bc_key_f32(*(volatile unsigned*)&s_theta));
+    const float th = fmaxf(best_l, bc_key_f32(*(volatile unsigned*)&s_theta));
     post(pU, pt, th);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -248,8 +248,8 @@ int bc_snnls_destroy(bc_snnls* h);
 int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
 /* *form = 0: fp64 sweeps; 1: two-pass pre-filter (reduced-precision sweep, then one block rescoring the candidates from the
  * fp64 Phi); 2: branch-and-bound int8 sweep (csrc/bc_prefilter_bb.h: a fifth wave per sweep block rescoring the candidates
- * beside the stream; taken when a wave walks >= 6 mirror tiles, i.e. shards of ~3M rows and more; BC_I8_BB=1 / 0 forces it
- * on / off).  Same call sites as bc_snnls_prefilter_active (giga.py:31-38, frankwolfe.py:16-17): the row returned is the
+ * beside the stream; opt-in with BC_I8_BB=1 -- measured slower than form 1 at every size tried, kept for the record and its
+ * tests).  Same call sites as bc_snnls_prefilter_active (giga.py:31-38, frankwolfe.py:16-17): the row returned is the
  * fp64 sweep's in every form. */
 int bc_snnls_prefilter_form(const bc_snnls* h, int* form);
 /* Diagnostic: how many sweeps since creation overflowed the pre-filter's candidate lists (thousands of exactly
