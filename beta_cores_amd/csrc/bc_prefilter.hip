@@ -44,6 +44,8 @@ struct bc_pref {
   bc_hq2* rowq = nullptr;     // int8: (scale, delta) per row, two halfs
   float2* tile_cand = nullptr;   // int8: [ptiles][4]
   int* tile_ncand = nullptr;     // int8: [ptiles]
+  int2* blk_cand = nullptr;      // int8: [grid][BC_BLK_NC] the sweep blocks' own candidate lists (round 5)
+  int* blk_nc = nullptr;         // int8: [grid]
   int sp4 = 0;                // int8: k-groups stored per tile
   int prec = 32;              // 32, 16 or 8
   int ptile = BC_PTILE;       // rows per pre-filter tile (256 for fp32, 512 for fp16)
@@ -305,11 +307,13 @@ __global__ __launch_bounds__(256) void k_build_u16(const double* __restrict__ ti
 // passes B + C as their own launch (one block): multi-rank steps (the record goes into the exchange) and the
 // step-wise protocol.  On overflow the record carries BC_REC_OVERFLOW in its `valid` slot: whoever consumes the
 // gathered records (finish / pick kernels, every rank alike) turns that into "redo this step with the exact sweep".
+#define BC_RESCORE_THREADS 512      // (a thread of the rescoring stage holds the candidate lists of two sweep blocks: 1024 blocks)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, long long n_rows) {
+__global__ __launch_bounds__(BC_RESCORE_THREADS) void k_rescore(RescoreArgs a, long long n_rows) {
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
   if (skip) return;
-  if (bc_rescore_block<MODE>(a, n_rows, a.rec)) {
+  const RescorePre pre = bc_rescore_prefetch(a);
+  if (bc_rescore_block<MODE>(a, n_rows, a.rec, pre)) {
     if (threadIdx.x == 0) {
       a.rec[0] = -INFINITY;
       reinterpret_cast<long long*>(a.rec)[1] = -1;
@@ -348,6 +352,7 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   p->sp4 = bc_lay_i8_sp4(phi->s);
   p->ptiles = (phi->n_rows + p->ptile - 1) / p->ptile;
   if (p->ptiles < 1) p->ptiles = 1;
+  static_assert(BC_BLK_NC == BC_RS_BLK_NC, "bc_rescore_dev.h mirrors the block list length");
   static_assert(BC_ITILE == BC_LAY_ITILE && BC_IU == BC_LAY_IU && BC_TILE == BC_LAY_TILE && BC_IMAXG == BC_LAY_IMAXG, "bc_layout.h mirrors these");
   // one wave per tile and a grid-stride loop: size the grid so that all its waves are resident at once
   // (4 per SIMD) and every wave walks the same number of tiles -- a 2x over-subscribed grid left waves with
@@ -389,6 +394,8 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const size_t o_bu = take((size_t)p->grid * sizeof(float));
   const size_t o_c = take((size_t)p->cap * sizeof(long long));
   const size_t o_ctrl = take(256);
+  const size_t o_bc = take(p->prec == 8 ? (size_t)p->grid * BC_BLK_NC * sizeof(int2) : 0);
+  const size_t o_bn = take(p->prec == 8 ? (size_t)p->grid * sizeof(int) : 0);
   const size_t o_bbr = take(p->bb ? (size_t)p->grid * sizeof(BbRec) : 0);
   const size_t o_bbc = take(p->bb ? (size_t)p->grid * phi->s * sizeof(double) : 0);
   hipError_t e = hipMalloc(&p->slab, off);
@@ -402,6 +409,11 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
     p->rowq = (bc_hq2*)(base + o_rq);
     p->tile_cand = (float2*)(base + o_tc);
     p->tile_ncand = (int*)(base + o_tn);
+    static const int no_lists = getenv("BC_I8_BLKLIST") ? atoi(getenv("BC_I8_BLKLIST")) == 0 : 0;      // (A/B: 0 = walk tiles as before)
+    if (!no_lists) {
+      p->blk_cand = (int2*)(base + o_bc);
+      p->blk_nc = (int*)(base + o_bn);
+    }
   }
   p->live = p->prec == 16 ? (unsigned char*)(base + o_lv) : nullptr;
   p->tile_u = (float*)(base + o_tu);
@@ -487,6 +499,8 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
     ia.tile_ncand = p->tile_ncand;
     ia.blk_l = p->blk_l;
     ia.blk_u = p->blk_u;
+    ia.blk_cand = p->bb ? nullptr : p->blk_cand;
+    ia.blk_nc = p->bb ? nullptr : p->blk_nc;
     ia.ptiles = p->ptiles;
     ia.post_div = post_div;
     ia.s = phi->s;
@@ -533,6 +547,8 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
   r.u16 = p->u16;
   r.tile_cand = p->tile_cand;
   r.tile_ncand = p->tile_ncand;
+  r.blk_cand = (p->prec == 8 && !p->bb) ? p->blk_cand : nullptr;
+  r.blk_nc = (p->prec == 8 && !p->bb) ? p->blk_nc : nullptr;
   r.live = p->live;
   r.v_norm = v_norm_dev;
   r.delta = a.delta;
@@ -566,8 +582,8 @@ int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_no
   rc = bc_timer_begin(p->ctx, 3);
   if (rc) return rc;
   if (p->bb) hipLaunchKernelGGL(k_bb_winner, dim3(1), dim3(256), 0, p->ctx->stream, r.bb, r.s, r.skip_flag, r.ctrl, r.rec);
-  else if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
-  else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(256), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
+  else if (mode == 0) hipLaunchKernelGGL(k_rescore<0>, dim3(1), dim3(BC_RESCORE_THREADS), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
+  else hipLaunchKernelGGL(k_rescore<1>, dim3(1), dim3(BC_RESCORE_THREADS), 0, p->ctx->stream, r, (long long)p->phi->n_rows);
   BC_HIP(hipGetLastError());
   return bc_timer_end(p->ctx, 3);
 }

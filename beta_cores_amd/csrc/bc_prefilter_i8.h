@@ -50,10 +50,13 @@ struct I8Args {
   int* tile_ncand;          // [ptiles]
   double* blk_l;
   float* blk_u;
+  int2* blk_cand;           // [grid][BC_BLK_NC] (upper bound bits, local row): the block's rows whose upper bound reaches the BLOCK's
+  int* blk_nc;              // best lower bound -- a superset of those that reach the global one; count, or -1: "scan my tiles"
   long long ptiles;
   double post_div;
   int s, sp4;
 };
+#define BC_BLK_NC 8
 
 // The interval of bc_score_interval evaluated in fp32.  The int8 mirror's delta is ~1e-2, five orders of magnitude
 // above fp32 rounding, so single precision costs nothing in selectivity; every fp32 evaluation error is covered
@@ -232,9 +235,17 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
   __shared__ float s_tu[4][BC_IFLUSH];
   __shared__ int s_nc[4][BC_IFLUSH];
   __shared__ __attribute__((aligned(16))) float2 s_cd[4][BC_IFLUSH][4];
+  // round 5: the block's own short list of candidates (see I8Args::blk_cand), so that the rescoring stage finds the rows in
+  // play in its FIRST round of loads instead of walking blocks -> tiles -> pairs (a dependent round trip, ~2 us of every step)
+  __shared__ int bl_n, bl_scan;
+  __shared__ int2 bl_list[BC_BLK_NC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float best_l = -INFINITY;
   float umax = -INFINITY;
+  int ti_last = 0;                                   // tiles still parked in LDS when the wave has walked its last tile
+  long long t_first = 0, t_step = 0;
+  bool flushed_early = false;
+  if (threadIdx.x == 0) { bl_n = 0; bl_scan = 0; }
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
   if (!skip) {
     const int S = a.s, SP4 = a.sp4;
@@ -385,16 +396,50 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         s_nc[wave][ti] = base;
       }
       if (ti == 0) t_park = t;
-      if (++ti == BC_IFLUSH) flush();
+      if (++ti == BC_IFLUSH) {
+        flush();
+        if (t + tstride < a.ptiles) flushed_early = true;      // (a flush that happens to be the wave's last leaves all in LDS)
+        else ti_last = BC_IFLUSH;
+      }
       best_l = fmaxf(best_l, tl);
       umax = fmaxf(umax, tmax);
     }
-    if (ti > 0) flush();
+    if (ti > 0) {
+      ti_last = ti;
+      flush();
+    }
+    t_first = t_park;
+    t_step = tstride;
   }
   if (lane == 0) { sl[wave] = best_l; su[wave] = umax; }
   __syncthreads();
+  const float blk_best_l = fmaxf(fmaxf(sl[0], sl[1]), fmaxf(sl[2], sl[3]));
   if (threadIdx.x == 0) {
-    a.blk_l[blockIdx.x] = (double)fmaxf(fmaxf(sl[0], sl[1]), fmaxf(sl[2], sl[3]));
+    a.blk_l[blockIdx.x] = (double)blk_best_l;
     a.blk_u[blockIdx.x] = fmaxf(fmaxf(su[0], su[1]), fmaxf(su[2], su[3]));
   }
+  if (a.blk_nc == nullptr) return;
+  // ---- the block's candidates: parked pairs whose upper bound reaches the block's best lower bound.  The parked results of
+  // the wave's last <= BC_IFLUSH tiles are still in LDS (the flush only copied them out); a wave that flushed before that, or a
+  // tile with more than four pairs, makes the rescoring stage walk this block's tiles as before (blk_nc = -1).
+  if (flushed_early && lane == 0) bl_scan = 1;
+  if (!flushed_early && lane < ti_last) {
+    const int nc = s_nc[wave][lane];
+    const long long tt = t_first + (long long)lane * t_step;
+    if (nc > 4) {
+      if (s_tu[wave][lane] >= blk_best_l) bl_scan = 1;       // (only if the tile is in play at all: 1-2 % of all tiles hold > 4 pairs)
+    } else {
+      for (int i = 0; i < nc; ++i) {
+        const float2 pr = s_cd[wave][lane][i];
+        if (pr.x >= blk_best_l) {
+          const int slot = atomicAdd(&bl_n, 1);
+          if (slot < BC_BLK_NC) bl_list[slot] = make_int2(__float_as_int(pr.x), (int)(tt * BC_ITILE + (long long)pr.y));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int n = bl_n;
+  if ((int)threadIdx.x < n && threadIdx.x < BC_BLK_NC) a.blk_cand[(size_t)blockIdx.x * BC_BLK_NC + threadIdx.x] = bl_list[threadIdx.x];
+  if (threadIdx.x == 0) a.blk_nc[blockIdx.x] = (bl_scan != 0 || n > BC_BLK_NC) ? -1 : n;
 }

@@ -65,6 +65,8 @@ struct RescoreArgs {
   int sp;
   const float2* tile_cand;   // int8 mode: the sweep left up to 4 (upper bound, row) pairs per tile
   const int* tile_ncand;
+  const int2* blk_cand;      // int8 mode, round 5: ... and up to BC_RS_BLK_NC (upper bound bits, local row) pairs per BLOCK
+  const int* blk_nc;         //   (count; -1: walk the block's tiles); nullptr: no such lists
   long long* cand;
   int* ctrl;
   double* rec;
@@ -76,6 +78,9 @@ struct RescoreArgs {
 
 #ifndef FSTAMP      // diagnostic builds define it before including this header (bc_snnls.hip, -DBC_FIN_STAMPS)
 #define FSTAMP(i) do { } while (0)
+#endif
+#ifndef FDBG
+#define FDBG(i, v) do { } while (0)
 #endif
 
 // same per-row arithmetic as bc_sweep.hip (sequential fma chain over k, bc_row_score epilogue)
@@ -203,9 +208,15 @@ __device__ __forceinline__ void bc_rs_accumulate(bc_h2 x, const double* __restri
 // The sweep blocks' bounds a thread of the rescoring block looks at (threads 0..255, blocks t, t+256, ...): a caller
 // with other loads to wait for requests them in the same round (bc_rescore_prefetch) instead of paying a round trip
 // of their own at the start of the rescoring.
+#define BC_RS_BLK_NC 8      /* == BC_BLK_NC (bc_prefilter_i8.h) */
+#define BC_RS_BLK_PER 2     // block lists a thread looks at: blocks t, t + blockDim (nblk <= 1024, blockDim >= 512)
 struct RescorePre {
   double l[4];
   float u[4];
+  // the sweep blocks' own candidate lists (int8 mirror): thread t holds those of blocks t, t + blockDim
+  int nc[BC_RS_BLK_PER];
+  float bu[BC_RS_BLK_PER];
+  int2 c[BC_RS_BLK_PER][BC_RS_BLK_NC];
 };
 
 __device__ __forceinline__ RescorePre bc_rescore_prefetch(const RescoreArgs& a) {
@@ -220,11 +231,28 @@ __device__ __forceinline__ RescorePre bc_rescore_prefetch(const RescoreArgs& a) 
       p.u[q] = a.blk_u[i];
     }
   }
+#pragma unroll
+  for (int q = 0; q < BC_RS_BLK_PER; ++q) {
+    const int i = threadIdx.x + q * blockDim.x;
+    p.nc[q] = 0;
+    p.bu[q] = -INFINITY;
+    if (a.blk_nc != nullptr && i < a.nblk) {
+      p.nc[q] = a.blk_nc[i];
+      p.bu[q] = a.blk_u[i];
+      const int4* src = reinterpret_cast<const int4*>(a.blk_cand + (size_t)i * BC_RS_BLK_NC);
+#pragma unroll
+      for (int e = 0; e < BC_RS_BLK_NC / 2; ++e) {      // loaded whatever the count says: no dependent second round
+        const int4 v = src[e];
+        p.c[q][2 * e] = make_int2(v.x, v.y);
+        p.c[q][2 * e + 1] = make_int2(v.z, v.w);
+      }
+    }
+  }
   return p;
 }
 
 template <int MODE>
-__device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* __restrict__ rec, const RescorePre* pre = nullptr) {
+__device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* __restrict__ rec, const RescorePre& mine) {
   __shared__ double sv[16];
   __shared__ long long si[16];
   __shared__ long long win;
@@ -242,13 +270,14 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
   double lmax = -INFINITY;
   float bu[4];                               // this thread's share of the block upper bounds (nblk <= 1024)
   {
-    const RescorePre mine = pre ? *pre : bc_rescore_prefetch(a);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       lmax = fmax(lmax, mine.l[q]);             // (-inf where there is no block: fmax ignores it, a NaN bound too -- as before)
       bu[q] = mine.u[q];
     }
   }
+  // the sweep blocks left their own candidate lists (int8 mirror): they came in with the first round of loads
+  const bool lists = a.blk_nc != nullptr && a.nblk <= BC_RS_BLK_PER * (int)blockDim.x;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
   if (lane == 0) sv[wave] = lmax;
@@ -259,14 +288,55 @@ __device__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* 
   FSTAMP(10);
   // phase B1: tiles whose maximum upper bound reaches Lmax -- first the sweep blocks whose maximum does
   // (usually one or two), then only the tiles those blocks walked
+  if (lists) {
+    // every row whose upper bound reaches Lmax is in its block's list (it reaches the block's best lower bound a fortiori);
+    // only a block that could not keep a list (-1: a tile with more than four pairs, more than BC_RS_BLK_NC rows, or tiles
+    // flushed out of LDS early) goes through the tile walk below
+    // (almost every thread finds nothing: one branch-free pass decides whether it has anything to do at all)
+    bool any = false;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (bu[q] != -INFINITY && (double)bu[q] >= lmax) {
-      const int slot = atomicAdd(&bcnt, 1);
-      if (slot < 64) blist[slot] = threadIdx.x + q * 256;
+    for (int q = 0; q < BC_RS_BLK_PER; ++q) {
+      any |= mine.nc[q] < 0 && mine.bu[q] != -INFINITY && (double)mine.bu[q] >= lmax;
+#pragma unroll
+      for (int e = 0; e < BC_RS_BLK_NC; ++e) any |= e < mine.nc[q] && (double)__int_as_float(mine.c[q][e].x) >= lmax;
     }
+    if (any) {
+#pragma unroll
+      for (int q = 0; q < BC_RS_BLK_PER; ++q) {
+        if (mine.nc[q] < 0) {
+          if (mine.bu[q] != -INFINITY && (double)mine.bu[q] >= lmax) {
+            const int slot = atomicAdd(&bcnt, 1);
+            if (slot < 64) blist[slot] = threadIdx.x + q * blockDim.x;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < BC_RS_BLK_NC; ++e) {
+            const float ub = __int_as_float(mine.c[q][e].x);
+            if (e < mine.nc[q] && (double)ub >= lmax) {
+              const int slot = atomicAdd(&cnt, 1);
+              const long long row = mine.c[q][e].y;
+              if (slot < a.cap) a.cand[slot] = row;
+              if (slot < 32) scand[slot] = row;
+            }
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (bu[q] != -INFINITY && (double)bu[q] >= lmax) {
+        const int slot = atomicAdd(&bcnt, 1);
+        if (slot < 64) blist[slot] = threadIdx.x + q * 256;
+      }
+  }
+  FSTAMP(23);
   __syncthreads();
+  FSTAMP(24);
   const int nbl = bcnt;
+  FDBG(20, nbl);
+  FDBG(21, cnt);
+  FDBG(22, lists ? 1 : 0);
   bool merged = false;                       // int8 mirror, few blocks in play: phases B1 and B2 in one round of loads
   if (nbl <= 64 && a.tile_cand) {
     merged = true;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 __device__ unsigned long long g_fin_stamps[64];
 #define FSTAMP(i) do { if (threadIdx.x == 0) g_fin_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FDBG(i, v) do { if (threadIdx.x == 0) g_fin_stamps[i] = (unsigned long long)(v); } while (0)
 extern "C" int bc_debug_fin_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_stamps), sizeof(g_fin_stamps)) == hipSuccess ? 0 : -1;
 }
@@ -734,18 +735,28 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
   double* l_rec = l_xwp + s;
   double* l_val = l_rec + nrec;
   long long* l_idx = reinterpret_cast<long long*>(l_val + (nnz_hint + 1));
-  // ---- one round of loads
-  if (threadIdx.x == 0) S = *P0.st;
-  for (int k = threadIdx.x; k < s; k += blockDim.x) {
-    l_b[k] = P0.b[k];
-    l_bn[k] = P0.bn[k];
-    l_xw[k] = P0.xw[k];
+  // ---- one round of loads.  Everything is requested into REGISTERS first and parked in LDS afterwards: written as
+  // "load, store to LDS" group by group the compiler waited for each group before it issued the next -- six dependent
+  // round trips (state, vectors, list, bounds, ...) instead of one: 6.6k of the step's 45k cycles (tools/fin_stamps.py).
+  // Indices are clamped instead of branched around, so that nothing separates the requests.
+  const int k0 = (int)threadIdx.x < s ? (int)threadIdx.x : 0;                 // (s <= blockDim: one element per thread)
+  const double r_b = P0.b[k0], r_bn = P0.bn[k0], r_xw = P0.xw[k0];
+  double r_rec[BC_PF_MAXREC / BC_FIN_THREADS];
+  if (!RS) {
+#pragma unroll
+    for (int u = 0; u < BC_PF_MAXREC / BC_FIN_THREADS; ++u) {
+      const int i = threadIdx.x + u * BC_FIN_THREADS;
+      r_rec[u] = (nrec > 0) ? P0.cand_all[i < nrec ? i : 0] : 0.;
+    }
   }
-  if (!RS)
-    for (int i = threadIdx.x; i < nrec; i += blockDim.x) l_rec[i] = P0.cand_all[i];
-  for (int j = threadIdx.x; j < nnz_hint; j += blockDim.x) {
-    l_val[j] = P0.val[j];
-    l_idx[j] = P0.idx[j];
+  double r_val[BC_PF_MAXNNZ / BC_FIN_THREADS];
+  long long r_idx[BC_PF_MAXNNZ / BC_FIN_THREADS];
+#pragma unroll
+  for (int u = 0; u < BC_PF_MAXNNZ / BC_FIN_THREADS; ++u) {
+    const int j = threadIdx.x + u * BC_FIN_THREADS;
+    const int jc = j < nnz_hint ? j : 0;                                      // (the list slab always holds slot 0)
+    r_val[u] = P0.val[jc];
+    r_idx[u] = P0.idx[jc];
   }
   RescorePre pre;
   BbPre bbpre;
@@ -756,11 +767,31 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
   double c16[BC_PF_NC];
 #pragma unroll
   for (int u = 0; u < BC_PF_NC; ++u) {
-    c16[u] = 0.;
-    if (g < G && nnz_hint > 0) {
-      long long j = g + (long long)u * G;
-      j = j < nnz_hint ? j : nnz_hint - 1;          // clamped: always a valid slot, unused when past the list
-      c16[u] = P0.cols[(size_t)j * s + kk];
+    long long j = (g < G ? g : 0) + (long long)u * G;
+    j = j < nnz_hint ? j : (nnz_hint > 0 ? nnz_hint - 1 : 0);      // clamped: always a valid slot, unused when past the list
+    c16[u] = P0.cols[(size_t)j * s + (g < G ? kk : 0)];
+  }
+  FSTAMP(25);
+  // ---- park
+  if (threadIdx.x == 0) S = *P0.st;                  // (requested behind the others: it arrives with them)
+  if ((int)threadIdx.x < s) {
+    l_b[threadIdx.x] = r_b;
+    l_bn[threadIdx.x] = r_bn;
+    l_xw[threadIdx.x] = r_xw;
+  }
+  if (!RS) {
+#pragma unroll
+    for (int u = 0; u < BC_PF_MAXREC / BC_FIN_THREADS; ++u) {
+      const int i = threadIdx.x + u * BC_FIN_THREADS;
+      if (i < nrec) l_rec[i] = r_rec[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < BC_PF_MAXNNZ / BC_FIN_THREADS; ++u) {
+    const int j = threadIdx.x + u * BC_FIN_THREADS;
+    if (j < nnz_hint) {
+      l_val[j] = r_val[u];
+      l_idx[j] = r_idx[u];
     }
   }
   __syncthreads();
@@ -781,7 +812,7 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
     if (RS == 2) {
       if (!S.skip) pf_ovf = bc_bb_pick(ra.bb, bbpre, s, ra.ctrl, l_rec) != 0;
     } else if (!S.skip) {
-      pf_ovf = bc_rescore_block<(ALG == BC_ALG_GIGA) ? 0 : 1>(ra, n_rows, l_rec, &pre) != 0;
+      pf_ovf = bc_rescore_block<(ALG == BC_ALG_GIGA) ? 0 : 1>(ra, n_rows, l_rec, pre) != 0;
     }
     __syncthreads();
     FSTAMP(2);

@@ -19,8 +19,8 @@ import beta_cores_amd as bc
 from beta_cores_amd import _native as N
 import bench
 
-ORDER = [0, 1, 10, 11, 12, 14, 13, 2, 3, 4, 5, 6, 7, 15, 8, 9]
-NAMES = {0: 'kernel start', 1: 'up-front loads + barrier', 10: 'rescoring: Lmax', 11: 'rescoring: block/tile scan (B1+B2 merged)',
+ORDER = [0, 25, 1, 10, 23, 24, 11, 12, 14, 13, 2, 3, 4, 5, 6, 7, 15, 8, 9]
+NAMES = {0: 'kernel start', 25: 'up-front loads requested', 23: 'rescoring: block lists consumed', 24: 'rescoring: barrier behind that', 1: 'up-front loads + barrier', 10: 'rescoring: Lmax', 11: 'rescoring: block/tile scan (B1+B2 merged)',
          12: 'rescoring: candidate list complete', 14: 'rescoring: candidate row + v in LDS', 13: 'rescoring: exact scores (chains)',
          2: 'rescoring: record written (winner, column)', 3: 'pick', 4: 'step sizes (5 wave sums, divisions)', 5: 'apply (list scale / append)',
          6: 'xw = A.w and error from the list', 7: 'guard + retry state', 15: 'prep: next sweep vectors', 8: 'prep: int8 digits',
@@ -75,6 +75,7 @@ def main():
             print('  %-52s at %8.0f ticks  (+%6.0f)' % (NAMES[i], t[i], t[i] - prev))
             prev = t[i]
         print('  prefilter stats (sweeps, candidates, fallbacks):', alg.snnls._eng.prefilter_stats())
+        print('  last step: blocks walked tile by tile %d, candidates straight from the block lists %d, lists in use %d' % (buf[20], buf[21], buf[22]))
 
 
 if __name__ == '__main__':
