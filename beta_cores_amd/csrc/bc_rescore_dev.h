@@ -293,6 +293,8 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
     // only a block that could not keep a list (-1: a tile with more than four pairs, more than BC_RS_BLK_NC rows, or tiles
     // flushed out of LDS early) goes through the tile walk below
     // (almost every thread finds nothing: one branch-free pass decides whether it has anything to do at all)
+    // (Tried and dropped: the thread that finds a candidate touching its fp64 row right away, to start the ~2 us TLB miss of
+    // that first access into the 8 GB Phi early -- __syncthreads() carries a vmcnt(0), so the next barrier waits for the touch.)
     bool any = false;
 #pragma unroll
     for (int q = 0; q < BC_RS_BLK_PER; ++q) {
