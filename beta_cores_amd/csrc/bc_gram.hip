@@ -260,6 +260,136 @@ __global__ __launch_bounds__(256, BT == 64 ? 3 : 2) void k_gram(GramArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// D <= 128 without weights (the drivers' full-data posterior, `sampler_optimal`: ONE diagonal tile, A == B == the raw rows):
+// the slab goes from global memory STRAIGHT INTO LDS (`global_load_lds_dwordx4`: a wave instruction moves one 1 KB panel row,
+// no VGPR round trip, no ds_write), which frees the staging registers of gram_tile (228 -> 113 VGPRs: FOUR resident blocks per
+// CU instead of two) and lets the slabs be double-buffered: one barrier per slab instead of two, and the rows of slab s + 1
+// are requested a whole slab of MFMAs ahead instead of being waited for at the next ds_write.  X^T y comes from the fragments the waves
+// hold anyway (each wave owns two of the eight 16-column strips), with y[row] read beside them.
+// Same k-step order over the rows as gram_tile -> the same bits in every Gram element; X^T y is summed in another order
+// (lane-private partial sums over the row groups, combined at the end) and agrees to rounding.
+// Measured at N = 10M, D = 128 on one box (tools/k4_bench.py, Gram + reduction; profiles/r05_notes.md): 16-row slabs with four
+// resident blocks per CU 3.16 ms, three blocks 3.17, 32-row slabs x 2 blocks 3.23-3.26, 64 rows x 1 block 3.28; k_gram 3.51.
+#ifndef BC_GD_KR
+#define BC_GD_KR 16
+#endif
+#ifndef BC_GD_BLOCKS
+#define BC_GD_BLOCKS 4         // resident blocks per CU: 4 x 37 KB of LDS, 113 VGPRs (four waves per SIMD)
+#endif
+#define BC_GD_LDX 144
+template <int V>
+__device__ __forceinline__ void gram_dma_tile(const GramArgs& a, long long split, double* __restrict__ panel /* [2][KR][LDX] */,
+                                              double* __restrict__ ys /* [2][KR] */) {
+  constexpr int BT = 128, KR = BC_GD_KR, LDX = BC_GD_LDX;
+  constexpr int NA = GramDiag<BT, V>::n;
+  // the two strips of X^T y this wave accumulates: both are in the fragment set it loads for its MFMAs
+  constexpr int YS0 = V == 0 ? 0 : (V == 1 ? 4 : (V == 2 ? 2 : 6)), YS1 = YS0 + 1;
+  constexpr bool ys_in_a = V == 2;          // (wave 2 holds strips 2, 3 as A fragments; the others hold theirs as B fragments)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const long long r_begin = split * a.rows_per_split;
+  long long r_end = r_begin + a.rows_per_split;
+  if (r_end > a.n_rows) r_end = a.n_rows;
+  double4_t acc[NA];
+#pragma unroll
+  for (int x = 0; x < NA; ++x) acc[x] = (double4_t){0., 0., 0., 0.};
+  double vy0 = 0., vy1 = 0.;
+
+  // wave V moves rows 8V .. 8V+7 of a slab: lane l the 16 bytes [2l, 2l+1] of the row; wave 0 also the 32 y values (two
+  // dwords each).  Rows past the end of the split are zero-filled by hand (there is no range check on this path).
+  auto request = [&](long long r0, int buf) {
+    double* pb = panel + (size_t)buf * KR * LDX;
+#pragma unroll
+    for (int q = 0; q < KR / 4; ++q) {
+      const int lr = V * (KR / 4) + q;
+      const long long r = r0 + lr;
+      double* dst = pb + lr * LDX;
+      if (r < r_end) {
+        __builtin_amdgcn_global_load_lds((const void*)(a.z + (size_t)r * a.dz + 2 * lane),
+                                         (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+      } else {
+        dst[2 * lane] = 0.;
+        dst[2 * lane + 1] = 0.;
+      }
+    }
+    if (V == 0) {
+#pragma unroll
+      for (int h = 0; h < KR; h += 32) {                             // 32 rows' y values per instruction
+        double* yb = ys + buf * KR + h;
+        const long long r = r0 + h + (lane >> 1);
+        const long long rc = r < r_end ? r : r_begin;               // (clamped: zeroed below)
+        if (h + (lane >> 1) < KR)
+          __builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const int*>(a.z + (size_t)rc * a.dz + a.d) + (lane & 1)),
+                                           (void __attribute__((address_space(3)))*)yb, 4, 0, 0);
+      }
+    }
+  };
+  // (y of rows past the end: the x values of those rows are zero, so whatever y holds there multiplies a zero -- unless it is
+  // a NaN/inf: overwrite)
+  auto patch_y = [&](long long r0, int buf) {
+    if (V == 0 && r0 + KR > r_end) {
+      double* yb = ys + buf * KR;
+      for (int i = lane; i < KR; i += 64)
+        if (r0 + i >= r_end) yb[i] = 0.;
+    }
+  };
+
+  if (r_begin < r_end) request(r_begin, 0);
+  int buf = 0;
+  for (long long r0 = r_begin; r0 < r_end; r0 += KR, buf ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0) (lgkm / exp untouched): this wave's share of the slab has landed
+    patch_y(r0, buf);
+    __syncthreads();                             // everybody's share has, and nobody reads the other buffer any more
+    if (r0 + KR < r_end) request(r0 + KR, buf ^ 1);
+    const double* pb = panel + (size_t)buf * KR * LDX;
+    const double* yb = ys + buf * KR;
+    constexpr int NF = BT / 16;
+    double fa[2][NF], fb[2][NF], fy[2];
+    auto frags = [&](int kk, double (&xa)[NF], double (&xb)[NF], double& y) {
+      const double* row = pb + (kk * 4 + g) * LDX;
+      gram_diag_frags<BT, V>(row, row, j, xa, xb);
+      y = yb[kk * 4 + g];
+    };
+    frags(0, fa[0], fb[0], fy[0]);
+#pragma unroll
+    for (int kk = 0; kk < KR / 4; ++kk) {
+      if (kk + 1 < KR / 4) frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1], fy[(kk + 1) & 1]);
+      gram_diag_mma<BT, V>(fa[kk & 1], fb[kk & 1], acc);
+      const double x0 = ys_in_a ? fa[kk & 1][YS0] : fb[kk & 1][YS0], x1 = ys_in_a ? fa[kk & 1][YS1] : fb[kk & 1][YS1];
+      vy0 = fma(x0, fy[kk & 1], vy0);
+      vy1 = fma(x1, fy[kk & 1], vy1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // X^T y: the four row groups g of a strip column, combined in a fixed order
+  vy0 += __shfl_xor(vy0, 16, 64);
+  vy0 += __shfl_xor(vy0, 32, 64);
+  vy1 += __shfl_xor(vy1, 16, 64);
+  vy1 += __shfl_xor(vy1, 32, 64);
+  if (g == 0) {
+    double* py = a.partial_y + (size_t)split * a.nt * BT;
+    py[YS0 * 16 + j] = vy0;
+    py[YS1 * 16 + j] = vy1;
+  }
+  double* out = a.partial + (size_t)split * a.ntri * BT * BT;
+  gram_diag_store<BT, V>(out, g, j, acc);
+}
+
+__global__ __launch_bounds__(256, BC_GD_BLOCKS) void k_gram_dma(GramArgs a) {
+  extern __shared__ double gd_lds[];            // [2][KR][LDX] panel + [2][KR] y
+  double* panel = gd_lds;
+  double* ys = gd_lds + 2 * BC_GD_KR * BC_GD_LDX;
+  const long long split = (long long)(blockIdx.x >> 3) * 8 + (blockIdx.x & 7);     // (as k_gram with one tile per split)
+  if (split >= a.splits) return;
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {     // (scalar branch: one variant per wave)
+    case 0: gram_dma_tile<0>(a, split, panel, ys); break;
+    case 1: gram_dma_tile<1>(a, split, panel, ys); break;
+    case 2: gram_dma_tile<2>(a, split, panel, ys); break;
+    default: gram_dma_tile<3>(a, split, panel, ys); break;
+  }
+}
+
 // Sum of the per-split partial tiles IN SPLIT ORDER, in two levels so that it is parallel: level 1 adds runs of SEG
 // consecutive splits (one thread per element and run, eight loads in flight), level 2 adds the run sums in run order
 // and scatters the tile (and its mirror image) into the dense d x d matrix.  The association is fixed by (splits, SEG):
@@ -406,7 +536,11 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   const int dz = data->dz, d = dz - 1;
   const int nt = (d + BT - 1) / BT;
   const int ntri = nt * (nt + 1) / 2;
-  const int KR = BT == 64 ? 32 : 16;
+  // one unweighted diagonal tile whose rows hold at least 128 doubles: the LDS-DMA kernel (k_gram_dma); BC_GRAM_DMA=0: the
+  // register-staged k_gram (A/B)
+  const int dma_env = getenv("BC_GRAM_DMA") ? atoi(getenv("BC_GRAM_DMA")) : 1;      // (read per call: tests flip it)
+  const bool use_dma = BT == 128 && ntri == 1 && w_dev == nullptr && dz >= 128 && dma_env != 0 && data->n_rows >= 4096;
+  const int KR = use_dma ? BC_GD_KR : (BT == 64 ? 32 : 16);
   // Row splits, in units of the 2 * n_cu resident block slots (BC_GRAM_WAVES overrides), at least 2 slabs per split.
   // One tile (D <= 128): exactly one block per slot -- every further split writes, and the reduction reads back, another
   // 128 KB tile (8 per slot were 268 MB of partials at N = 10M, D = 128: 6.06 ms with one, 7.76 ms with eight).  Several
@@ -415,7 +549,7 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   // shared rows are fetched again; static priorities or a start stagger change nothing (profiles/r03_notes.md).
   static const int waves_env = getenv("BC_GRAM_WAVES") ? atoi(getenv("BC_GRAM_WAVES")) : 0;
   const int waves = waves_env > 0 ? waves_env : (ntri == 1 ? 1 : 8);
-  const int slots = BT == 64 ? 3 : 2;      // resident blocks per CU (k_gram's launch bounds)
+  const int slots = use_dma ? BC_GD_BLOCKS : (BT == 64 ? 3 : 2);      // resident blocks per CU (the kernels' launch bounds)
   long long want_splits = ((long long)ctx->n_cu * slots * (waves > 0 ? waves : 1) + ntri - 1) / ntri;
   long long max_splits = (data->n_rows + 2 * KR - 1) / (2 * KR);
   long long splits = want_splits < max_splits ? want_splits : max_splits;
@@ -448,8 +582,21 @@ static int run_gram(bc_ctx* ctx, const bc_data* data, const double* w_dev, doubl
   a.ntri = ntri;
   int rc = bc_timer_begin(ctx, 2);
   if (!rc) {
-    hipLaunchKernelGGL(k_gram<BT>, dim3((unsigned)(((splits + 7) / 8) * 8 * ntri)), dim3(256), 0, ctx->stream, a);
-    e = hipGetLastError();
+    if (use_dma) {
+      const size_t lds = (size_t)(2 * BC_GD_KR * BC_GD_LDX + 2 * BC_GD_KR) * sizeof(double);      // 37 KB at 16-row slabs
+      static unsigned attr_done_mask = 0;
+      if (!((attr_done_mask >> (ctx->device & 31)) & 1u)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_dma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done_mask |= 1u << (ctx->device & 31);
+      }
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gram_dma, dim3((unsigned)(((splits + 7) / 8) * 8)), dim3(256), lds, ctx->stream, a);
+        e = hipGetLastError();
+      }
+    } else {
+      hipLaunchKernelGGL(k_gram<BT>, dim3((unsigned)(((splits + 7) / 8) * 8 * ntri)), dim3(256), 0, ctx->stream, a);
+      e = hipGetLastError();
+    }
   }
   if (!rc && e == hipSuccess) {
     double* part2 = partial + (size_t)splits * tile_elems;

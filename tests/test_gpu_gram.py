@@ -57,3 +57,29 @@ def test_gram_large_rows_splitk(bc):
     assert np.abs(v - vr).max() <= 1e-11 * np.abs(vr).max()
     G2, v2 = bc.weighted_gram(Z, w)
     assert np.array_equal(G, G2) and np.array_equal(v, v2)            # fixed split order: run-to-run deterministic
+
+
+@pytest.mark.parametrize('n', [4096, 10_007, 100_001, 262_145])
+@pytest.mark.parametrize('d', [127, 128])
+def test_gram_lds_dma_kernel(bc, n, d, monkeypatch):
+    """One unweighted diagonal tile whose rows hold >= 128 doubles (the drivers' full-data posterior at D = 128,
+    model_linreg.py:25-34 with w = 1) runs k_gram_dma: slabs go from global memory straight into LDS, 32 rows at a time,
+    double-buffered.  Row counts that end inside a slab (zero-filled rows), one that is a multiple of 32, one row more than
+    a multiple of the split size.  Run-to-run deterministic; against the register-staged kernel (BC_GRAM_DMA=0) the results
+    agree to rounding (the row splits, and with them the association of the partial sums, follow the slab size); both
+    match NumPy."""
+    rng = np.random.RandomState(n + d)
+    Z = rng.randn(n, d + 1)
+    Z[-1, -1] = 7.5                                       # the last row's y: the end of the array is read exactly, not past
+    monkeypatch.setenv('BC_GRAM_DMA', '1')
+    G, v = bc.weighted_gram(Z, None)
+    G2, v2 = bc.weighted_gram(Z, None)
+    assert np.array_equal(G, G2) and np.array_equal(v, v2)
+    monkeypatch.setenv('BC_GRAM_DMA', '0')
+    G0, v0 = bc.weighted_gram(Z, None)
+    assert np.abs(G - G0).max() <= 1e-13 * np.abs(G0).max()
+    np.testing.assert_allclose(v, v0, rtol=1e-12, atol=1e-12 * np.abs(v0).max())
+    Gr, vr = M.linreg_xtwx(Z, np.ones(n))
+    assert np.abs(G - Gr).max() <= 1e-12 * np.abs(Gr).max()
+    assert np.abs(v - vr).max() <= 1e-11 * max(1., np.abs(vr).max())
+    assert np.array_equal(G, G.T)
