@@ -143,4 +143,55 @@ BC_KM double bc_logistic_beta_value(double m, double c0, double c1, double c2, c
   return (m != m) ? m : v;
 }
 
+// ---- round 5: the same value with ONE exp and the log1p less.  Per element the body above spends exp(-|m|), a log1p and two
+// more exp on what are powers of f = 1 + e^-|m| in [1, 2] and of e^-|m| itself:
+//   f^-b       = rc_i^b * (1 + t)^-b,  t = f * rc_i - 1, |t| <= 2^-9  (the log table's reduction, bc_log1p_exp_neg_tab_uf)
+//              = Tb[i] * (1 + a t + a(a-1)/2 t^2 + ... to t^6),  a = -b;  Tb[i] = exp(-b * lc_i) -- 257 entries that depend on
+//                beta: each K1 block builds them once in its LDS prologue (bc_pow_table_entry); truncation C(a,7) 2^-63:
+//                1e-15 at b = 8, 2e-12 at b = 32 (the limit the library accepts for this model, BC_K1_POWTAB_MAX_BETA)
+//   (e^-|m|)^b = exp(-b |m|)                                                        -- the second and last exp
+//   m <= 0:  (1+e^m) = f:       e1 = f^-b,           e2 = f^-b / f,            e3 = (f / u)^(-b-1) = u u^b f^-b / f
+//   m  > 0:  (1+e^m) = f / u:   e1 = u^b f^-b,       e2 = u u^b f^-b / f,      e3 = f^-b / f
+// so e2 + e3 = (f^-b / f) (1 + u u^b) on both sides.  ~62 vector instructions per element instead of ~83; same saturation
+// limits, same cutoff at np.exp's overflow; max abs error against 80-bit arithmetic < 1e-14 for b <= 1 (tests/k1_math_harness.c).
+#define BC_K1_POWTAB_MAX_BETA 32.0
+// the series' coefficients b1..b6 of (1 + t)^a, a = -beta (host side: they travel as model constants)
+BC_KM void bc_powtab_coefs(double a, double (*k)[6]) {
+  (*k)[0] = a;
+  (*k)[1] = (*k)[0] * (a - 1.) * (1. / 2.);
+  (*k)[2] = (*k)[1] * (a - 2.) * (1. / 3.);
+  (*k)[3] = (*k)[2] * (a - 3.) * (1. / 4.);
+  (*k)[4] = (*k)[3] * (a - 4.) * (1. / 5.);
+  (*k)[5] = (*k)[4] * (a - 5.) * (1. / 6.);
+}
+// entry i of the power table: rc_i^beta = exp(-beta * lc_i) with lc_i = -ln(rc_i) from the log table
+BC_KM double bc_pow_table_entry(int i, double c1 /* = -beta */, const double* tab) {
+  return bc_exp_tab_core(c1 * tab[BC_K1_EXP_N + 2 * i + 1], tab);
+}
+// k1..k6: the coefficients above (k1 == c1 == -beta)
+BC_KM double bc_logistic_beta_value_pt(double m, double c0, double k1, double k2, double k3, double k4, double k5, double k6,
+                                       const double* tab, const double* tb) {
+  const double am = fmin(fabs(m), 800.);              // (fmin drops a NaN: restored below)
+  const double u = bc_exp_tab_core(-am, tab);         // e^-|m|
+  const double ub = bc_exp_tab_core(k1 * am, tab);    // (e^-|m|)^beta
+  const double f = 1. + u;
+  const double fm1 = f - 1.;                          // exact
+  const unsigned iu = bc_k1_lo32(fma(fm1, 256., 6755399441055744.));
+  const int i = (int)(iu < 256u ? iu : 256u);
+  const double rc = tab[BC_K1_EXP_N + 2 * i], T = tb[i];
+  const double t = fma(f, rc, -1.);
+  double q = fma(t, k6, k5);
+  q = fma(q, t, k4);
+  q = fma(q, t, k3);
+  q = fma(q, t, k2);
+  q = fma(q, t, k1);
+  const double fp = fma(T * q, t, T);                 // f^-beta
+  const double fpf = fp * bc_rcp_1_2(f);              // f^(-beta-1)
+  const double e1s = (m <= 0.) ? fp : ub * fp;        // (1 + e^m)^-beta
+  const double e1 = (m > BC_EXP_OVERFLOW_ARG) ? 0. : e1s;          // (1 + inf)^-b == 0 in the reference (model_lr.py:85)
+  const double e23 = fma(u * ub, fpf, fpf);           // (1 + e^m)^(-beta-1) + (1 + e^-m)^(-beta-1)
+  const double v = -((c0 * e1) - e23);
+  return (m != m) ? m : v;
+}
+
 #endif  // BC_K1_MATH_H

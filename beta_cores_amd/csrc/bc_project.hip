@@ -74,6 +74,11 @@ struct ProjArgs {
 __device__ const unsigned long long g_k1_tab_bits[BC_K1_TAB_DOUBLES] = BC_K1_TABLE_INIT;
 
 template <int MODEL>
+constexpr bool bc_model_uses_tables();
+// doubles of LDS the tables take: the static ones, plus the per-launch power table of the logistic beta-likelihood
+template <int MODEL>
+constexpr int bc_model_tab_doubles() { return !bc_model_uses_tables<MODEL>() ? 0 : BC_K1_TAB_DOUBLES + (MODEL == BC_MODEL_LOGISTIC_BETA ? 264 : 0); }
+template <int MODEL>
 constexpr bool bc_model_uses_tables() {
   return MODEL == BC_MODEL_LINREG_BETA || MODEL == BC_MODEL_LOGISTIC_LL || MODEL == BC_MODEL_LOGISTIC_BETA ||
          MODEL == BC_MODEL_GAUSS_BETA || MODEL == BC_MODEL_GAUSS_BETA_GRAD;
@@ -104,8 +109,9 @@ __device__ __forceinline__ double bc_model_value(double p, double ra, double sa,
       // (|m| is bounded for the body: past 800 it returns 0 either way; fmin drops a NaN, which the other branch keeps)
       return (m < 100.) ? -(fmax(m, 0.) + bc_log1p_exp_neg_tab(fmin(fabs(m), 800.), tab)) : -m;
     }
-    case BC_MODEL_LOGISTIC_BETA:          // -( (b+1)/b*(1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) ), out of line (below)
-      return bc_logistic_beta_value(-p, c[0], c[1], c[2], tab);
+    case BC_MODEL_LOGISTIC_BETA:          // -( (b+1)/b*(1+e^m)^-b - ((1+e^m)^(-b-1) + (1+e^-m)^(-b-1)) ): bc_k1_math.h, the form with the
+                                          // per-launch power table behind the static tables (c[1], c[4..7], c[2]: its series)
+      return bc_logistic_beta_value_pt(-p, c[0], c[1], c[4], c[5], c[6], c[7], c[2], tab, tab + BC_K1_TAB_DOUBLES);
     case BC_MODEL_GAUSS_LL: {             // cc - 1/2*(xSx + tSt - 2*xSt)
       const double q = (ra + sa) - 2. * p;
       return c[0] - 1. / 2. * q;
@@ -426,6 +432,9 @@ __global__ __launch_bounds__(128 / (16 * JT) * 64, (JT == 1 && NT <= 8) ? 4 : 2)
   double* tabl = lds + 128 * LDZ + NR * LDT;      // lookup tables of the epilogue's exp / log bodies (models that have one)
   if (bc_model_uses_tables<MODEL>()) {
     for (int i = threadIdx.x; i < BC_K1_TAB_DOUBLES; i += NTHR) tabl[i] = __builtin_bit_cast(double, g_k1_tab_bits[i]);
+    if (MODEL == BC_MODEL_LOGISTIC_BETA)          // the power table of this launch's beta (bc_k1_math.h), from the global tables
+      for (int i = threadIdx.x; i < BC_K1_LOG_N; i += NTHR)
+        tabl[BC_K1_TAB_DOUBLES + i] = bc_pow_table_entry(i, a.c[1], reinterpret_cast<const double*>(g_k1_tab_bits));
   }                                               // visible after the first barrier of the contraction loop
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -688,8 +697,12 @@ __global__ __launch_bounds__(512, 2) void k_project_r(ProjArgs a) {
   } else {
     for (int i = tid; i < 8 * NR; i += 512) csum[i] = 0.;
   }
-  if (bc_model_uses_tables<MODEL>())
+  if (bc_model_uses_tables<MODEL>()) {
     for (int i = tid; i < BC_K1_TAB_DOUBLES; i += 512) tabl[i] = __builtin_bit_cast(double, g_k1_tab_bits[i]);
+    if (MODEL == BC_MODEL_LOGISTIC_BETA)
+      for (int i = tid; i < BC_K1_LOG_N; i += 512)
+        tabl[BC_K1_TAB_DOUBLES + i] = bc_pow_table_entry(i, a.c[1], reinterpret_cast<const double*>(g_k1_tab_bits));
+  }
   __syncthreads();
 
   const double* trow = Tl + j * ldt + g;
@@ -966,9 +979,21 @@ static int model_constants(int model, const double* p, int np, int d, double* c,
       // bc_model_value_np); without the second one the library evaluates that value itself with the restated np.power
       if (np != 1 && np != 2) return BC_INVALID_ARGUMENT;
       const double beta = p[0];
+      if (!(beta <= BC_K1_POWTAB_MAX_BETA)) {
+        bc_set_error("bc_project: the logistic beta-likelihood takes 0 < beta <= %g on the device (got %g)", BC_K1_POWTAB_MAX_BETA, beta);
+        return BC_INVALID_ARGUMENT;
+      }
       c[0] = (beta + 1.) / beta;
-      c[1] = -beta;
-      c[2] = -beta - 1.;
+      {
+        double k[6];
+        bc_powtab_coefs(-beta, &k);        // (1 + t)^-beta to t^6: c[1] = -beta, c[4..7], c[2]
+        c[1] = k[0];
+        c[4] = k[1];
+        c[5] = k[2];
+        c[6] = k[3];
+        c[7] = k[4];
+        c[2] = k[5];
+      }
       if (np == 2) {
         c[3] = p[1];
       } else {
@@ -1012,7 +1037,7 @@ enum { PROJ_FULL = 0, PROJ_RAW = 1, PROJ_COLSUM = 2 };
 template <int MODEL, int NT, int KC, int JT, bool RAW = false, int TL = 0, bool STORE = true>
 static int launch_project(bc_ctx* ctx, const ProjArgs& a, long long ntiles) {
   size_t lds = (size_t)(128 * (KC + 1) + (NT * 16 + TL) * (KC + 2)) * sizeof(double);
-  if (bc_model_uses_tables<MODEL>()) lds += (size_t)BC_K1_TAB_DOUBLES * sizeof(double);
+  if (bc_model_uses_tables<MODEL>()) lds += (size_t)bc_model_tab_doubles<MODEL>() * sizeof(double);
 #ifdef BC_K1_STAMPS
   if (getenv("BC_K1_EXTRA_LDS")) lds += (size_t)atoi(getenv("BC_K1_EXTRA_LDS"));   // diagnostic: fewer blocks per CU
 #endif
@@ -1057,13 +1082,13 @@ static int launch_project_model(bc_ctx* ctx, const ProjArgs& a, long long ntiles
 }
 
 // ---- Theta-resident kernel: one 512-thread block per CU, LDS = Theta + per-wave column sums + transposition scratch (+ tables)
-static size_t project_r_lds_bytes(int nr, int dk, bool tables) {
-  return ((size_t)nr * (dk + 2) + 8 * (size_t)nr + 8 * (5 * 4 * 17) + (tables ? BC_K1_TAB_DOUBLES : 0)) * sizeof(double);
+static size_t project_r_lds_bytes(int nr, int dk, int table_doubles) {
+  return ((size_t)nr * (dk + 2) + 8 * (size_t)nr + 8 * (5 * 4 * 17) + (size_t)table_doubles) * sizeof(double);
 }
 
 template <int MODEL, int NT, int TL, bool STORE>
 static int launch_project_r(bc_ctx* ctx, const ProjArgs& a, int grid) {
-  const size_t lds = project_r_lds_bytes(NT * 16 + TL, a.dk, bc_model_uses_tables<MODEL>());
+  const size_t lds = project_r_lds_bytes(NT * 16 + TL, a.dk, bc_model_tab_doubles<MODEL>());
   static unsigned attr_done = 0;
   const unsigned bit = 1u << (ctx->device & 31);
   if (!(attr_done & bit)) {
@@ -1223,7 +1248,7 @@ static int project_r_grid(const bc_ctx* ctx, const ProjPlan& pl, const bc_phi* p
   if (pl.model == BC_MODEL_LOGISTIC_BETA && !(env && atoi(env) < 0)) return 0;      // measured slower there (0.80 vs 0.74 ms at N = 1M, D = 128): four
                                                                                        // transcendental bodies per element; BC_K1_STAGED=-1 forces the resident kernel
   const int nr = pl.ntsel * 16 + (pl.ntsel == 6 ? 4 : 0);
-  if (project_r_lds_bytes(nr, pl.a.dk, true) > (size_t)ctx->max_lds) return 0;
+  if (project_r_lds_bytes(nr, pl.a.dk, BC_K1_TAB_DOUBLES + 264) > (size_t)ctx->max_lds) return 0;
   const long long grid = ctx->n_cu;
   if (phi->ntiles < grid * 8) return 0;
   return (int)grid;

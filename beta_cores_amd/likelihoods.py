@@ -55,10 +55,14 @@ class LogisticRegression(_Model):
     model_id = LOGISTIC_LL
     beta_model_id = LOGISTIC_BETA
 
+    MAX_BETA = 32.     # csrc/bc_k1_math.h: BC_K1_POWTAB_MAX_BETA (the power series of the device body is truncated for beta up to here)
+
     def params(self, beta=None, grad=False):
         if beta is None:
             return np.array([])
         beta = _checked_beta(beta)
+        if not 0. < beta <= self.MAX_BETA:
+            raise ValueError('the device logistic beta-likelihood takes 0 < beta <= %g (got %r)' % (self.MAX_BETA, beta))
         return np.array([beta, self.beta_value_at_zero(beta)])
 
     @staticmethod

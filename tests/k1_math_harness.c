@@ -73,6 +73,38 @@ int main(int argc, char** argv) {
     const long double wantb = -(((long double)c0) * powl(1.L + expl(709.78L), (long double)c1) - (powl(1.L + expl(709.78L), (long double)c2) + 1.L));
     if (fabsl((long double)below - wantb) > 1e-14L || below > 0.92) { printf("beta-lik below the cutoff BAD %.17g\n", below); return 1; }
   }
+  /* round 5: the body K1 runs -- power table + binomial series instead of log1p + exp (bc_logistic_beta_value_pt) */
+  {
+    const double pb[6] = {0.01, 0.1, 0.5, 1.0, 8.0, 32.0};
+    double pmax_small = 0., pmax_big = 0.;
+    for (int bi = 0; bi < 6; ++bi) {
+      const double b = pb[bi], c0 = (b + 1.) / b;
+      double k[6], tb[BC_K1_LOG_N];
+      bc_powtab_coefs(-b, &k);
+      for (int i = 0; i < BC_K1_LOG_N; ++i) tb[i] = bc_pow_table_entry(i, -b, tab);
+      for (long i = 0; i < n / 4; ++i) {
+        const double r = rnd();
+        const double m = (i & 3) == 0 ? (r - 0.5) * 1400. : ((i & 3) == 1 ? (r - 0.5) * 8. : (r - 0.5) * 80.);
+        const double got = bc_logistic_beta_value_pt(m, c0, k[0], k[1], k[2], k[3], k[4], k[5], tab, tb);
+        const long double em = expl((long double)m), enm = expl(-(long double)m);
+        const long double want = -(((long double)c0) * powl(1.L + em, -(long double)b) - (powl(1.L + em, -(long double)b - 1.L) + powl(1.L + enm, -(long double)b - 1.L)));
+        const double err = (double)fabsl((long double)got - want);
+        if (b <= 1.) { if (err > pmax_small) pmax_small = err; } else if (err > pmax_big) pmax_big = err;
+      }
+      /* saturation and np.exp's overflow: exactly the reference's values */
+      if (bc_logistic_beta_value_pt(900., c0, k[0], k[1], k[2], k[3], k[4], k[5], tab, tb) != 1.0 ||
+          bc_logistic_beta_value_pt(709.79, c0, k[0], k[1], k[2], k[3], k[4], k[5], tab, tb) != 1.0 ||
+          bc_logistic_beta_value_pt(-900., c0, k[0], k[1], k[2], k[3], k[4], k[5], tab, tb) != -(c0 - 1.0) ||
+          bc_logistic_beta_value_pt(-47., c0, k[0], k[1], k[2], k[3], k[4], k[5], tab, tb) != -(c0 - 1.0) ||
+          !isnan(bc_logistic_beta_value_pt(NAN, c0, k[0], k[1], k[2], k[3], k[4], k[5], tab, tb))) {
+        printf("beta-lik (power table) limits BAD at beta %g\n", b);
+        return 1;
+      }
+    }
+    printf("logistic_beta_value_pt: max abs err %.3g (beta <= 1; values O(1/beta)), %.3g (beta = 8, 32)\n", pmax_small, pmax_big);
+    /* beta = 0.01: values reach 100; 80-bit pow itself is good to ~1e-17 relative */
+    if (!(pmax_small < 2e-13) || !(pmax_big < 1e-11)) return 1;
+  }
   printf("logistic_beta_value: max abs err %.3g (values are O(1..1/beta))\n", bmax);
   if (!(bmax < 1e-14)) return 1;
   /* special values */

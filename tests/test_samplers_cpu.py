@@ -92,6 +92,10 @@ def test_logistic_beta_constant_at_zero_is_numpys():
             np.testing.assert_array_equal(row[0], g['S%d_b%g_phi_const' % (S, beta)][0])
     p = LogisticRegression().params(0.1)
     assert p.shape == (2,) and p[0] == 0.1 and p[1] == LogisticRegression.beta_value_at_zero(0.1)
+    for bad in (0., -0.5, 33.):        # the device body's power series covers 0 < beta <= 32 (csrc/bc_k1_math.h)
+        with pytest.raises(ValueError):
+            LogisticRegression().params(bad)
+    assert LogisticRegression().params(32.)[0] == 32.
 
 
 @pytest.mark.parametrize('S', [37, 100])
