@@ -38,6 +38,8 @@ _SIGNATURES = {
     'bc_data_create': [vp, C.c_int64, C.c_int32, vpp],
     'bc_data_upload': [vp, vp, C.c_int64],
     'bc_data_gather_rows': [vp, vp, C.c_int64, vp],
+    'bc_data_zero_feature_keys': [vp, C.c_int32, C.c_int64, vp, C.POINTER(C.c_int64)],
+    'bc_ctx_set_constant_row_values': [vp, C.c_int, vp, C.c_int32, vp, vp, C.c_int64],
     'bc_data_destroy': [vp],
     'bc_phi_from_host': [vp, vp, C.c_int64, C.c_int32, C.c_int64, vpp],
     'bc_phi_create': [vp, C.c_int64, C.c_int32, vpp],

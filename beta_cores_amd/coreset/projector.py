@@ -17,6 +17,7 @@ import numpy as np
 
 from .. import _native as N
 from ..device import DeviceData, DevicePhi, _as_f64, _ptr, default_context
+from ..util import numpy_bits
 
 
 class Projector(object):
@@ -201,6 +202,11 @@ class _DeviceProjectorBase(Projector):
         self._pins = {}            # id(ndarray) -> (weakref, DeviceData): arrays the caller pinned (see pin())
         self._slots = {}           # dz -> DeviceData slot for small transient inputs
         self._pool = _PhiPool(self.ctx)
+        # constant rows whose value holds an np.exp: on a host whose NumPy is not the one the library restates they are
+        # evaluated on the host (util/numpy_bits.py); `_key_cache`: the y's of the all-zero-feature rows of large inputs
+        self._host_constants = numpy_bits.warn_if_constant_bits_differ(model) and getattr(model, 'host_constants', None) is not None
+        self._key_cache = {}
+        self.constant_rows_from_host = 0      # how many (y, value) pairs the last beta-projection handed to the kernel
         self.update(np.array([]), np.array([]))
 
     def update(self, wts, pts):
@@ -270,10 +276,59 @@ class _DeviceProjectorBase(Projector):
             return slot.update(pts), True
         return DeviceData(pts, ctx=self.ctx), False            # live array, uploaded for this call
 
+    def _zero_feature_keys(self, pts, d):
+        """Sorted unique y of the rows of `pts` whose d features are all zero (host array: NumPy; resident rows: one device scan)."""
+        if isinstance(pts, DeviceData):
+            hit = self._key_cache.get(id(pts))
+            if hit is not None and hit[0]() is pts:
+                return hit[1]
+            cap = 65536
+            out, n = np.empty(cap), C.c_int64()
+            N.call('bc_data_zero_feature_keys', pts.h, int(d), cap, _ptr(out), C.byref(n))
+            if n.value > cap:
+                raise ValueError('%d data rows have all-zero features: more than the %d the host route for constant rows handles'
+                                 % (n.value, cap))
+            keys = np.unique(out[:n.value])
+            try:
+                self._key_cache[id(pts)] = (weakref.ref(pts, lambda _, k=id(pts), c=self._key_cache: c.pop(k, None)), keys)
+            except TypeError:
+                pass
+            return keys
+        arr = np.atleast_2d(np.asarray(pts, dtype=np.float64))
+        big = arr.shape[0] >= _SMALL_ROWS and isinstance(pts, np.ndarray)
+        if big:
+            hit = self._key_cache.get(id(pts))
+            if hit is not None and hit[0]() is pts:
+                return hit[1]
+        keys = np.unique(arr[~arr[:, :d].any(axis=1), d])
+        if big:
+            try:
+                self._key_cache[id(pts)] = (weakref.ref(pts, lambda _, k=id(pts), c=self._key_cache: c.pop(k, None)), keys)
+            except TypeError:
+                pass
+        return keys
+
+    def _stage_host_constants(self, pts, model_id, params, more=None):
+        """Before a beta-projection on a host whose NumPy the library does not restate: the constants of the all-zero-feature
+        rows of `pts` (and of `more`, a second row set projected by the same native call), evaluated here, go to the kernel
+        (bc_ctx_set_constant_row_values).  No-op everywhere else."""
+        if not self._host_constants or model_id != self.model.beta_model_id:
+            return
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        d = self.model.data_width(np.atleast_2d(self.samples).shape[1]) - 1
+        keys = self._zero_feature_keys(pts, d)
+        if more is not None:
+            keys = np.union1d(keys, self._zero_feature_keys(more, d))
+        vals = np.ascontiguousarray(self.model.host_constants(keys, params[1]), dtype=np.float64) if keys.size else np.zeros(0)
+        self.constant_rows_from_host = int(keys.size)
+        N.call('bc_ctx_set_constant_row_values', self.ctx.h, int(model_id), _ptr(params), int(params.shape[0]),
+               _ptr(np.ascontiguousarray(keys)), _ptr(vals), int(keys.size))
+
     def _run_from_host(self, pts, model_id, params, keep=False):
         """project(ndarray) for a LARGE live host array: upload and K1 pipelined in one native call (bc_project_from_host;
         Phi, norms and column sums are the resident path's bit for bit).  Returns (DevicePhi, DeviceData of the uploaded
         rows); the latter is dropped by the caller unless it wants the rows to stay in HBM."""
+        self._stage_host_constants(pts, model_id, params)
         pts = _as_f64(np.atleast_2d(pts), 'data')
         theta = self.model.theta_for_device(self.samples)
         if pts.shape[1] != self.model.data_width(theta.shape[1]):
@@ -295,6 +350,7 @@ class _DeviceProjectorBase(Projector):
     def _run(self, pts, model_id, params):
         if isinstance(pts, np.ndarray) and pts.ndim == 2 and pts.shape[0] >= _PIPE_ROWS and self._pins.get(id(pts)) is None:
             return self._run_from_host(pts, model_id, params)[0]
+        self._stage_host_constants(pts, model_id, params)
         dd, transient = self.device_data(pts)
         theta = self.model.theta_for_device(self.samples)
         if dd.shape[1] != self.model.data_width(theta.shape[1]):
@@ -337,6 +393,7 @@ class _DeviceProjectorBase(Projector):
             return None
         model_id, params = self._ids(beta)
         params = np.ascontiguousarray(params, dtype=np.float64)
+        self._stage_host_constants(pts, model_id, params)
         out = np.empty(S)
         N.call('bc_project_colsum', self.ctx.h, dd.h, int(model_id), _ptr(theta), S, _ptr(params), int(params.shape[0]),
                comm, _ptr(out))
@@ -363,6 +420,7 @@ class _DeviceProjectorBase(Projector):
             raise ValueError('one weight per coreset row')
         model_id, params = self._ids(beta)
         params = np.ascontiguousarray(params, dtype=np.float64)
+        self._stage_host_constants(data, model_id, params, more=core)
         grad = np.empty(m)
         resid = np.empty(S) if want_resid else None
         N.call('bc_vi_gradient_begin', self.ctx.h, dd.h, _ptr(core), m, int(model_id), _ptr(theta), S, _ptr(params),

@@ -94,7 +94,7 @@ extern "C" int bc_ctx_destroy(bc_ctx* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->colsum_phi) bc_phi_destroy(ctx->colsum_phi);
   if (ctx->core_phi) bc_phi_destroy(ctx->core_phi);
-  bc_scratch* all[] = {&ctx->proj_theta, &ctx->proj_rowaux, &ctx->proj_rowaux2, &ctx->gradx, &ctx->vi_buf,
+  bc_scratch* all[] = {&ctx->proj_theta, &ctx->proj_rowaux, &ctx->proj_rowaux2, &ctx->gradx, &ctx->vi_buf, &ctx->const_rows,
                        &ctx->gram[0], &ctx->gram[1], &ctx->gram[2], &ctx->gram[3], &ctx->gram[4]};
   for (bc_scratch* sc : all)
     if (sc->p) (void)hipFree(sc->p);

@@ -71,6 +71,12 @@ struct bc_ctx {
   hipStream_t vi_side = nullptr;  // bc_vi_gradient: the coreset rows' K1 runs here, beside the data rows' launch on `stream`
   hipEvent_t vi_ev_staged = nullptr, vi_ev_core = nullptr;
   struct bc_uploader* upl = nullptr;   // pipelined host -> HBM uploads (bc_upload.hip): copy streams, pinned staging, events
+  // host-evaluated constants of constant rows (bc_ctx_set_constant_row_values): sorted keys, then values, on the device
+  bc_scratch const_rows;
+  int64_t n_const_rows = 0;
+  int const_model = -1;
+  double const_params[4] = {0., 0., 0., 0.};
+  int const_n_params = 0;
 };
 
 // bc_upload.hip: rows of a host array -> dst_dev through pinned staging and several copy threads; the hook (optional) is

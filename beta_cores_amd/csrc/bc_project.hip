@@ -58,6 +58,11 @@ struct ProjArgs {
   int part_init;          // k_project_r: start the per-wave column partials from tile_part instead of 0 (a later chunk of
                           // a chunked projection, bc_project_from_host: the same sums in the same order as ONE launch)
   double c[8];            // model constants, see model_constants()
+  // constant rows whose model value the HOST evaluated (bc_ctx_set_constant_row_values: hosts whose NumPy does not take the
+  // SVML exp bc_np_exp.h restates): sorted keys (LINREG_BETA: the row's y), the values, how many; 0: none
+  const double* ck;
+  const double* cv;
+  int nck;
 #ifdef BC_K1_STAMPS       // diagnostic build: s_memtime of wave 0 at phase boundaries, 32 slots per tile
   unsigned long long* stamps;
 #endif
@@ -181,9 +186,21 @@ constexpr bool bc_model_const_fixup() { return bc_model_has_np_exp<MODEL>() || M
 // the constant of a constant row from the contraction value `p` of the lane's first sample: every lane of the row
 // evaluates its own (they agree up to the last bit), the lane with g == 0 decides
 template <int MODEL>
-__device__ __forceinline__ double bc_const_row_value(double devval, double p, double ra, double sa, const double* c, int lane, const double* tab) {
+__device__ __forceinline__ double bc_const_row_value(double devval, double p, double ra, double sa, const double* c, int lane, const double* tab,
+                                                     const double* ck = nullptr, const double* cv = nullptr, int nck = 0) {
   if (!bc_model_const_fixup<MODEL>()) return devval;
   double v = bc_model_value_np<MODEL>(p, ra, sa, c, tab);
+  if (MODEL == BC_MODEL_LINREG_BETA && nck > 0) {
+    // the caller's own evaluation of the reference's expression for rows with all-zero features (their value depends on y
+    // alone): binary search on y.  (Rare branch of a rare branch; the value still has to agree with the device's to 1e-13.)
+    int lo = 0, hi = nck - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const double k = ck[mid];
+      if (k == ra) { v = cv[mid]; break; }
+      if (k < ra) lo = mid + 1; else hi = mid - 1;
+    }
+  }
   v = __shfl(v, lane & 15, BC_WAVE);
   // the restated value is the same number as the device's own up to the last bits; anything else means the row is
   // constant for another reason than equal arguments (it then keeps the device's value)
@@ -273,7 +290,7 @@ __device__ __forceinline__ void k1_row_stats(double4_t (&acc)[JT][NT], double (&
         ok &= (d0 == __shfl_xor(d0, 32, BC_WAVE)) ? 1 : 0;
         ok &= __shfl_xor(ok, 32, BC_WAVE);
         if (ok) {                                    // the four lanes of a constant row take this together
-          const double cval = bc_const_row_value<MODEL>(mean + d0, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane, tabl);
+          const double cval = bc_const_row_value<MODEL>(mean + d0, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane, tabl, a.ck, a.cv, a.nck);
           mean = bc_np_sum_const_256(cval, S) / (double)S;
           const double v = cval - mean;
           sq = 0.;
@@ -371,7 +388,7 @@ __device__ __forceinline__ void k1_row_stats(double4_t (&acc)[JT][NT], double (&
     // residue, a non-zero norm, and is NOT one of the "all-zero rows" dropped at hilbert.py:16.  The tree-order sum
     // above would round differently and flip that zero / non-zero status, so such rows use NumPy's order.
     if (bc_model_const_fixup<MODEL>() && __builtin_amdgcn_ballot_w64(constant_row && live) != 0ull) {
-      const double cnp = bc_const_row_value<MODEL>(cval, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane, tabl);
+      const double cnp = bc_const_row_value<MODEL>(cval, p00, ra, (MODEL >= BC_MODEL_GAUSS_LL) ? a.saux[g] : 0., a.c, lane, tabl, a.ck, a.cv, a.nck);
       if (constant_row && live) {                // the reference's bits for the constant: every element of the row IS it
         cval = cnp;
 #pragma unroll
@@ -1171,6 +1188,12 @@ static int plan_stage(bc_ctx* ctx, int model, const double* theta, int32_t s, co
     bc_set_error("bc_project: model %d expects a different number of parameters than %d (d = %d)", model, n_params, d);
     return BC_INVALID_ARGUMENT;
   }
+  if (ctx->n_const_rows > 0 && ctx->const_model == model && ctx->const_n_params == n_params &&
+      memcmp(ctx->const_params, params, (size_t)n_params * sizeof(double)) == 0) {
+    a.ck = ctx->const_rows.p;                   // host-evaluated constants for exactly this model and these parameters
+    a.cv = ctx->const_rows.p + ctx->n_const_rows;
+    a.nck = (int)ctx->n_const_rows;
+  }
   const int nt = (s + 15) / 16;
   static const int no_tail = getenv("BC_K1_NOTAIL") ? atoi(getenv("BC_K1_NOTAIL")) : 0;
   const bool tail = !raw && s > 96 && s <= 100 && !no_tail;      // 6 MFMA tiles + one sample quad
@@ -1377,6 +1400,79 @@ extern "C" int bc_project(bc_ctx* ctx, const bc_data* data, int model, const dou
 // Host rows -> Phi, pipelined (hilbert.py:11-17 and bcores.py:44 hand the projector HOST arrays): the rows are uploaded in
 // chunks (bc_upload.hip) and K1 runs on chunk c behind the event that marks its arrival while chunks c+1.. are still on
 // the wire.  Rows are independent, so Phi and the norms are the resident path's bit for bit; the column sums too, because
+// ---- constant rows with the CALLER's bits (hosts whose NumPy does not evaluate np.exp with the SVML routine bc_np_exp.h
+// restates: the reference's own bits for a constant row's value are then NumPy's on THAT host).
+// A data row with all-zero features projects to S equal values that depend on its y alone (model_neurlinr.py:102-110 with
+// x = 0); the host layer finds those rows (bc_data_zero_feature_keys), evaluates the reference's expression for their y's
+// with its own NumPy and hands (y, value) pairs over; K1's constant-row branch then takes the value from here.
+__global__ __launch_bounds__(256) void k_zero_feature_keys(const double* __restrict__ z, long long n_rows, int dz, int d,
+                                                          double* __restrict__ out, unsigned long long* __restrict__ count,
+                                                          long long cap) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const double* row = z + (size_t)r * dz;
+  for (int k = 0; k < d; ++k)
+    if (row[k] != 0.) return;                   // (almost every row leaves at k = 0)
+  const unsigned long long slot = atomicAdd(count, 1ull);
+  if ((long long)slot < cap) out[slot] = row[d];
+}
+
+extern "C" int bc_data_zero_feature_keys(const bc_data* data, int32_t d, int64_t cap, double* out_keys, int64_t* out_n) {
+  if (!data || !out_n || d <= 0 || d >= data->dz || cap < 0 || (cap > 0 && !out_keys)) {
+    bc_set_error("bc_data_zero_feature_keys: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  bc_ctx* ctx = data->ctx;
+  *out_n = 0;
+  if (data->n_rows == 0) return BC_OK;
+  BC_HIP(hipSetDevice(ctx->device));
+  int rc = bc_scratch_grow(ctx, &ctx->proj_rowaux2, (size_t)cap + 2);
+  if (rc) return rc;
+  double* buf = ctx->proj_rowaux2.p;
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(buf + cap);
+  BC_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(k_zero_feature_keys, dim3((unsigned)((data->n_rows + 255) / 256)), dim3(256), 0, ctx->stream, data->z,
+                     (long long)data->n_rows, data->dz, d, buf, cnt, (long long)cap);
+  BC_HIP(hipGetLastError());
+  unsigned long long n = 0;
+  BC_HIP(hipMemcpyAsync(&n, cnt, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));
+  *out_n = (int64_t)n;                          // may exceed cap: the caller then knows the list is truncated
+  const int64_t take = (int64_t)n < cap ? (int64_t)n : cap;
+  if (take > 0) {
+    BC_HIP(hipMemcpyAsync(out_keys, buf, (size_t)take * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BC_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return BC_OK;
+}
+
+extern "C" int bc_ctx_set_constant_row_values(bc_ctx* ctx, int model, const double* params, int32_t n_params, const double* keys,
+                                              const double* values, int64_t n) {
+  if (!ctx || n < 0 || (n > 0 && (!keys || !values || !params)) || n_params < 0 || n_params > 4) {
+    bc_set_error("bc_ctx_set_constant_row_values: bad argument");
+    return BC_INVALID_ARGUMENT;
+  }
+  if (n == 0) { ctx->n_const_rows = 0; ctx->const_model = -1; return BC_OK; }
+  if (model != BC_MODEL_LINREG_BETA) {
+    bc_set_error("bc_ctx_set_constant_row_values: only the linear-regression beta-likelihood takes host-evaluated constants");
+    return BC_INVALID_ARGUMENT;
+  }
+  for (int64_t i = 1; i < n; ++i)
+    if (!(keys[i - 1] < keys[i])) { bc_set_error("bc_ctx_set_constant_row_values: keys must be strictly increasing"); return BC_INVALID_ARGUMENT; }
+  BC_HIP(hipSetDevice(ctx->device));
+  BC_HIP(hipStreamSynchronize(ctx->stream));    // no launch in flight may still read the old table
+  int rc = bc_scratch_grow(ctx, &ctx->const_rows, (size_t)(2 * n));
+  if (rc) return rc;
+  BC_HIP(hipMemcpyAsync(ctx->const_rows.p, keys, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  BC_HIP(hipMemcpyAsync(ctx->const_rows.p + n, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  BC_HIP(hipStreamSynchronize(ctx->stream));    // the host arrays are only borrowed for the call
+  ctx->n_const_rows = n;
+  ctx->const_model = model;
+  ctx->const_n_params = n_params;
+  memcpy(ctx->const_params, params, (size_t)n_params * sizeof(double));
+  return BC_OK;
+}
+
 // the chunks keep the partial sums' association: the staged kernel writes one partial row per 128-row tile (chunks are
 // tile-aligned), the Theta-resident kernel's per-wave partials are CONTINUED from chunk to chunk (ProjArgs::part_init;
 // chunks start at multiples of 8 * n_cu groups = 65 536 rows, so every wave adds the same groups in the same order as in

@@ -39,11 +39,25 @@ class LinearRegression(_Model):
     model_id = LINREG_LL
     beta_model_id = LINREG_BETA
 
+    constant_has_numpy_exp = True      # the beta-likelihood of a row with x = 0 is c(y) and holds an np.exp (util/numpy_bits.py)
+
     def __init__(self, sigsq=1.0):
         self.sigsq = float(sigsq)
 
     def params(self, beta=None, grad=False):
         return np.array([self.sigsq] if beta is None else [self.sigsq, _checked_beta(beta)])
+
+    def host_constants(self, y, beta):
+        """model_neurlinr.py:102-110 for rows with all-zero features (XST = x.th^T = 0 for every sample), evaluated with this
+        host's NumPy in the reference's expression order: the S equal values such a row projects to, one per y.  (Array
+        arithmetic on an (n, 1) column, the shape the reference's N x S expression has per sample.)"""
+        sigsq, beta = self.sigsq, float(beta)
+        y = np.asarray(y, dtype=np.float64)
+        XST = np.zeros((y.shape[0], 1))
+        with np.errstate(all='ignore'):
+            vals = 1. / (2 * np.pi * sigsq) ** (beta / 2.) * (-(beta + 1.) / beta * np.exp(-beta / (2. * sigsq) * (y[:, np.newaxis] ** 2 - 2 * XST * y[:, np.newaxis] + XST ** 2))
+                                                              + 1. / np.sqrt(1. + beta))
+        return vals[:, 0]
 
     def data_width(self, theta_dim):
         return theta_dim + 1
@@ -88,6 +102,9 @@ class GaussianLocation(_Model):
     model_id = GAUSS_LL
     beta_model_id = GAUSS_BETA
     beta_grad_model_id = GAUSS_BETA_GRAD
+
+    constant_has_numpy_exp = True      # (gaussian.py:42; constant rows need all samples equidistant from x: no host route)
+    host_constants = None
 
     def __init__(self, Siginv, logdetSig):
         self.Siginv = np.ascontiguousarray(Siginv, dtype=np.float64)

@@ -141,6 +141,19 @@ int bc_data_create(bc_ctx* ctx, int64_t cap_rows, int32_t dz, bc_data** out);
 int bc_data_upload(bc_data* d, const double* z_rowmajor, int64_t n_rows);
 /* rows by LOCAL index -> m x dz row-major on the host (`pts = data[idcs]`, hilbert.py:33) */
 int bc_data_gather_rows(bc_data* d, const int64_t* local_idx, int64_t m, double* out);
+/* Constant rows with the CALLER's bits.  A data row whose d features are all exactly 0 projects to S equal values (a
+ * "constant row"); whether the reference's centring (projector.py:26 / :55) leaves it exactly 0 depends on the last bit of
+ * that value, and for the beta-likelihood of the linear regression the value contains np.exp (model_neurlinr.py:107).  The
+ * library restates the routine NumPy takes on AVX-512 hosts (csrc/bc_np_exp.h); on any other host the reference's bits are
+ * that host's NumPy's, so the host layer (coreset/projector.py) evaluates the expression itself:
+ *   bc_data_zero_feature_keys: the y (column d) of every row whose first d columns are all zero -> out_keys[0 .. min(*out_n, cap));
+ *     *out_n = how many there are (a value above cap says the list is truncated).
+ *   bc_ctx_set_constant_row_values: (y, value) pairs, y strictly increasing, for `model` (only BC_MODEL_LINREG_BETA) with
+ *     exactly these `params`; later bc_project* calls of that model and those parameters on this context take a constant
+ *     row's value from the table when its y is in it (and the value agrees with the device's own to 1e-13).  n = 0 clears. */
+int bc_data_zero_feature_keys(const bc_data* data, int32_t d, int64_t cap, double* out_keys, int64_t* out_n);
+int bc_ctx_set_constant_row_values(bc_ctx* ctx, int model, const double* params, int32_t n_params, const double* keys,
+                                   const double* values, int64_t n);
 int bc_data_destroy(bc_data* d);
 
 /* ---- Phi: the N x S matrix of row-centred (beta-)log-likelihoods ------- */

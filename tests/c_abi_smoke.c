@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   void* syms[] = {(void*)bc_version, (void*)bc_last_error, (void*)bc_ctx_create, (void*)bc_ctx_destroy, (void*)bc_ctx_sync,
                   (void*)bc_ctx_kernel_time, (void*)bc_ctx_kernel_time_reset, (void*)bc_ctx_enable_timing,
                   (void*)bc_data_from_host, (void*)bc_data_from_device, (void*)bc_data_create, (void*)bc_data_upload,
-                  (void*)bc_data_gather_rows, (void*)bc_data_destroy, (void*)bc_phi_from_host, (void*)bc_phi_create,
+                  (void*)bc_data_gather_rows, (void*)bc_data_zero_feature_keys, (void*)bc_ctx_set_constant_row_values, (void*)bc_data_destroy, (void*)bc_phi_from_host, (void*)bc_phi_create,
                   (void*)bc_project, (void*)bc_project_grad_x, (void*)bc_phi_shape, (void*)bc_phi_colsum, (void*)bc_phi_norms, (void*)bc_phi_norm_stats,
                   (void*)bc_phi_to_host, (void*)bc_phi_gather_rows, (void*)bc_phi_group_sum, (void*)bc_phi_matvec, (void*)bc_phi_destroy,
                   (void*)bc_phi_argmax, (void*)bc_snnls_create, (void*)bc_snnls_destroy, (void*)bc_snnls_prefilter_active, (void*)bc_snnls_prefilter_form,

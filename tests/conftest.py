@@ -26,17 +26,6 @@ def golden():
 def numpy_uses_svml_exp():
     """True where the running NumPy evaluates float64 np.exp with the SVML routine it bundles (x86-64 with AVX512_SKX):
     the hosts the goldens were generated on, and the ones on which 'the reference's bits' of an exp are defined the
-    way beta_cores_amd/csrc/bc_np_exp.h restates them."""
-    import math
-    import numpy as np
-    try:
-        from numpy._core._multiarray_umath import __cpu_features__ as feats
-    except Exception:
-        try:
-            from numpy.core._multiarray_umath import __cpu_features__ as feats
-        except Exception:
-            return False
-    if not feats.get('AVX512_SKX', False):
-        return False
-    x = -np.random.RandomState(0).uniform(0, 50, 20000)
-    return bool((np.exp(x) != np.array([math.exp(v) for v in x])).any())
+    way beta_cores_amd/csrc/bc_np_exp.h restates them.  (The product's own probe: beta_cores_amd/util/numpy_bits.py.)"""
+    from beta_cores_amd.util.numpy_bits import numpy_uses_svml_exp as probe
+    return probe()

@@ -207,6 +207,27 @@ def test_f13_zero_rows_are_nan_candidates(bc, S, nm, projector):
         np.testing.assert_array_equal(alg.wts, g['S%d_%s_allw_%d' % (S, nm, m)])
 
 
+@pytest.mark.parametrize('S', [16, 100])
+def test_f13_through_the_host_evaluated_constants(bc, S, monkeypatch):
+    """Golden F13 (all-zero-feature rows under the beta-likelihood of the linear regression: NaN candidates or residue rows
+    depending on the last bit of their constant) with the projector forced onto the route a host without AVX-512 NumPy takes:
+    constants evaluated on the host and handed to K1 -- through the materialising projection, the store-free column sums and
+    the fused gradient.  Same selections, same weights."""
+    from beta_cores_amd.util import numpy_bits
+    monkeypatch.setattr(numpy_bits, '_cached', False)
+    monkeypatch.setattr(numpy_bits, '_warned', set())
+    g = load_golden('f13_greedy_vi_zero_rows')
+    Z, E = g['S%d_Z' % S], g['S%d_E' % S]
+    with pytest.warns(UserWarning, match='evaluated on the host'):
+        prj = bc.DeviceBetaProjector(make_sampler(Z, E), S, bc.likelihoods.LinearRegression(1.0))
+    alg = bc.BetaCoreset(Z, prj, opt_itrs=5, step_sched=lambda i: 0.1 / (1. + i), beta=0.1, learn_beta=False)
+    for m in range(4):
+        alg.build(1, m + 1)
+        np.testing.assert_array_equal(alg.idcs, g['S%d_bcores_allidcs_%d' % (S, m)])
+        np.testing.assert_array_equal(alg.wts, g['S%d_bcores_allw_%d' % (S, m)])
+    assert prj.constant_rows_from_host > 0
+
+
 def _load_example():
     import importlib.util
     import os

@@ -620,3 +620,63 @@ def test_abi_null_sweep_with_a_live_context():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, os.path.join(root, 'tests', 'abi_null_sweep.py')], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and 'live-context checks ok' in res.stdout and 'swept 7' in res.stdout, res.stdout + res.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ round 5: constant rows evaluated on the host
+def test_constant_rows_take_host_evaluated_values(bc, monkeypatch):
+    """On a host whose NumPy does not evaluate np.exp with the routine csrc/bc_np_exp.h restates, the projector evaluates
+    the constants of all-zero-feature rows itself (LinearRegression.host_constants: the reference's expression,
+    model_neurlinr.py:102-110) and hands (y, value) pairs to K1 (bc_ctx_set_constant_row_values).  The probe is forced to
+    "not the restated NumPy" here: the host route must give the reference's rows bit for bit (this host's NumPy IS the
+    reference's), through host arrays, resident rows and the store-free column sums -- and the kernel must really take its
+    constants from the table (a table entry moved by one ulp moves the device row with it)."""
+    import ctypes as C
+    from beta_cores_amd.util import numpy_bits
+    from beta_cores_amd import _native as N
+    from beta_cores_amd.device import _ptr
+    monkeypatch.setattr(numpy_bits, '_cached', False)
+    monkeypatch.setattr(numpy_bits, '_warned', set())
+    rng = np.random.RandomState(14)
+    n, d, S = 5000, 6, 100
+    za = np.array([0, 5, 128, 129, 4095, 4999])
+    Z = rng.randn(n, d + 1)
+    Z[za, :d] = 0.
+    Z[129, d] = Z[5, d]                                   # two constant rows with the same y share a table entry
+    th = rng.randn(S, d) * 0.4
+    model = bc.likelihoods.LinearRegression(1.7)
+    with pytest.warns(UserWarning, match='evaluated on the host'):
+        prj = bc.DeviceBetaProjector(fixed(th), S, model)
+    rawb = M.linreg_beta_lik(Z, th, 0.2, 1.7)
+    refb = rawb - rawb.mean(axis=1)[:, None]
+    for src in (Z, bc.DeviceData(Z)):
+        devb = prj.project_f(src, 0.2)
+        assert prj.constant_rows_from_host == 5           # six rows, five distinct y
+        hostb = np.asarray(devb)
+        assert np.array_equal(hostb[za], refb[za])
+        assert np.array_equal(devb.norms() > 0, np.sqrt((refb ** 2).sum(axis=1)) > 0)
+        np.testing.assert_array_equal(prj.colsum(src, beta=0.2), devb.colsum())
+    # the plain log-likelihood needs no table (no transcendental in its constant)
+    prj.project(Z)
+    # ... and the kernel reads the table: nudge one entry by an ulp (inside the 1e-13 agreement guard) and the row follows
+    params = np.ascontiguousarray(model.params(beta=0.2))
+    keys = np.unique(Z[za, d])
+    vals = model.host_constants(keys, 0.2)
+    vals2 = vals.copy()
+    k = int(np.searchsorted(keys, Z[128, d]))
+    vals2[k] = np.nextafter(vals[k], np.inf)
+    monkeypatch.setattr(prj, '_host_constants', False)    # keep the projector from restoring the table
+    N.call('bc_ctx_set_constant_row_values', prj.ctx.h, int(model.beta_model_id), _ptr(params), int(params.shape[0]),
+           _ptr(keys), _ptr(vals2), int(keys.size))
+    try:
+        row = np.asarray(prj.project_f(Z, 0.2))[128]
+        c2 = vals2[k]
+        assert np.all(row == c2 - np.full(S, c2).mean()) and not np.array_equal(row, refb[128])
+        # other parameters than the table was made for: not used
+        row_other = np.asarray(prj.project_f(Z, 0.3))[128]
+        rawo = M.linreg_beta_lik(Z[128:129], th, 0.3, 1.7)
+        assert np.array_equal(row_other, (rawo - rawo.mean(axis=1)[:, None])[0])      # (the library's restated exp: an AVX-512 host)
+    finally:
+        N.call('bc_ctx_set_constant_row_values', prj.ctx.h, 0, None, 0, None, None, 0)
+    with pytest.raises(ValueError):                       # keys must be strictly increasing
+        N.call('bc_ctx_set_constant_row_values', prj.ctx.h, int(model.beta_model_id), _ptr(params), int(params.shape[0]),
+               _ptr(keys[::-1].copy()), _ptr(vals), int(keys.size))
