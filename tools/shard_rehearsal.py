@@ -4,8 +4,8 @@
 bench.py runs under torch.distributed.run with ONE rank and BC_FORCE_EXCHANGE=1, so that the step takes the multi-rank route
 (sweep -> k_rescore -> ncclAllGather of one (S+4)-double record over the library's own RCCL communicator -> replicated
 finish) on the row count one of G GPUs would hold at N = 10M: what it shows is the FIXED cost of a shard step (everything but
-the sweep's stream), which bounds strong scaling before any real link latency is paid.  A/B: BC_I8_QV=0 makes every sweep
-block quantise the sweep vector in its own prologue again (round 3's behaviour).
+the sweep's stream), which bounds strong scaling before any real link latency is paid.  A/B (round 5): BC_I8_BLKLIST=0 makes the
+rescoring stage walk blocks -> tiles -> pairs again instead of reading the sweep blocks' own candidate lists (round 4's behaviour).
 
   python tools/shard_rehearsal.py [out.json]      (on the GPU box; ~1 minute)
 """
@@ -18,11 +18,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(rows, qv, steps=300, warmup=120):
+def run(rows, lists, steps=300, warmup=120):
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, BC_FORCE_EXCHANGE='1', BC_I8_QV=str(qv), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, BC_FORCE_EXCHANGE='1', BC_I8_BLKLIST=str(lists), HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--rows', str(rows), '--steps', str(steps),
            '--warmup', str(warmup), '--no-cpu', '--no-extra', '--no-host', '--detail', '/dev/null']
@@ -32,7 +32,7 @@ def run(rows, qv, steps=300, warmup=120):
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     st = d['step_stages']
-    return {'rows': rows, 'quantised_in_finish': bool(qv), 'us_per_step': round(1e3 * d['ms_per_step'], 2),
+    return {'rows': rows, 'block_candidate_lists': bool(lists), 'us_per_step': round(1e3 * d['ms_per_step'], 2),
             'sweep_launch_us (HIP events, timed pass)': round(1e3 * d['roofline']['avg_launch_ms'], 2),
             'stage_us (separate instrumented pass: an event pair per stage costs stream time)':
                 {k: (None if st[k] is None else round(1e3 * st[k], 2)) for k in ('sweep', 'rescore', 'gather', 'finish')},
@@ -41,7 +41,7 @@ def run(rows, qv, steps=300, warmup=120):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r04_shard_rehearsal.json')
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r05_shard_rehearsal.json')
     only = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (2, 4, 8)
     sys.path.insert(0, ROOT)
     res = {'what': 'REHEARSAL on ONE GPU, one rank, RCCL all-gather with world = 1: the per-step fixed cost of a row shard; not a scaling curve',
@@ -50,8 +50,8 @@ def main():
     for G, rows in ((2, 5_000_064), (4, 2_500_096), (8, 1_250_048)):
         if G not in only:
             continue
-        for qv in (1, 0, 1):
-            r = run(rows, qv)
+        for lists in (1, 0, 1):
+            r = run(rows, lists)
             r['shard_of_G'] = G
             res['runs'].append(r)
             sys.stderr.write(json.dumps(r) + '\n')
