@@ -409,8 +409,11 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
     p->rowq = (bc_hq2*)(base + o_rq);
     p->tile_cand = (float2*)(base + o_tc);
     p->tile_ncand = (int*)(base + o_tn);
-    static const int no_lists = getenv("BC_I8_BLKLIST") ? atoi(getenv("BC_I8_BLKLIST")) == 0 : 0;      // (A/B: 0 = walk tiles as before)
-    if (!no_lists) {
+    // the sweep blocks' own candidate lists (round 5): OPT-IN, BC_I8_BLKLIST=1.  They take the tile walk out of the rescoring
+    // stage (-2k of its 20k cycles) and put ~0.7 us of list building at the end of every sweep block: no gain at N = 10M
+    // (5 587-5 655 against 5 640-5 671 it/s) nor at a 1.25M-row shard (50.7-50.9 against 50.2 us per step), profiles/r05_notes.md
+    const char* lenv = getenv("BC_I8_BLKLIST");
+    if (lenv && atoi(lenv) != 0) {
       p->blk_cand = (int2*)(base + o_bc);
       p->blk_nc = (int*)(base + o_bn);
     }

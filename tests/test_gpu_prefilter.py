@@ -12,14 +12,19 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[32, 16, 8, 'bb'])
+@pytest.fixture(params=[32, 16, 8, 'bb', 'lists'])
 def prec(request, monkeypatch):
     """Storage precision of the mirror; 'bb' = the int8 mirror swept in the branch-and-bound form (csrc/bc_prefilter_bb.h:
-    the sweep blocks rescore their candidates themselves), forced on for these small inputs -- 8 forces the two-pass form."""
+    the sweep blocks rescore their candidates themselves), forced on for these small inputs -- 8 forces the two-pass form;
+    'lists' = two-pass with the sweep blocks' own candidate lists (BC_I8_BLKLIST=1: the rescoring stage skips the tile walk)."""
     if request.param == 'bb':
         monkeypatch.setenv('BC_I8_BB', '1')
         return 8
     monkeypatch.setenv('BC_I8_BB', '0')
+    if request.param == 'lists':
+        monkeypatch.setenv('BC_I8_BLKLIST', '1')
+        return 8
+    monkeypatch.setenv('BC_I8_BLKLIST', '0')
     return request.param
 
 

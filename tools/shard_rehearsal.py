@@ -4,8 +4,8 @@
 bench.py runs under torch.distributed.run with ONE rank and BC_FORCE_EXCHANGE=1, so that the step takes the multi-rank route
 (sweep -> k_rescore -> ncclAllGather of one (S+4)-double record over the library's own RCCL communicator -> replicated
 finish) on the row count one of G GPUs would hold at N = 10M: what it shows is the FIXED cost of a shard step (everything but
-the sweep's stream), which bounds strong scaling before any real link latency is paid.  A/B (round 5): BC_I8_BLKLIST=0 makes the
-rescoring stage walk blocks -> tiles -> pairs again instead of reading the sweep blocks' own candidate lists (round 4's behaviour).
+the sweep's stream), which bounds strong scaling before any real link latency is paid.  A/B (round 5): BC_I8_BLKLIST=1 lets the
+rescoring stage read the sweep blocks' own candidate lists instead of walking blocks -> tiles -> pairs (the default).
 
   python tools/shard_rehearsal.py [out.json]      (on the GPU box; ~1 minute)
 """
