@@ -35,6 +35,9 @@
 #endif
 #define BC_IMAXG 320     // k-groups the digit table holds: S <= 1280
 #define BC_IFLUSH 32     // tiles a wave parks in LDS before it writes their results out
+#ifndef BC_I8_DEPTH
+#define BC_I8_DEPTH 1    // batches requested ahead of the one being consumed (2: tools/build_variant.sh experiment, S >= 37 only)
+#endif
 typedef int bc_i4 __attribute__((ext_vector_type(4)));
 typedef _Float16 bc_hq8 __attribute__((ext_vector_type(8)));   // ... of a lane's four rows
 
@@ -254,11 +257,19 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
     long long t = (long long)blockIdx.x * 4 + wave;
     bc_i4 x[U], y[U];
     bc_hq8 rq = {(_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f, (_Float16)0.f, (_Float16)-1.f};
+#if BC_I8_DEPTH == 2
+    bc_i4 z[U];                                        // two batches ahead (needs SP4 >= 2 U: the launcher checks)
+    bc_hq8 rq_n = rq;
+#endif
     if (t < a.ptiles) {
       const bc_i4* __restrict__ p0 = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)t * SP4 * BC_ITILE) + lane;
 #pragma unroll
       for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p0 + (size_t)u * 64);
       rq = reinterpret_cast<const bc_hq8*>(a.rowq + t * BC_ITILE)[lane];
+#if BC_I8_DEPTH == 2
+#pragma unroll
+      for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p0 + (size_t)(U + u) * 64);
+#endif
     }
     // ---- prologue.  With a.qv (the step kernel that produced v left its digits behind, bc_i8_quant.h): copy 1.3 KB into
     // LDS, one barrier.  Without (standalone argmax sweeps): quantise v here, every block the same tiny job.
@@ -333,6 +344,20 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         for (int c = 0; c < NV; ++c) acc[j][c] = 0;
       const bc_hq8 cq = rq;                            // this tile's (scale, delta) x 4 rows
       for (int g0 = 0; g0 < SP4; g0 += U) {
+#if BC_I8_DEPTH == 2
+        // two batches ahead: batch g0 / U + 2 of this tile, or batch 0 / 1 of the wave's next tile (with its row constants)
+        const int nb = g0 + 2 * U;
+        if (nb < SP4) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) z[u] = __builtin_nontemporal_load(p + (size_t)(nb + u) * 64);
+        } else if (t + tstride < a.ptiles) {
+          const long long tn = t + tstride;
+          const bc_i4* __restrict__ pn = reinterpret_cast<const bc_i4*>(a.u8 + (size_t)tn * SP4 * BC_ITILE) + lane;
+#pragma unroll
+          for (int u = 0; u < U; ++u) z[u] = __builtin_nontemporal_load(pn + (size_t)(nb - SP4 + u) * 64);
+          if (nb == SP4) rq_n = reinterpret_cast<const bc_hq8*>(a.rowq + tn * BC_ITILE)[lane];
+        }
+#else
         const bool more = g0 + U < SP4;
         if (more) {
 #pragma unroll
@@ -344,6 +369,7 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
           for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(pn + (size_t)u * 64);
           rq = reinterpret_cast<const bc_hq8*>(a.rowq + tn * BC_ITILE)[lane];
         }
+#endif
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bc_i4 dg = *reinterpret_cast<const bc_i4*>(&dig[g0 + u][0]);
@@ -354,7 +380,14 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = y[u];        // (after the last batch: the next tile's first batch, if any)
+#if BC_I8_DEPTH == 2
+#pragma unroll
+        for (int u = 0; u < U; ++u) y[u] = z[u];
+#endif
       }
+#if BC_I8_DEPTH == 2
+      rq = rq_n;
+#endif
       // ---- per-row intervals (4 rows per lane), fp32 with explicit slack (bc_score_interval_f32)
       const float sc[4] = {(float)cq[0], (float)cq[2], (float)cq[4], (float)cq[6]};
       const float dl[4] = {(float)cq[1], (float)cq[3], (float)cq[5], (float)cq[7]};
