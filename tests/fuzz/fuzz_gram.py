@@ -17,10 +17,12 @@ cases = bad = 0
 while time.time() < t_end:
     d = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300]))
     n = int(10 ** rng.uniform(0, 4.2))
+    mode = rng.randint(4)
+    if rng.rand() < 0.12:            # the LDS-DMA kernel (k_gram_dma): one unweighted tile, rows of >= 128 doubles, >= 4096 rows
+        d, n, mode = int(rng.choice([127, 128])), int(rng.randint(4096, 40000)), 0
     if n * (d + 1) > 6_000_000:
         continue
     Z = rng.randn(n, d + 1) * 10.0 ** rng.uniform(-2, 2)
-    mode = rng.randint(4)
     w = None if mode == 0 else rng.rand(n) * 3.
     if mode == 2:
         w[rng.rand(n) < 0.5] = 0.

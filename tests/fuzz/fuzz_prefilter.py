@@ -1,4 +1,4 @@
-"""Fuzz (not collected by pytest): random problems through the int8 / fp16 / fp32 pre-filter mirrors against the fp64
+"""Fuzz (not collected by pytest): random problems through the int8 (three forms) / fp16 / fp32 pre-filter mirrors against the fp64
 sweep -- traces, weights and errors must be identical.  Usage: python tests/fuzz/fuzz_prefilter.py SEED SECONDS (needs a GPU)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
@@ -24,7 +24,13 @@ def make(rng, n, s, kind):
         phi = rng.randn(n, s) * 10.0 ** rng.uniform(-5, 0, size=(n, s))
     return phi - phi.mean(axis=1)[:, None] if s > 1 else phi
 
+FORMS = {8: ('0', '0'), 'lists': ('0', '1'), 'bb': ('1', '0')}       # int8 mirror: two-pass / + block lists / branch-and-bound
+
+
 def run(cls, phi, steps, pref):
+    if pref in FORMS:
+        os.environ['BC_I8_BB'], os.environ['BC_I8_BLKLIST'] = FORMS[pref]
+        pref = 8
     os.environ['BC_PREFILTER'] = str(pref)
     sv = cls(phi.T, phi.sum(axis=0), allow_zero_rows=True) if cls is bc.snnls.GIGA else cls(phi.T, phi.sum(axis=0))
     sv.build(steps)
@@ -47,13 +53,13 @@ while time.time() < t_end:
         ref = run(cls, phi, steps, 0)
     except ValueError:
         continue
-    for pref in (8, 16, 32):
+    for pref in (8, 'lists', 'bb', 16, 32):
         got = run(cls, phi, steps, pref)
         ok = all(np.array_equal(a, b) for a, b in zip(ref[0], got[0])) and np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2]) and ref[3] == got[3]
         falls += got[4][2]
         if not ok:
             bad += 1
-            print('MISMATCH n=%d s=%d kind=%d alg=%s steps=%d pref=%d' % (n, s, kind, cls.__name__, steps, pref), ref[0][0][:10], got[0][0][:10])
+            print('MISMATCH n=%d s=%d kind=%d alg=%s steps=%d pref=%s' % (n, s, kind, cls.__name__, steps, pref), ref[0][0][:10], got[0][0][:10])
     cases += 1
-print('fuzz: %d problems x 3 mirrors, %d mismatches, %d fp64 fallbacks' % (cases, bad, falls))
+print('fuzz: %d problems x 5 forms (int8 two-pass, + block lists, branch-and-bound; fp16; fp32), %d mismatches, %d fp64 fallbacks' % (cases, bad, falls))
 sys.exit(1 if bad else 0)

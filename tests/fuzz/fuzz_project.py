@@ -36,6 +36,8 @@ while time.time() < t_end:
         model = bc.likelihoods.GaussianLocation(Si, ld); Z = rng.randn(n, d)
         ll = lambda x, t: M.gauss_loglik(x, t, Si, ld); bl = lambda x, t, b: M.gauss_beta_lik(x, t, b, Si, ld)
     beta = None if rng.rand() < 0.4 else float(rng.choice([0.1, 0.3, 0.7]))
+    if beta is not None and kind == 1 and rng.rand() < 0.5:      # the logistic beta-likelihood's power-table body over its whole range
+        beta = float(rng.choice([0.01, 0.05, 1.0, 2.0, 8.0, 30.0]))
     prj = bc.DeviceBetaProjector(lambda k, w, p: th, s, model)
     dd = bc.DeviceData(Z)
     v = ll(Z, th) if beta is None else bl(Z, th, beta)       # un-centred model values: their maximum sets the tolerance
