@@ -221,15 +221,17 @@ struct RescorePre {
 
 __device__ __forceinline__ RescorePre bc_rescore_prefetch(const RescoreArgs& a) {
   RescorePre p;
+  // (clamped indices instead of branches: every thread loads, nothing separates the requests -- with the loads inside
+  // `if`s the compiler waited for the first bound before it issued the rest)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = threadIdx.x + q * 256;
-    p.l[q] = -INFINITY;
-    p.u[q] = -INFINITY;
-    if (threadIdx.x < 256 && i < a.nblk) {
-      p.l[q] = a.blk_l[i];
-      p.u[q] = a.blk_u[i];
-    }
+    const bool ok = threadIdx.x < 256 && i < a.nblk;
+    const unsigned ic = ok ? (unsigned)i : 0u;
+    const double l = a.blk_l[ic];
+    const float u = a.blk_u[ic];
+    p.l[q] = ok ? l : -INFINITY;
+    p.u[q] = ok ? u : -INFINITY;
   }
 #pragma unroll
   for (int q = 0; q < BC_RS_BLK_PER; ++q) {

@@ -297,13 +297,17 @@ def test_config4_all_rows_vs_oracle(env):
 
 # ------------------------------------------------------------------ the beta-Cores loop itself at configs[1] / configs[2] size
 _BCORES_ORACLE = {}
-_BCORES_CFGS = ['linreg_1M_64', 'logistic_1M_128', 'logistic_1M_128_laplace']
+_BCORES_CFGS = ['linreg_1M_64', 'logistic_1M_128', 'logistic_1M_128_laplace', 'svi_linreg_1M_64', 'svi_logistic_1M_128']
 
 
 def _bcores_case(bc, torch, cfg):
     """Data, beta-likelihood and sampler of one stated-size BetaCoreset case.  The samplers are host closures
     (projector.py:37,66 calls them with the <= M coreset rows) and the SAME closure serves the oracle and the device run."""
     S, beta, opt_itrs = 100, 0.1, 3
+    if cfg.startswith('svi_'):            # SparseVI on the plain log-likelihood (sparsevi.py:72-136): same data and samplers
+        Z, S, _, opt_itrs, kind, sampler, _ = _bcores_case(bc, torch, 'linreg_1M_64' if 'linreg' in cfg else 'logistic_1M_128')
+        ll = (lambda z, t: M.linreg_loglik(z, t, 1.0)) if kind == 'linreg' else M.logistic_loglik
+        return Z, S, None, opt_itrs, kind, sampler, ll
     if cfg == 'linreg_1M_64':
         n, d, kind = 1_000_000, 64, 'linreg'
         Z, thstar = gen(torch, n, d, 20, kind)
@@ -339,7 +343,8 @@ def _bcores_case(bc, torch, cfg):
 @pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('cfg', _BCORES_CFGS)
 def test_beta_coreset_steps_at_stated_size_vs_oracle(env, cfg, fused):
-    """`BetaCoreset.build(2, 2)` with `opt_itrs = 3` at BASELINE configs[1] (N = 1M, D = 64, beta-likelihood of the linear
+    """(`svi_*`: the same with `SparseVICoreset` on the plain log-likelihood, sparsevi.py:72-136.)
+    `BetaCoreset.build(2, 2)` with `opt_itrs = 3` at BASELINE configs[1] (N = 1M, D = 64, beta-likelihood of the linear
     regression, model_neurlinr.py:102-110; Theta follows the coreset posterior) and configs[2] (N = 1M, D = 128, logistic
     beta-likelihood, model_lr.py:81-86; once with a fixed Theta, once with the Laplace sampler) against
     `oracle.coreset_ref.RefGreedyVI` (bcores.py:74-150) on ALL rows (its K1 in row chunks on the host, ~20-40 s per case): the
@@ -357,7 +362,7 @@ def test_beta_coreset_steps_at_stated_size_vs_oracle(env, cfg, fused):
 
         def one(args):
             with np.errstate(over='ignore'):
-                return C.project_f(blik, args[0], args[1], beta)
+                return C.project(blik, args[0], args[1]) if beta is None else C.project_f(blik, args[0], args[1], beta)
 
         def proj(pts, th):                       # rows are independent (projector.py:53-55 centres per row)
             if pts.shape[0] <= CH:
@@ -377,8 +382,12 @@ def test_beta_coreset_steps_at_stated_size_vs_oracle(env, cfg, fused):
         sampler._mode = None
     data = bc.DeviceData.from_torch(Z, ctx=ctx)
     model = bc.likelihoods.LogisticRegression() if kind == 'logistic' else bc.likelihoods.LinearRegression(1.0)
-    alg = bc.BetaCoreset(data, bc.DeviceBetaProjector(sampler, S, model, ctx=ctx), opt_itrs=opt_itrs, step_sched=sched, beta=beta,
-                         learn_beta=False, fused_gradient=fused)
+    if beta is None:
+        alg = bc.SparseVICoreset(data, bc.DeviceProjector(sampler, S, model, ctx=ctx), opt_itrs=opt_itrs, step_sched=sched,
+                                 fused_gradient=fused)
+    else:
+        alg = bc.BetaCoreset(data, bc.DeviceBetaProjector(sampler, S, model, ctx=ctx), opt_itrs=opt_itrs, step_sched=sched, beta=beta,
+                             learn_beta=False, fused_gradient=fused)
     for m in range(2):
         alg.build(1, m + 1)
         ridx, rw = _BCORES_ORACLE[cfg][m]
