@@ -280,8 +280,7 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
   }
   // the sweep blocks left their own candidate lists (int8 mirror): they came in with the first round of loads
   const bool lists = a.blk_nc != nullptr && a.nblk <= BC_RS_BLK_PER * (int)blockDim.x;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) lmax = fmax(lmax, __shfl_down(lmax, d, BC_WAVE));
+  lmax = bc_wave_max_all(lmax);                // (DPP rotations + readlane: the six ds_bpermute steps of a __shfl_down tree cost ~0.7k cycles)
   if (lane == 0) sv[wave] = lmax;
   if (threadIdx.x == 0) { cnt = 0; tcnt = 0; bcnt = 0; ocnt = 0; }
   __syncthreads();

@@ -342,8 +342,10 @@ __device__ void dev_pick(const SnnlsDev& P, SnnlsState& S, double* red) {
       S.sel_score = valid ? rec[0] : -INFINITY;
       if (valid) S.sel_norm = rec[2];
     }
-    if (valid)
-      for (int k = threadIdx.x; k < s; k += blockDim.x) P.xf[k] = rec[BC_REC_HDR + k];
+    if (P.xf != rec + BC_REC_HDR) {                 // (block-uniform; the fused kernel aliases the two)
+      if (valid)
+        for (int k = threadIdx.x; k < s; k += blockDim.x) P.xf[k] = rec[BC_REC_HDR + k];
+    }
     __syncthreads();
     return;
   }
@@ -805,6 +807,9 @@ __global__ __launch_bounds__(BC_FIN_THREADS) void k_step_finish_pf(SnnlsDev P0, 
   P.idx = l_idx;
   if (nrec) P.cand_all = l_rec;
   if (RS) { P.world = 1; P.fuse_winner = 0; }
+  // one record, already in LDS (the rescoring stage of this launch wrote it): its column IS the picked column -- dev_pick
+  // then has nothing to copy (and no barrier to pass)
+  if (RS && ALG != BC_ALG_OMP) P.xf = l_rec + BC_REC_HDR;
   FSTAMP(1);
   if (S.reached_limit || S.pf_overflow) return;      // snnls.py:32-34 / :73-74; a pending exact redo consumes nothing
   bool pf_ovf = false;
