@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BC_BB_THREADS, BC_BB_MINWAVES) void k_sweep_i8_bb(I
         ++nres;
         const long long r = row;
         const double nr = b.norms[r];
-        const double sc = bc_exact_score_wave<MODE>(b.tiles, a.v, r, S, nr, a.post_div, strip, currow);
+        const double sc = bc_exact_score_wave<MODE, 4>(b.tiles, a.v, r, S, nr, a.post_div, strip, currow);      // (4: this kernel's register budget is the stream's)
         const long long gi = b.row_offset + r;
         if (bc_better(sc, gi, bv, bi)) {
           bv = sc; bi = gi; bnorm = nr;

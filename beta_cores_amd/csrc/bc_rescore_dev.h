@@ -131,7 +131,10 @@ __device__ __forceinline__ double bc_exact_score(const double* __restrict__ tile
 // With a handful of candidates this replaces four dependent load batches and a one-lane chain by one round trip and
 // a pipelined chain.  (Wave-private strip: LDS serves a wave's requests in order, the wavefront-scope fences only
 // keep the compiler from reordering.)
-template <int MODE>
+// CH: pairs fetched from the strip ahead of the fmas that consume them (registers: 4 CH dwords).  With 8 (a `#pragma unroll`)
+// the chain ran at 33 cycles per step -- the LDS latency showed through every eighth step; entries S..255 of the strip are
+// zeros, so the trip count is rounded up to a multiple of CH without a branch (fma(0, 0, acc) == acc).
+template <int MODE, int CH = 16>
 __device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__ tiles, const double* __restrict__ v, long long r,
                                                       int S, double nr, double post_div, double* strip /* [2][256][2] */,
                                                       double* rowcopy = nullptr /* [S]: the row, if the caller wants it */) {
@@ -167,10 +170,13 @@ __device__ __forceinline__ double bc_exact_score_wave(const double* __restrict__
     __builtin_amdgcn_wave_barrier();
     FSTAMP(14);
     const int n = (S - base) < 256 ? (S - base) : 256;
-#pragma unroll 8
-    for (int kk = 0; kk < n; ++kk) {
-      const double2 xv = mine[kk];
-      acc = fma(xv.x, xv.y, acc);
+    const int npad = (n + CH - 1) / CH * CH;              // <= 256: CH divides 256
+    for (int k0 = 0; k0 < npad; k0 += CH) {
+      double2 xv[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) xv[u] = mine[k0 + u];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) acc = fma(xv[u].x, xv[u].y, acc);
     }
   }
   if (MODE == 0) {
@@ -257,7 +263,6 @@ template <int MODE>
 __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long n_rows, double* __restrict__ rec, const RescorePre& mine) {
   __shared__ double sv[16];
   __shared__ long long si[16];
-  __shared__ long long win;
   __shared__ int cnt, tcnt, bcnt, ocnt;
   __shared__ int tlist[1024];
   __shared__ int blist[64];                  // sweep blocks whose maximum upper bound reaches Lmax
@@ -266,7 +271,6 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
   __shared__ double currow[4][256];          // ... and the row it is scoring
   __shared__ double bestrow[4][256];         // the row of each scoring wave's best candidate (S <= 256): the record's column
   __shared__ double snorm[16];
-  __shared__ int swave;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   bool overflow = false;
   double lmax = -INFINITY;
@@ -593,24 +597,30 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
   }
   FSTAMP(13);
   if (!keep_rows) bc_wave_argmax(bv, bi);     // (keep_rows: every lane of a scoring wave already holds the wave's best)
-  __syncthreads();
+  // (sv / si were last read right after the Lmax barrier, several barriers ago: no barrier needed before they are rewritten)
   if (lane == 0) { sv[wave] = bv; si[wave] = bi; snorm[wave] = bnorm; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int bw = 0;
+  // every thread combines the (at most eight) wave results itself -- the same loop, the same order, hence the same winner in
+  // every thread -- instead of thread 0 doing it between two more barriers
+  int bw = 0;
+  {
+    double cv = sv[0];
+    long long ci = si[0];
     const int nsc = (count <= 32) ? (nw < 4 ? nw : 4) : nw;      // a handful of candidates: only waves 0..3 scored
     for (int w = 1; w < nsc; ++w)
-      if (bc_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; bw = w; }
-    const bool valid = bi != LLONG_MAX;
+      if (bc_better(sv[w], si[w], cv, ci)) { cv = sv[w]; ci = si[w]; bw = w; }
+    bv = cv;
+    bi = ci;
+  }
+  const bool valid = bi != LLONG_MAX;
+  if (threadIdx.x == 0) {
     rec[0] = bv;
     reinterpret_cast<long long*>(rec)[1] = valid ? bi : -1;
     rec[2] = valid ? (keep_rows ? snorm[bw] : a.norms[bi - a.row_offset]) : 0.0;
     rec[3] = valid ? 1.0 : 0.0;
-    win = valid ? bi - a.row_offset : -1;
-    swave = bw;
   }
-  __syncthreads();
-  const long long r = win;
+  const long long r = valid ? bi - a.row_offset : -1;
+  const int swave = bw;
   if (keep_rows && r >= 0) {
     const double* src = bestrow[swave];
     for (int k = threadIdx.x; k < a.s; k += blockDim.x) rec[BC_REC_HDR + k] = src[k];
