@@ -13,7 +13,10 @@ record holds all of it; the evidence sits inside the two objects that record kee
   roofline.kernels    one entry per timed kernel (avg ms by HIP events, GB / GF per launch, fractions of the HBM / fp64-MFMA peaks)
   roofline.loops      the beta-Cores gradient loops of configs 2, 3 (logistic + Laplace sampler) and 4, per-phase split
   roofline.from_host  ndarray -> resident rows / first iteration / M = 100 coreset (upload + K1 pipelined); never part of `value`
-  cpu_baseline        the NumPy oracle on the same host: greedy loop on ALL rows, and the gradient loops (`loops`)
+  roofline.fp64_formulation   SURVEY 8(d)'s kernel (fp64 Phi streamed once per step) timed in the same run: {ms, frac, it_s, GB, same_sel}
+  ms_per_step_M100    steps 2..100 of the coreset built in the from_host leg (list lengths 1..100), wall clock per step
+  cpu_baseline        the NumPy oracle on the same host: greedy loop on ALL rows (all BLAS threads, and `one_thread`), the host's
+                      CPU model string, and the gradient loops (`loops`)
 Everything verbose (full roofline objects, phase timers, solver_init parts) goes to --detail FILE, or to one stderr
 line tagged BENCH_DETAIL.
 
