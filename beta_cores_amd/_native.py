@@ -80,6 +80,7 @@ _SIGNATURES = {
     'bc_snnls_prefilter_form': [vp, c_ip],
     'bc_snnls_prefilter_fallbacks': [vp, C.POINTER(C.c_int64)],
     'bc_snnls_prefilter_stats': [vp, c_i64p, c_i64p, c_i64p],
+    'bc_snnls_prefilter_levels': [vp, c_i64p, c_i64p, c_i64p],
     'bc_snnls_bind_exchange': [vp, C.c_int, vp, vp],
     'bc_snnls_record_doubles': [vp, c_i32p],
     'bc_snnls_build_begin': [vp, C.c_int],

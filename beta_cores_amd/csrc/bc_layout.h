@@ -53,6 +53,29 @@ BC_LAY long long bc_lay_i8_src_row(long long r, long long n_rows) {
 #endif
 }
 
+// ---- two-level pre-filter (bc_prefilter_i4.h)
+//   4-bit mirror  tiles of 256 rows, inside a tile [SP8][256] dwords (one dword = 8 consecutive samples of one row as signed
+//                 nibbles, sample 8g+j in bits 4j..4j+3); SP8 = ceil(S/8) rounded up to a multiple of the sweep's batch U;
+//                 per row one 16-bit word (scale code | delta code << 8): [ptiles*256]
+//   int8 records  row-major copy of the int8 mirror for the second level's gather: record of RB bytes per row,
+//                 ceil(S/4) dwords of digits, zeros, and the row's (scale, delta) halfs in its LAST dword; RB a multiple of
+//                 128 so that a row is one (or a few whole) cache lines
+BC_LAY int bc_lay_i4_groups(int S) { return (S + 7) / 8; }
+BC_LAY int bc_lay_i4_sp8(int S, int U) { return (bc_lay_i4_groups(S) + U - 1) / U * U; }
+// the batch size (loads a wave keeps in flight per buffer) with the least padding among the instantiated ones; ties: larger
+BC_LAY int bc_lay_i4_batch(int S) {
+  const int cand[5] = {13, 8, 7, 6, 5};
+  int best = cand[0];
+  for (int i = 1; i < 5; ++i)
+    if (bc_lay_i4_sp8(S, cand[i]) < bc_lay_i4_sp8(S, best)) best = cand[i];
+  return best;
+}
+BC_LAY size_t bc_lay_i4_words(long long ptiles, int sp8) { return (size_t)ptiles * (size_t)sp8 * BC_LAY_ITILE; }
+BC_LAY size_t bc_lay_i4_word(long long ptile, int g, int row_in_tile, int sp8) {
+  return (size_t)ptile * (size_t)sp8 * BC_LAY_ITILE + (size_t)g * BC_LAY_ITILE + (size_t)row_in_tile;
+}
+BC_LAY int bc_lay_r8_bytes(int S) { return (4 * ((S + 3) / 4) + 4 + 127) / 128 * 128; }
+
 BC_LAY long long bc_lay_chunk_unit(int rgrid) { return rgrid > 0 ? (long long)rgrid * 8 * 32 : (long long)BC_LAY_TILE * 512; }
 BC_LAY long long bc_lay_chunk_rows(int dz, long long unit, long long forced) {
   long long rows = (((long long)128 << 20) / ((long long)dz * 8) + unit - 1) / unit * unit;

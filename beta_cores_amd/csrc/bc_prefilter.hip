@@ -60,6 +60,31 @@ struct bc_pref {
   unsigned long long* bb_theta = nullptr;
   BbRec* bb_rec = nullptr;         // [grid]
   double* bb_col = nullptr;        // [grid][S]
+  // int8, two-level form (bc_prefilter_i4.h): a 4-bit first level in front of a row-major copy of the int8 mirror
+  bool two = false;
+  int i4_u = 13;                   // loads per batch of the 4-bit sweep (template parameter)
+  int sp8 = 0, g4 = 0, rb = 0;     // k-groups of 8 stored per tile; ceil(S / 4); bytes of an int8 row record
+  int* u4 = nullptr;               // [ptiles][sp8][256]
+  unsigned short* rowq4 = nullptr; // [ptiles*256]
+  unsigned char* r8 = nullptr;     // [ptiles*256][rb]
+  const int* qv4 = nullptr;        // the owner's sweep vector in 4-bit digits (bc_i4_quant.h), or nullptr
+  long long* hot = nullptr;        // [BC_I4_SEEDS + BC_I4_HOT] seeds
+  unsigned l1_seq = 0;             // two-level sweeps launched
+  // the host's watch over the first level (bc_pref_adapt): on data whose top scores the 4-bit bounds do not separate from the
+  // bulk it passes on a large share of the rows, and the one-level int8 sweep is the faster form
+  bool two_active = true;
+  unsigned chk_l1 = 0;             // l1_seq and the device's row total at the last check
+  unsigned long long chk_rows = 0;
+  long long int8_since = 0;        // one-level sweeps since the two-level form was put aside
+  long long reprobe = 256;         // ... after which it is tried again (doubled every time it fails)
+  double last_share = -1.;         // share of the rows passed on, last window (diagnostic)
+  long long sweeps_launched = 0;   // any form: the first sweep has no seeds and runs as the plain int8 sweep
+  int grid1 = 1;
+  double* l2_blk_l = nullptr;      // [grid1] the two-level sweep's block lists (the int8 sweep keeps its own)
+  float* l2_blk_u = nullptr;
+  int2* l2_blk_cand = nullptr;
+  int* l2_blk_nc = nullptr;
+  int2* spill = nullptr;           // [cap] pairs of blocks with more than BC_BLK_NC rows in play
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
   int* ctrl = nullptr;        // [1] the last rescoring overflowed, [3] overflows so far,
                               // [4..5] sweeps so far (u64), [6..7] candidates rescored so far (u64)
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(256) void k_sweep_f32(PrefArgs a) {
 
 #include "bc_prefilter_i8.h"
 #include "bc_prefilter_bb.h"
+#include "bc_prefilter_i4.h"
 
 // ---- fp16 variant.  Tile = 512 rows, [S][512] halfs: one sample of a tile = 1 KiB = 64 lanes x 8 halfs.
 typedef _Float16 bc_h8 __attribute__((ext_vector_type(8)));
@@ -345,6 +371,8 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   bc_pref* p = new bc_pref();
   p->ctx = ctx;
   p->phi = phi;
+  bool want_two = prec == 4;
+  if (prec == 4) prec = 8;
   p->prec = prec == 16 ? 16 : (prec == 8 ? 8 : 32);
   if (p->prec == 8 && (phi->s + 3) / 4 > BC_IMAXG - BC_IU) p->prec = 16;      // the digit table of k_sweep_i8 holds S <= ~1260
   p->ptile = p->prec == 16 ? BC_HTILE : (p->prec == 8 ? BC_ITILE : BC_PTILE);
@@ -379,6 +407,16 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
       if (p->grid < 1) p->grid = 1;
     }
   }
+  // two-level form: S <= 256 (digit tables in LDS), local rows as 32-bit integers, not together with the branch-and-bound sweep
+  p->two = want_two && p->prec == 8 && !p->bb && phi->s <= 256 && (long long)p->ptiles * BC_ITILE < 2147483647LL;
+  if (p->two) {
+    p->i4_u = bc_lay_i4_batch(phi->s);
+    p->sp8 = bc_lay_i4_sp8(phi->s, p->i4_u);
+    p->g4 = (phi->s + 3) / 4;
+    p->rb = bc_lay_r8_bytes(phi->s);
+    p->grid1 = p->grid;                        // 8 waves per CU, every wave the same number of tiles (as the int8 sweep)
+    static_assert(BC_I4_SEEDS == 256, "k_sweep_i4 evaluates one seed per thread");
+  }
   // the fp64 tiles cover ntiles*128 rows; the unit rows cover ptiles*ptile >= that, reads past the fp64 tiles are masked by `live`
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -398,9 +436,29 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
   const size_t o_bn = take(p->prec == 8 ? (size_t)p->grid * sizeof(int) : 0);
   const size_t o_bbr = take(p->bb ? (size_t)p->grid * sizeof(BbRec) : 0);
   const size_t o_bbc = take(p->bb ? (size_t)p->grid * phi->s * sizeof(double) : 0);
+  const size_t o_u4 = take(p->two ? bc_lay_i4_words(p->ptiles, p->sp8) * sizeof(int) : 0);
+  const size_t o_rq4 = take(p->two ? (size_t)p->ptiles * BC_ITILE * sizeof(unsigned short) : 0);
+  const size_t o_r8 = take(p->two ? (size_t)p->ptiles * BC_ITILE * p->rb : 0);
+  const size_t o_hot = take(p->two ? (BC_I4_SEEDS + BC_I4_HOT) * sizeof(long long) : 0);
+  const size_t o_l2l = take(p->two ? (size_t)p->grid1 * sizeof(double) : 0);
+  const size_t o_l2u = take(p->two ? (size_t)p->grid1 * sizeof(float) : 0);
+  const size_t o_l2c = take(p->two ? (size_t)p->grid1 * BC_BLK_NC * sizeof(int2) : 0);
+  const size_t o_l2n = take(p->two ? (size_t)p->grid1 * sizeof(int) : 0);
+  const size_t o_sp = take(p->two ? (size_t)4096 * sizeof(int2) : 0);
   hipError_t e = hipMalloc(&p->slab, off);
   if (e != hipSuccess) { delete p; return bc_hip_fail(e, "hipMalloc(prefilter)", __FILE__, __LINE__); }
   char* base = (char*)p->slab;
+  if (p->two) {
+    p->u4 = (int*)(base + o_u4);
+    p->rowq4 = (unsigned short*)(base + o_rq4);
+    p->r8 = (unsigned char*)(base + o_r8);
+    p->hot = (long long*)(base + o_hot);
+    p->l2_blk_l = (double*)(base + o_l2l);
+    p->l2_blk_u = (float*)(base + o_l2u);
+    p->l2_blk_cand = (int2*)(base + o_l2c);
+    p->l2_blk_nc = (int*)(base + o_l2n);
+    p->spill = (int2*)(base + o_sp);
+  }
   p->u32 = p->prec == 32 ? (float*)(base + o_u) : nullptr;
   p->u16 = p->prec == 16 ? (_Float16*)(base + o_u) : nullptr;
   p->ub = p->prec != 32 ? nullptr : (float*)(base + o_ub);
@@ -441,7 +499,20 @@ int bc_pref_create(bc_phi* phi, int prec, bc_pref** out) {
         hipLaunchKernelGGL(k_build_i8, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
                            (long long)phi->n_rows, phi->s, p->sp4, p->u8, p->rowq);
     }
-    else if (p->prec == 16)
+    if (p->two && e == hipSuccess) {
+      e = hipMemsetAsync(p->hot, 0xff, (BC_I4_SEEDS + BC_I4_HOT) * sizeof(long long), ctx->stream);            // -1: no seeds yet
+      if (e == hipSuccess) {
+        if (phi->s <= 104)
+          hipLaunchKernelGGL(k_build_i4<104>, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                             (long long)phi->n_rows, phi->s, p->sp8, p->u4, p->rowq4);
+        else
+          hipLaunchKernelGGL(k_build_i4<0>, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
+                             (long long)phi->n_rows, phi->s, p->sp8, p->u4, p->rowq4);
+        hipLaunchKernelGGL(k_build_r8, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, p->u8, p->rowq, p->sp4, p->g4, p->rb, p->r8);
+      }
+    }
+    if (p->prec == 8) {
+    } else if (p->prec == 16)
       hipLaunchKernelGGL(k_build_u16, dim3((unsigned)p->ptiles), dim3(256), 0, ctx->stream, phi->tiles, phi->norms,
                          (long long)phi->n_rows, phi->s, p->sp, p->u16, p->live);
     else
@@ -489,6 +560,48 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
   a.s = phi->s;
   int rc = bc_timer_begin(ctx, 0);
   if (rc) return rc;
+  // two-level form: needs both digit records from the owner's step kernels and seeds from an earlier rescoring
+  const bool two = p->two && p->two_active && p->qv != nullptr && p->qv4 != nullptr && p->sweeps_launched > 0;
+  p->sweeps_launched += 1;
+  if (p->two && !p->two_active) p->int8_since += 1;
+  if (two) {
+    I4Args fa;
+    fa.u4 = p->u4;
+    fa.rowq4 = p->rowq4;
+    fa.qv4 = p->qv4;
+    fa.qv8 = p->qv;
+    fa.r8 = p->r8;
+    fa.hot = p->hot;
+    fa.skip_flag = skip_flag;
+    fa.blk_l = p->l2_blk_l;
+    fa.blk_u = p->l2_blk_u;
+    fa.blk_cand = p->l2_blk_cand;
+    fa.blk_nc = p->l2_blk_nc;
+    fa.ctrl = p->ctrl;
+    fa.spill = p->spill;
+    fa.spill_cap = 4096;
+    fa.ptiles = p->ptiles;
+    fa.post_div = post_div;
+    p->l1_seq += 1;
+    fa.s = phi->s;
+    fa.sp8 = p->sp8;
+    fa.sp4 = p->sp4;
+    fa.g4 = p->g4;
+    fa.rb = p->rb;
+#define BC_I4_LAUNCH(MODE, UU) hipLaunchKernelGGL((k_sweep_i4<MODE, UU>), dim3(p->grid1), dim3(256), 0, ctx->stream, fa)
+#define BC_I4_BY_U(MODE)                                                                          \
+    switch (p->i4_u) {                                                                            \
+      case 13: BC_I4_LAUNCH(MODE, 13); break;                                                     \
+      case 8: BC_I4_LAUNCH(MODE, 8); break;                                                       \
+      case 7: BC_I4_LAUNCH(MODE, 7); break;                                                       \
+      case 6: BC_I4_LAUNCH(MODE, 6); break;                                                       \
+      default: BC_I4_LAUNCH(MODE, 5); break;                                                      \
+    }
+    if (mode == 0) { BC_I4_BY_U(0) } else { BC_I4_BY_U(1) }
+    BC_HIP(hipGetLastError());
+    rc = bc_timer_end(ctx, 0);
+    if (rc) return rc;
+  } else
   if (p->prec == 8) {
     I8Args ia;
     ia.u8 = p->u8;
@@ -532,9 +645,11 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
     if (mode == 0) hipLaunchKernelGGL(k_sweep_f32<0>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_sweep_f32<1>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
   }
-  BC_HIP(hipGetLastError());
-  rc = bc_timer_end(ctx, 0);
-  if (rc) return rc;
+  if (!two) {
+    BC_HIP(hipGetLastError());
+    rc = bc_timer_end(ctx, 0);
+    if (rc) return rc;
+  }
   RescoreArgs& r = *r_out;
   r.bb.rec = p->bb ? p->bb_rec : nullptr;
   r.bb.col = p->bb_col;
@@ -567,12 +682,63 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
   r.cap = p->cap;
   r.nblk = p->grid;
   r.ptile = p->ptile;
+  r.two_level = two ? 1 : 0;
+  r.spill = p->spill;
+  r.spill_cap = 4096;
+  r.hot = p->two ? p->hot + BC_I4_SEEDS : nullptr;      // (the ring behind the refine blocks' slots)
+  if (two) {
+    // the two-level sweep's block lists; there are no tiles behind them
+    r.blk_l = p->l2_blk_l;
+    r.blk_u = p->l2_blk_u;
+    r.blk_cand = p->l2_blk_cand;
+    r.blk_nc = p->l2_blk_nc;
+    r.nblk = p->grid1;
+    r.tile_u = nullptr;
+    r.tile_cand = nullptr;
+    r.tile_ncand = nullptr;
+    r.tile_rounds = 0;
+  }
   return BC_OK;
 }
 
 // The owner's step kernels keep a quantised copy of v_dev up to date (bc_snnls.hip: dev_prep -> bc_i8q_wave): the sweep
 // then skips its own quantisation prologue.  Only valid while EVERY launch of this pre-filter sweeps that same v.
 void bc_pref_set_qv(bc_pref* p, const int* qv_dev) { p->qv = (p->prec == 8) ? qv_dev : nullptr; }
+// ... and a 4-bit copy for the two-level form's first level (bc_i4_quant.h; sp8 must be bc_pref_sp8)
+void bc_pref_set_qv4(bc_pref* p, const int* qv4_dev) { p->qv4 = p->two ? qv4_dev : nullptr; }
+int bc_pref_sp8(const bc_pref* p) { return p->two ? p->sp8 : 0; }
+int bc_pref_two_level(const bc_pref* p) { return p->two ? 1 : 0; }
+// The host's watch over the two-level form; called where the host synchronises with the stream anyway (end of a build call,
+// every 64 steps of a long one).  BC_TWO_LEVEL_MAX_SHARE: share of the rows the first level may pass on (default 0.04).
+int bc_pref_adapt(bc_pref* p) {
+  if (!p || !p->two) return BC_OK;
+  static const double max_share = getenv("BC_TWO_LEVEL_MAX_SHARE") ? atof(getenv("BC_TWO_LEVEL_MAX_SHARE")) : 0.04;
+  const bool probe_due = !p->two_active && p->int8_since >= p->reprobe;
+  const unsigned dl1 = p->l1_seq - p->chk_l1;
+  if (!probe_due && !(p->two_active && dl1 >= 4)) return BC_OK;
+  unsigned long long rows = 0;
+  BC_HIP(hipMemcpyAsync(&rows, p->ctrl + 12, sizeof(rows), hipMemcpyDeviceToHost, p->ctx->stream));
+  BC_HIP(hipStreamSynchronize(p->ctx->stream));
+  if (p->two_active) {
+    const double share = (double)(rows - p->chk_rows) / ((double)dl1 * (double)(p->phi->n_rows > 0 ? p->phi->n_rows : 1));
+    p->last_share = share;
+    if (share > max_share) {
+      p->two_active = false;
+      p->int8_since = 0;
+    } else {
+      p->reprobe = 256;
+    }
+  } else {
+    p->two_active = true;                        // try again (the ring of seeds kept turning meanwhile)
+    p->reprobe = p->reprobe < 8192 ? 2 * p->reprobe : p->reprobe;
+  }
+  p->chk_l1 = p->l1_seq;
+  p->chk_rows = rows;
+  return BC_OK;
+}
+int bc_pref_two_level_active(const bc_pref* p) { return (p->two && p->two_active) ? 1 : 0; }
+
+long long bc_pref_l1_sweeps(const bc_pref* p) { return (long long)p->l1_seq; }     // (host count: includes sweeps the device skipped)
 int bc_pref_sp4(const bc_pref* p) { return p->sp4; }
 int bc_pref_bb(const bc_pref* p) { return p->bb ? 1 : 0; }
 

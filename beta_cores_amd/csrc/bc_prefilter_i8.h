@@ -89,6 +89,21 @@ __device__ __forceinline__ void bc_score_interval_f32(float s0, float s1, float 
   }
 }
 
+// The interval of one LIVE row from its exact integer dot products (a0 = sum q d0, a1 = sum q d1 of the score vector, a2 = sum q d
+// of GIGA's second vector): shared by the sweep below and by the second level of the two-level form (bc_prefilter_i4.h), which
+// evaluates the same rows from a row-major copy of the same digits -- the same arithmetic, hence the same bounds.
+template <int MODE>
+__device__ __forceinline__ void bc_i8_row_bounds(float sc, float dr, int a0, int a1, int a2, float fvs0, float fvs1, float fev0, float fev1,
+                                                 float fvn, bool vbad, float fpd, float& U, float& L) {
+  // u^.v^ : exact integers, scaled in fp32 (relative error < 3e-7, covered below)
+  const float s0 = sc * fvs0 * (128.f * (float)a0 + (float)a1);
+  const float s1 = (MODE == 0) ? sc * fvs1 * (float)a2 : 0.f;
+  const float delta0 = (dr * fvn + (1.f + dr) * fev0) * 1.00001f + 4e-7f * fabsf(s0) + 1e-12f;
+  const float delta1 = (MODE == 0) ? (dr * fvn + (1.f + dr) * fev1) * 1.00001f + 4e-7f * fabsf(s1) + 1e-12f : 0.f;
+  if (vbad || dr != dr) { U = INFINITY; L = -INFINITY; }
+  else bc_score_interval_f32<MODE>(s0, s1, delta0, delta1, fpd, U, L);
+}
+
 // one block per 256-row tile, thread = row
 __global__ __launch_bounds__(256) void k_build_i8(const double* __restrict__ tiles, const double* __restrict__ norms,
                                                  long long n_rows, int S, int SP4, int* __restrict__ u8,
@@ -398,14 +413,7 @@ __global__ __launch_bounds__(256) void k_sweep_i8(I8Args a) {
         Ub[j] = -INFINITY;
         Lb[j] = -INFINITY;
         if (!(dl[j] < 0.f)) {                           // live (a NaN delta counts as live and yields [-inf, inf])
-          const float dr = dl[j];
-          // u^.v^ : exact integers, scaled in fp32 (relative error < 3e-7, covered below)
-          const float s0 = sc[j] * fvs0 * (128.f * (float)acc[j][0] + (float)acc[j][1]);
-          const float s1 = (MODE == 0) ? sc[j] * fvs1 * (float)acc[j][NV - 1] : 0.f;
-          const float delta0 = (dr * fvn + (1.f + dr) * fev0) * 1.00001f + 4e-7f * fabsf(s0) + 1e-12f;
-          const float delta1 = (MODE == 0) ? (dr * fvn + (1.f + dr) * fev1) * 1.00001f + 4e-7f * fabsf(s1) + 1e-12f : 0.f;
-          if (vbad || dr != dr) { Ub[j] = INFINITY; Lb[j] = -INFINITY; }
-          else bc_score_interval_f32<MODE>(s0, s1, delta0, delta1, fpd, Ub[j], Lb[j]);
+          bc_i8_row_bounds<MODE>(sc[j], dl[j], acc[j][0], acc[j][1], acc[j][NV - 1], fvs0, fvs1, fev0, fev1, fvn, vbad, fpd, Ub[j], Lb[j]);
           tl = fmaxf(tl, Lb[j]);
           tmax = fmaxf(tmax, Ub[j]);
         }

@@ -74,7 +74,14 @@ struct RescoreArgs {
   double post_div;
   int s, cap, nblk, ptile;
   int tile_rounds;           // tiles per sweep wave = ceil(ptiles / (4 * nblk)): block b swept tiles 4b+w + 4*nblk*i
+  // two-level form (bc_prefilter_i4.h): the block lists come from the refine kernel -- there are no tiles behind them, a block
+  // that could not keep its list means "redo the step exactly" -- and ctrl[8] says whether the first level's list overflowed
+  int two_level;
+  const int2* spill;         // two-level form: pairs of the blocks whose list says -1 (count in ctrl[14], reset here)
+  int spill_cap;
+  long long* hot;            // ring of BC_RS_HOT rows that were in play lately (the first level's seeds), position in ctrl[9]; or nullptr
 };
+#define BC_RS_HOT 32         /* == BC_I4_HOT (bc_prefilter_i4.h) */
 
 #ifndef FSTAMP      // diagnostic builds define it before including this header (bc_snnls.hip, -DBC_FIN_STAMPS)
 #define FSTAMP(i) do { } while (0)
@@ -223,10 +230,12 @@ struct RescorePre {
   int nc[BC_RS_BLK_PER];
   float bu[BC_RS_BLK_PER];
   int2 c[BC_RS_BLK_PER][BC_RS_BLK_NC];
+  int l1_ovf;                // two-level form: the first level's list overflowed (ctrl[8])
 };
 
 __device__ __forceinline__ RescorePre bc_rescore_prefetch(const RescoreArgs& a) {
   RescorePre p;
+  p.l1_ovf = a.two_level ? a.ctrl[8] : 0;
   // (clamped indices instead of branches: every thread loads, nothing separates the requests -- with the loads inside
   // `if`s the compiler waited for the first bound before it issued the rest)
 #pragma unroll
@@ -314,6 +323,7 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
           if (mine.bu[q] != -INFINITY && (double)mine.bu[q] >= lmax) {
             const int slot = atomicAdd(&bcnt, 1);
             if (slot < 64) blist[slot] = threadIdx.x + q * blockDim.x;
+            if (mine.nc[q] < -1) atomicAdd(&ocnt, 1);      // (two-level form: a block that could not keep its rows)
           }
         } else {
 #pragma unroll
@@ -345,7 +355,11 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
   FDBG(21, cnt);
   FDBG(22, lists ? 1 : 0);
   bool merged = false;                       // int8 mirror, few blocks in play: phases B1 and B2 in one round of loads
-  if (nbl <= 64 && a.tile_cand) {
+  if (a.two_level) {
+    // the lists ARE the candidates.  A block in play whose list says -1 left its pairs in the spill list (scanned below);
+    // -2 (it could not keep them at all) cannot be walked: the step is redone with the exact sweep
+    overflow = mine.l1_ovf != 0 || !lists;
+  } else if (nbl <= 64 && a.tile_cand) {
     merged = true;
     const int per = 4 * a.tile_rounds, total = nbl * per;
     for (int i0 = 0; i0 < total; i0 += 4 * blockDim.x) {
@@ -437,8 +451,25 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
   const int ntl = tcnt;
   if (threadIdx.x == 0 && !merged) bcnt = 0; // reused by the int8 branch below
   __syncthreads();
-  overflow = ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
-  if (merged) {
+  overflow = overflow || ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
+  if (a.two_level) {
+    overflow = overflow || ocnt > 0;
+    if (!overflow && nbl > 0) {                // (block-uniform, rare) some block in play spilled: scan the spill list
+      const int ns = a.ctrl[14];
+      overflow = ns > a.spill_cap;
+      if (!overflow)
+        for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+          const int2 pr = a.spill[i];
+          if ((double)__int_as_float(pr.x) >= lmax) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < a.cap) a.cand[slot] = pr.y;
+            if (slot < 32) scand[slot] = pr.y;
+          }
+        }
+      __syncthreads();
+    }
+    overflow = overflow || cnt > a.cap;
+  } else if (merged) {
     // the pairs were consumed with the tile maxima; what is left are the tiles that hand over all of their rows
     const int no = ocnt;
     overflow = overflow || no > 64;
@@ -559,6 +590,7 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
     overflow = cnt > a.cap;
   }
   if (threadIdx.x == blockDim.x - 1) {         // (the last wave scores no candidate: its read-modify-writes delay nobody)
+    if (a.two_level) a.ctrl[14] = 0;           // the spill list is consumed (or abandoned)
     a.ctrl[1] = overflow ? 1 : 0;              // observable: the last launch overflowed
     if (overflow) a.ctrl[3] += 1;              // ... and how often since creation
     unsigned long long* st = reinterpret_cast<unsigned long long*>(a.ctrl + 4);   // diagnostics: sweeps, candidates rescored
@@ -569,6 +601,13 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
   FSTAMP(12);
 
   const int count = cnt;
+  // seeds of the two-level form's next sweeps: the rows in play go into the ring (the last wave: it scores nothing)
+  if (a.hot != nullptr && wave == nw - 1) {
+    const int pos = a.ctrl[9];
+    const int n = count < BC_RS_HOT ? count : BC_RS_HOT;
+    if (lane < n) a.hot[(pos + lane) & (BC_RS_HOT - 1)] = scand[lane];
+    if (lane == 0) a.ctrl[9] = (pos + n) & (BC_RS_HOT - 1);
+  }
   double bv = -INFINITY, bnorm = 0.;
   long long bi = LLONG_MAX;
   const bool keep_rows = count <= 32 && a.s <= 256;      // the winner's row stays on chip: no reload for the record

@@ -21,6 +21,7 @@ extern "C" int bc_debug_fin_stamps(unsigned long long* out) {
 #include "bc_rescore_dev.h"
 #include "bc_layout.h"
 #include "bc_i8_quant.h"
+#include "bc_i4_quant.h"
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -41,6 +42,11 @@ void bc_pref_set_cap(bc_pref* p, int cap);
 const int* bc_pref_ctrl(const bc_pref* p);
 void bc_pref_set_qv(bc_pref* p, const int* qv_dev);
 int bc_pref_sp4(const bc_pref* p);
+void bc_pref_set_qv4(bc_pref* p, const int* qv4_dev);
+int bc_pref_sp8(const bc_pref* p);
+int bc_pref_two_level(const bc_pref* p);
+int bc_pref_adapt(bc_pref* p);
+int bc_pref_two_level_active(const bc_pref* p);
 int bc_pref_launch(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
                    const int* skip_flag, double* rec_dev);
 int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double* v_norm_dev, double post_div,
@@ -82,6 +88,8 @@ struct SnnlsDev {
   double* v;          // sweep vectors: GIGA [s][2], else [s]
   int* qv;            // the same, quantised for the int8 pre-filter's sweep (bc_i8_quant.h record) -- or nullptr
   int sp4;            // k-groups of that record
+  int* qv4;           // two-level pre-filter: the same in 4-bit digits for its first level (bc_i4_quant.h record) -- or nullptr
+  int sp8;            // k-groups of that record
   double* xf;         // picked column
   const double* cand_all;
   const double* tiles;
@@ -318,8 +326,14 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const double* vsrc = lds_copy ? vq : P.v;
+      m0 = bc_wave_max_all(m0);
+      m1 = bc_wave_max_all(m1);
       if (ALG == BC_ALG_GIGA) bc_i8q_wave<0>(vsrc, s, P.sp4, 1., P.qv, lane, m0, m1);
       else bc_i8q_wave<1>(vsrc, s, P.sp4, vnorm, P.qv, lane, m0, m1);
+      if (P.qv4 != nullptr) {
+        if (ALG == BC_ALG_GIGA) bc_i4q_wave<0>(vsrc, s, P.sp8, 1., P.qv4, lane, m0, m1);
+        else bc_i4q_wave<1>(vsrc, s, P.sp8, vnorm, P.qv4, lane, m0, m1);
+      }
     }
   }
   __syncthreads();
@@ -1140,6 +1154,18 @@ extern "C" int bc_snnls_destroy(bc_snnls* h) {
   return BC_OK;
 }
 
+// Two-level pre-filter (bc_prefilter_i4.h) wanted?  BC_PREFILTER=4 forces it, =8 keeps the one-level int8 sweep; by default it
+// is used from BC_TWO_LEVEL_MIN_ROWS rows (where the halved stream outweighs the refine kernel's launch).  S <= 256.
+#define BC_TWO_LEVEL_MIN_ROWS (1LL << 62)
+static bool bc_want_two_level(int preq, long long n_rows, int s) {
+  if (s > 256 || n_rows <= 0) return false;
+  if (preq == 4) return true;
+  if (preq >= 0 && preq != 1) return false;          // an explicit BC_PREFILTER precision other than 4
+  const char* tenv = getenv("BC_TWO_LEVEL_MIN_ROWS");
+  const long long min_rows = tenv ? atoll(tenv) : BC_TWO_LEVEL_MIN_ROWS;
+  return n_rows >= min_rows;
+}
+
 #define LAUNCH1(kern, ...)                                                         \
   do {                                                                             \
     hipLaunchKernelGGL(kern, dim3(1), dim3(BC_FIN_THREADS), 0, h->ctx->stream, __VA_ARGS__);   \
@@ -1194,7 +1220,8 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_st = 0, o_b = up(sizeof(SnnlsState)), o_bn = o_b + up(s * 8), o_xw = o_bn + up(s * 8), o_xwp = o_xw + up(s * 8),
                  o_xf = o_xwp + up(s * 8), o_rec = o_xf + up(s * 8), o_v = o_rec + up(d.rec_len * 8),
-                 o_qv = o_v + up(2 * (s + BC_V_PAD) * 8), total = o_qv + up((size_t)BC_I8Q_INTS(bc_lay_i8_sp4(s)) * sizeof(int));
+                 o_qv = o_v + up(2 * (s + BC_V_PAD) * 8), o_qv4 = o_qv + up((size_t)BC_I8Q_INTS(bc_lay_i8_sp4(s)) * sizeof(int)),
+                 total = o_qv4 + up((size_t)BC_I4Q_INTS(bc_lay_i4_sp8(s, bc_lay_i4_batch(s))) * sizeof(int));
     char* slab = nullptr;
     hipError_t e0 = hipMalloc((void**)&slab, total);
     if (e0 == hipSuccess) e0 = hipMemsetAsync(slab, 0, total, ctx->stream);
@@ -1213,10 +1240,13 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
     const char* penv = getenv("BC_PREFILTER");
     const int preq = penv ? atoi(penv) : -1;
     const bool pwant = penv ? preq != 0 : phi->n_rows >= 163840;
-    const int pprec = (preq == 8 || preq == 16 || preq == 32) ? preq : BC_PREF_DEFAULT_PREC;
+    const int pprec = (preq == 8 || preq == 16 || preq == 32) ? preq : BC_PREF_DEFAULT_PREC;      // (4: the int8 mirror behind a 4-bit first level)
+    const bool ptwo = bc_want_two_level(preq, phi->n_rows, s);
     const char* qenv = getenv("BC_I8_QV");               // =0: sweeps quantise in their own prologue (A/B, tests)
     d.sp4 = bc_lay_i8_sp4(s);
     d.qv = (pwant && pprec == 8 && phi->n_rows > 0 && (s + 3) / 4 <= BC_LAY_IMAXG - BC_LAY_IU && !(qenv && atoi(qenv) == 0)) ? (int*)(slab + o_qv) : nullptr;
+    d.sp8 = bc_lay_i4_sp8(s, bc_lay_i4_batch(s));
+    d.qv4 = (d.qv && ptwo) ? (int*)(slab + o_qv4) : nullptr;
   }
   hipError_t e = hipSuccess;
   d.cand_all = h->cand_send;
@@ -1244,11 +1274,13 @@ extern "C" int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int al
   const int req = env ? atoi(env) : -1;
   const bool want = env ? req != 0 : phi->n_rows >= 163840;   // measured break-even ~131k rows at S = 100 (int8 mirror, profiles/r01_notes.md)
   if (want && phi->n_rows > 0) {
-    rc = bc_pref_create(phi, (req == 8 || req == 16 || req == 32) ? req : BC_PREF_DEFAULT_PREC, &h->pref);
+    const int cprec = (req == 8 || req == 16 || req == 32) ? req : BC_PREF_DEFAULT_PREC;
+    rc = bc_pref_create(phi, (cprec == 8 && d.qv4) ? 4 : cprec, &h->pref);
     if (rc) { bc_snnls_destroy(h); return rc; }
     const char* cap = getenv("BC_PREFILTER_CAP");
     if (cap) bc_pref_set_cap(h->pref, atoi(cap));
     if (d.qv && bc_pref_sp4(h->pref) == d.sp4) bc_pref_set_qv(h->pref, d.qv);
+    if (d.qv4 && bc_pref_two_level(h->pref) && bc_pref_sp8(h->pref) == d.sp8) bc_pref_set_qv4(h->pref, d.qv4);
   }
   *out = h;
   return BC_OK;
@@ -1263,7 +1295,7 @@ extern "C" int bc_snnls_prefilter_active(const bc_snnls* h, int* on) {
 int bc_pref_bb(const bc_pref* p);
 extern "C" int bc_snnls_prefilter_form(const bc_snnls* h, int* form) {
   if (!h || !form) { bc_set_error("bc_snnls_prefilter_form: bad argument"); return BC_INVALID_ARGUMENT; }
-  *form = !h->pref ? 0 : (bc_pref_bb(h->pref) ? 2 : 1);
+  *form = !h->pref ? 0 : (bc_pref_bb(h->pref) ? 2 : (bc_pref_two_level_active(h->pref) ? 3 : 1));      // (3 put aside by the watch: 1)
   return BC_OK;
 }
 
@@ -1292,6 +1324,25 @@ extern "C" int bc_snnls_prefilter_stats(const bc_snnls* h, int64_t* sweeps, int6
   if (sweeps) *sweeps = (int64_t)st[0];
   if (candidates) *candidates = (int64_t)st[1];
   if (fallbacks) *fallbacks = ctrl[3];
+  return BC_OK;
+}
+
+long long bc_pref_l1_sweeps(const bc_pref* p);
+extern "C" int bc_snnls_prefilter_levels(const bc_snnls* h, int64_t* l1_sweeps, int64_t* listed, int64_t* refined) {
+  if (!h) { bc_set_error("bc_snnls_prefilter_levels: bad argument"); return BC_INVALID_ARGUMENT; }
+  if (l1_sweeps) *l1_sweeps = 0;
+  if (listed) *listed = 0;
+  if (refined) *refined = 0;
+  if (!h->pref || !bc_pref_two_level(h->pref)) return BC_OK;
+  int ctrl[16];
+  BC_HIP(hipMemcpyAsync(ctrl, bc_pref_ctrl(h->pref), sizeof(ctrl), hipMemcpyDeviceToHost, h->ctx->stream));
+  BC_HIP(hipStreamSynchronize(h->ctx->stream));
+  unsigned long long st[2];
+  memcpy(st, ctrl + 10, sizeof(st));
+  if (l1_sweeps) *l1_sweeps = (int64_t)bc_pref_l1_sweeps(h->pref);
+  (void)st[0];
+  if (listed) *listed = (int64_t)st[1];            // (every row the first level passes on is re-bounded by the same wave)
+  if (refined) *refined = (int64_t)st[1];
   return BC_OK;
 }
 
@@ -1495,6 +1546,10 @@ extern "C" int bc_snnls_build_end(bc_snnls* h, int* reached_numeric_limit, int* 
   if (rc) return rc;
   h->nnz_upper = st.nnz;
   h->iter_upper = st.iter;
+  if (h->pref) {                                  // (the stream is idle: the two-level form's watch costs one small copy)
+    rc = bc_pref_adapt(h->pref);
+    if (rc) return rc;
+  }
   if (reached_numeric_limit) *reached_numeric_limit = st.reached_limit;
   if (iterations_consumed) *iterations_consumed = (int)st.iter;
   if (pending_exact) *pending_exact = st.pf_overflow;
@@ -1522,6 +1577,8 @@ extern "C" int bc_snnls_build(bc_snnls* h, int itrs, int* reached_numeric_limit)
       rc = bc_snnls_step_local(h);
       if (!rc) rc = exchange(h);
       if (!rc) rc = bc_snnls_step_finish(h);
+      // a long call: let the two-level form's watch look every 64 steps (a stream synchronisation: ~0.5 us per step)
+      if (!rc && h->pref && bc_pref_two_level(h->pref) && (i & 63) == 63 && i + 1 < left) rc = bc_pref_adapt(h->pref);
     }
     if (rc) return rc;
     int consumed = 0, pending = 0;

@@ -57,7 +57,7 @@ class HipEngine:
         N.call('bc_snnls_prefilter_active', h, C.byref(on))
         form = C.c_int()
         N.call('bc_snnls_prefilter_form', h, C.byref(form))
-        self.prefilter_form = int(form.value)    # 0 fp64 sweeps, 1 two-pass pre-filter, 2 branch-and-bound int8 sweep
+        self.prefilter_form = int(form.value)    # 0 fp64 sweeps, 1 two-pass pre-filter, 2 branch-and-bound int8 sweep, 3 two-level (4-bit, int8, fp64)
         self.prefilter = int(on.value)           # 0, or the storage precision (16 / 32) of the mirror of Phi the sweeps
                                                  # stream; candidates are rescored in fp64, selections are unchanged
         self.world = 1 if comm is None else comm.world
@@ -201,6 +201,12 @@ class HipEngine:
         """(sweeps, candidates handed to the exact rescoring, fp64 fallbacks) since this solver was created."""
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         N.call('bc_snnls_prefilter_stats', self.h, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
+    def prefilter_levels(self):
+        """Two-level form (prefilter_form 3): (first-level sweeps, rows they listed, rows re-bounded from the int8 records)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        N.call('bc_snnls_prefilter_levels', self.h, C.byref(a), C.byref(b), C.byref(c))
         return int(a.value), int(b.value), int(c.value)
 
     def trace(self):

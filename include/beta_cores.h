@@ -262,7 +262,8 @@ int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
 /* *form = 0: fp64 sweeps; 1: two-pass pre-filter (reduced-precision sweep, then one block rescoring the candidates from the
  * fp64 Phi); 2: branch-and-bound int8 sweep (csrc/bc_prefilter_bb.h: a fifth wave per sweep block rescoring the candidates
  * beside the stream; opt-in with BC_I8_BB=1 -- measured slower than form 1 at every size tried, kept for the record and its
- * tests).  Same call sites as bc_snnls_prefilter_active (giga.py:31-38, frankwolfe.py:16-17): the row returned is the
+ * tests); 3: two-level pre-filter (csrc/bc_prefilter_i4.h: a 4-bit mirror streamed first -- half a byte per element --, the rows
+ * it cannot exclude re-bounded from row-major int8 records, then the fp64 rescoring; BC_PREFILTER=4, S <= 256).  Same call sites as bc_snnls_prefilter_active (giga.py:31-38, frankwolfe.py:16-17): the row returned is the
  * fp64 sweep's in every form. */
 int bc_snnls_prefilter_form(const bc_snnls* h, int* form);
 /* Diagnostic: how many sweeps since creation overflowed the pre-filter's candidate lists (thousands of exactly
@@ -272,6 +273,11 @@ int bc_snnls_prefilter_fallbacks(const bc_snnls* h, int64_t* n);
 /* Diagnostic: sweeps run through the pre-filter since creation, rows it handed to the exact fp64 rescoring in
  * total (candidates / sweeps = how selective the reduced-precision bounds are on this data), and fallbacks. */
 int bc_snnls_prefilter_stats(const bc_snnls* h, int64_t* sweeps, int64_t* candidates, int64_t* fallbacks);
+/* Diagnostic of the two-level form (prefilter_form 3, csrc/bc_prefilter_i4.h: a 4-bit first level in front of the int8
+ * records): first-level sweeps run, rows they listed in total, and rows the second level re-bounded from the int8 records
+ * (listed / (sweeps * rows) = what the seeds leave of the stream; refined / sweeps = the gather's size).  All zero for the
+ * other forms.  Same call sites as bc_snnls_prefilter_stats. */
+int bc_snnls_prefilter_levels(const bc_snnls* h, int64_t* l1_sweeps, int64_t* listed, int64_t* refined);
 /* bayesiancoresets/util/__init__.py:4-7 (TOL, set_tolerance); default 1e-12 */
 int bc_snnls_set_tolerance(bc_snnls* h, double tol);
 /* multi-rank: device buffers (world*(S+4) and (S+4) doubles) through which the

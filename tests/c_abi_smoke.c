@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
                   (void*)bc_project, (void*)bc_project_grad_x, (void*)bc_phi_shape, (void*)bc_phi_colsum, (void*)bc_phi_norms, (void*)bc_phi_norm_stats,
                   (void*)bc_phi_to_host, (void*)bc_phi_gather_rows, (void*)bc_phi_group_sum, (void*)bc_phi_matvec, (void*)bc_phi_destroy,
                   (void*)bc_phi_argmax, (void*)bc_snnls_create, (void*)bc_snnls_destroy, (void*)bc_snnls_prefilter_active, (void*)bc_snnls_prefilter_form,
-                  (void*)bc_snnls_prefilter_fallbacks, (void*)bc_snnls_prefilter_stats,
+                  (void*)bc_snnls_prefilter_fallbacks, (void*)bc_snnls_prefilter_stats, (void*)bc_snnls_prefilter_levels,
                   (void*)bc_snnls_set_tolerance, (void*)bc_snnls_bind_exchange, (void*)bc_snnls_record_doubles,
                   (void*)bc_snnls_build_begin, (void*)bc_snnls_step_local, (void*)bc_snnls_step_local_exact, (void*)bc_snnls_step_finish, (void*)bc_snnls_build_end, (void*)bc_snnls_select_local_exact,
                   (void*)bc_snnls_build, (void*)bc_snnls_select, (void*)bc_snnls_select_local, (void*)bc_snnls_select_pick,

@@ -196,4 +196,4 @@ def test_every_entry_point_refuses_null_arguments():
     import subprocess
     import sys
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'abi_null_sweep.py')], capture_output=True, text=True, timeout=120)
-    assert res.returncode == 0 and 'swept 7' in res.stdout, res.stdout + res.stderr[-2000:]
+    assert res.returncode == 0 and 'swept 8' in res.stdout, res.stdout + res.stderr[-2000:]

@@ -12,11 +12,12 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[32, 16, 8, 'bb', 'lists'])
+@pytest.fixture(params=[32, 16, 8, 'bb', 'lists', 4])
 def prec(request, monkeypatch):
     """Storage precision of the mirror; 'bb' = the int8 mirror swept in the branch-and-bound form (csrc/bc_prefilter_bb.h:
     the sweep blocks rescore their candidates themselves), forced on for these small inputs -- 8 forces the two-pass form;
-    'lists' = two-pass with the sweep blocks' own candidate lists (BC_I8_BLKLIST=1: the rescoring stage skips the tile walk)."""
+    'lists' = two-pass with the sweep blocks' own candidate lists (BC_I8_BLKLIST=1: the rescoring stage skips the tile walk);
+    4 = the two-level form (csrc/bc_prefilter_i4.h: a 4-bit first level, int8 records behind it; S <= 256)."""
     if request.param == 'bb':
         monkeypatch.setenv('BC_I8_BB', '1')
         return 8
@@ -58,7 +59,9 @@ class prefilter:
 def run(bc, cls, phi, steps, on, cap=None, stepwise=False):
     with prefilter(on, cap):
         s = cls(phi.T, phi.sum(axis=0))
-    assert s._eng.prefilter == on
+    assert s._eng.prefilter == (8 if on == 4 else on)
+    if on == 4:
+        assert s._eng.prefilter_form == (3 if phi.shape[1] <= 256 else 1)
     if on == 8 and os.environ.get('BC_I8_BB') is not None:
         # (the branch-and-bound form keeps the winner's row in a 256-double LDS strip: wider projections stay two-pass)
         assert s._eng.prefilter_form == (2 if os.environ['BC_I8_BB'] == '1' and phi.shape[1] <= 256 else 1)
@@ -127,11 +130,12 @@ def test_candidate_overflow_falls_back_to_fp64(bc, cap, prec):
     with prefilter(prec):
         s = bc.snnls.GIGA(phi2.T, np.ones(32))
     s.build(5)
-    if s._eng.prefilter_form != 2:
+    if s._eng.prefilter_form not in (2, 3):
         assert s._eng.prefilter_fallbacks() == 0
     else:
         # b = 1 is orthogonal to every (centred) row: all 3000 scores tie at rounding noise.  The two-pass form's lists hold 4096
-        # candidates; a branch-and-bound block rescores at most 48 rows per sweep and hands such a step to the exact sweep
+        # candidates; a branch-and-bound block rescores at most 48 rows per sweep and hands such a step to the exact sweep, and
+        # so does a refine block of the two-level form that is left with more than eight rows in play
         assert s._eng.prefilter_fallbacks() >= 1
         with prefilter(prec):
             s = bc.snnls.GIGA(phi2.T, phi2.sum(axis=0))
@@ -249,6 +253,35 @@ def test_int8_mirror_builders_agree(bc, n, s, monkeypatch):
     assert sa == sb
 
 
+def test_two_level_watch_puts_the_first_level_aside_where_it_does_not_select(bc):
+    """The host watches the share of rows the 4-bit first level passes on (csrc/bc_prefilter.hip: bc_pref_adapt, at the end
+    of every build call): on rows whose scores the 4-bit bounds cannot tell apart (here
+    linear-regression rows under widely scattered parameter samples: a tenth of them and more pass) the solver goes back to the one-level int8 sweep; selections are the fp64 sweep's either way."""
+    import torch
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    n, d, s = 400_000, 32, 100
+    Z = torch.randn((n, d + 1), generator=g, dtype=torch.float64, device='cuda')
+    th = np.random.default_rng(1).standard_normal((s, d)) * 0.3
+    phi = bc.DeviceProjector(lambda k, w, p: th, s, bc.likelihoods.LinearRegression(1.0)).project(bc.DeviceData.from_torch(Z))
+    with prefilter(4):
+        sv = bc.snnls.GIGA(phi.T, phi.colsum())
+    assert sv._eng.prefilter_form == 3
+    sv.build(12)
+    l1, listed, _ = sv._eng.prefilter_levels()
+    assert l1 >= 4 and listed > 0.04 * l1 * n
+    N_ = __import__('beta_cores_amd._native', fromlist=['x'])
+    import ctypes as C
+    form = C.c_int()
+    N_.call('bc_snnls_prefilter_form', sv._eng.h, C.byref(form))
+    assert form.value == 1                                   # put aside
+    sv.build(12)
+    assert sv._eng.prefilter_levels()[0] == l1               # no further first-level sweeps
+    with prefilter(0):
+        ref = bc.snnls.GIGA(phi.T, phi.colsum())
+    ref.build(24)
+    assert np.array_equal(sv._eng.trace()[0], ref._eng.trace()[0])
+
+
 def _fuzz_problem(rng, n, s, kind):
     if kind == 0:
         phi = rng.randn(n, s)
@@ -281,7 +314,7 @@ def test_random_problems_all_mirrors(bc):
         cls = bc.snnls.GIGA if rng.rand() < 0.6 else bc.snnls.FrankWolfe
         steps = min(n, rng.randint(1, 40))
         ref = run(bc, cls, phi, steps, 0)
-        for prec in (8, 16, 32):
+        for prec in (8, 16, 32, 4):
             same(run(bc, cls, phi, steps, prec), ref)
         os.environ['BC_I8_BB'] = '1'
         try:
@@ -300,7 +333,7 @@ def test_million_rows_identical(bc):
     data = bc.DeviceData.from_torch(Z)
     phi = bc.DeviceProjector(lambda k, w, p: th, s, bc.likelihoods.LinearRegression(1.0)).project(data)
     out = []
-    for on in (32, 16, 8, 'bb', 0):
+    for on in (32, 16, 8, 'bb', 4, 0):
         if on == 'bb':
             os.environ['BC_I8_BB'] = '1'
         try:
@@ -308,8 +341,12 @@ def test_million_rows_identical(bc):
                 sv = bc.snnls.GIGA(phi.T, phi.colsum())
         finally:
             os.environ.pop('BC_I8_BB', None)
-        assert sv._eng.prefilter == (8 if on == 'bb' else on) and (on != 'bb' or sv._eng.prefilter_form == 2)
+        assert sv._eng.prefilter == (8 if on in ('bb', 4) else on) and (on != 'bb' or sv._eng.prefilter_form == 2)
+        assert on != 4 or sv._eng.prefilter_form == 3
         sv.build(60)
+        if on == 4:
+            l1, listed, refined = sv._eng.prefilter_levels()
+            assert 1 <= l1 and 0 < refined == listed      # (the first sweep has no seeds: plain int8)
         out.append((sv._eng.trace(), sv._eng.sparse_weights(), sv.error()))
     tb, wb, eb = out[-1]
     for ta, wa, ea in out[:-1]:

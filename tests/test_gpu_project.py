@@ -619,7 +619,7 @@ def test_abi_null_sweep_with_a_live_context():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, os.path.join(root, 'tests', 'abi_null_sweep.py')], capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0 and 'live-context checks ok' in res.stdout and 'swept 7' in res.stdout, res.stdout + res.stderr[-2000:]
+    assert res.returncode == 0 and 'live-context checks ok' in res.stdout and 'swept 8' in res.stdout, res.stdout + res.stderr[-2000:]
 
 
 # ------------------------------------------------------------------ round 5: constant rows evaluated on the host

@@ -160,4 +160,4 @@ def test_c_abi_validation_paths_under_asan_ubsan(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan[0], ASAN_OPTIONS='detect_leaks=0', UBSAN_OPTIONS='print_stacktrace=1', BETA_CORES_LIB=lib)
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'abi_null_sweep.py')], capture_output=True, text=True, timeout=300, env=env)
     assert 'AddressSanitizer' not in res.stderr and 'runtime error' not in res.stderr, res.stderr[-3000:]
-    assert res.returncode == 0 and 'swept 7' in res.stdout, res.stdout + res.stderr[-2000:]
+    assert res.returncode == 0 and 'swept 8' in res.stdout, res.stdout + res.stderr[-2000:]
