@@ -768,7 +768,15 @@ def main():
         # fp16: the sweep streams the fp16 mirror of the normalised Phi (2 B/element, planes padded to a multiple of
         # 10) and one live-mask byte per 8 rows; it writes only per-tile / per-block bounds.  fp32: 4 B/element + the
         # norms, and one fp32 upper bound written per row.  Candidates are rescored in fp64 either way.
-        if pref == 8:
+        form = int(alg.snnls._eng.prefilter_form)
+        if pref == 8 and form == 3:
+            # two-level form (csrc/bc_prefilter_i4.h): the sweep streams the 4-bit mirror -- k-groups of 8 samples per dword, padded
+            # to a multiple of the batch (S = 100: 13 dwords, no padding) -- and a 16-bit (scale, delta) code per row; the rows it
+            # cannot exclude (prefilter.levels below: a fraction of a percent) are re-bounded from 128-byte int8 records
+            g8 = -(-S // 8)
+            sp8 = min(-(-g8 // u) * u for u in (13, 8, 7, 6, 5))
+            k3_bytes = 4.0 * n_local * sp8 + 2.0 * n_local
+        elif pref == 8:
             # int8 mirror: one byte per element (k-groups of 4 padded to a multiple of 5) + (scale, delta) halfs per row
             k3_bytes = 4.0 * n_local * (-(-(-(-S // 4)) // 5) * 5) + 4.0 * n_local
         elif pref == 16:
@@ -811,8 +819,9 @@ def main():
     err = alg.error()
     f_tr, st_tr, _ = alg.snnls._eng.trace()
 
-    pname = 'int8' if pref == 8 else 'fp%d' % pref
-    kname = 'k_sweep_i8' if pref == 8 else 'k_sweep_f%d' % pref
+    two_level = pref == 8 and int(alg.snnls._eng.prefilter_form) == 3
+    pname = ('4-bit + int8 two-level' if two_level else 'int8') if pref == 8 else 'fp%d' % pref
+    kname = ('k_sweep_i4' if two_level else 'k_sweep_i8') if pref == 8 else 'k_sweep_f%d' % pref
     algn = 'GIGA' if args.alg == 'giga' else 'dot'
     out, detail = None, {}
     kernels, loops = [], []
@@ -844,7 +853,9 @@ def main():
                          'bytes_per_launch': k3_bytes, 'fp64_formulation_bytes_per_launch': 8.0 * n_local * S + 8.0 * n_local,
                          'avg_launch_ms': k3_ms_per, 'launches': args.steps, 'launches_timed': k3_n,
                          'kernels': kernels, 'loops': loops},
-            'prefilter': dict(zip(('sweeps', 'candidates_rescored', 'fp64_fallbacks'), alg.snnls._eng.prefilter_stats())),
+            'prefilter': dict(zip(('sweeps', 'candidates_rescored', 'fp64_fallbacks'), alg.snnls._eng.prefilter_stats()),
+                              form=int(alg.snnls._eng.prefilter_form),
+                              levels=dict(zip(('l1_sweeps', 'rows_passed_on', 'rows_refined_int8'), alg.snnls._eng.prefilter_levels()))),
             'step_stages': {'sweep': sig(stage_ms['sweep']), 'rescore': sig(stage_ms['rescoring_or_local_winner']),
                             'gather': sig(stage_ms['all_gather']), 'finish': sig(stage_ms['finish']),
                             'instr_ms_per_step': sig(1e3 * t_diag / diag_steps), 'rccl_ranks': rccl_ranks,

@@ -59,6 +59,7 @@ struct I4Args {
   long long ptiles;
   double post_div;
   int s, sp8, sp4, g4, rb;       // sp4: k-groups of the int8 digit record; g4 = ceil(S / 4); rb: bytes of an int8 record
+  int seed_early;                // request the seeds' int8 records between the first two batches (A/B: BC_I4_SEED_EARLY)
 };
 
 __device__ __forceinline__ int bc_f32_ord(float f) {        // order-preserving map float -> int (for LDS atomicMax)
@@ -66,6 +67,28 @@ __device__ __forceinline__ int bc_f32_ord(float f) {        // order-preserving 
   return b >= 0 ? b : b ^ 0x7fffffff;
 }
 __device__ __forceinline__ float bc_ord_f32(int o) { return __builtin_bit_cast(float, o >= 0 ? o : o ^ 0x7fffffff); }
+
+// The same for a record of exactly 128 bytes that the caller already holds in registers (requested early: the seeds).
+template <int MODE>
+__device__ __forceinline__ void bc_r8_interval_regs(const bc_i4 (&w)[8], const int (*dig8)[4], const float* hdr, int g4, float fpd, float& U, float& L) {
+  int a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = 4 * u + j;
+      if (g < g4) {
+        const bc_i4 dg = *reinterpret_cast<const bc_i4*>(&dig8[g][0]);
+        a0 = __builtin_amdgcn_sdot4(w[u][j], dg[0], a0, false);
+        a1 = __builtin_amdgcn_sdot4(w[u][j], dg[1], a1, false);
+        if (MODE == 0) a2 = __builtin_amdgcn_sdot4(w[u][j], dg[2], a2, false);
+      }
+    }
+  const bc_hq2 rq = __builtin_bit_cast(bc_hq2, w[7][3]);
+  const float sc = (float)rq[0], dl = (float)rq[1];
+  if (dl < 0.f) { U = -INFINITY; L = -INFINITY; return; }      // dead row
+  bc_i8_row_bounds<MODE>(sc, dl, a0, a1, a2, hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] != 0.f, fpd, U, L);
+}
 
 // (U, L) of one row from its int8 record, against the int8 digit table in LDS.  hdr = the record's six header floats.
 template <int MODE>
@@ -98,6 +121,33 @@ __device__ __forceinline__ void bc_r8_interval(const unsigned char* __restrict__
   bc_i8_row_bounds<MODE>(sc, dl, a0, a1, a2, hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] != 0.f, fpd, U, L);
 }
 
+// bc_score_interval_f32 (bc_prefilter_i8.h) with the hardware's approximate reciprocal / square roots (v_rcp_f32, v_sqrt_f32,
+// v_rsq_f32: 1 ulp) instead of the correctly rounded sequences (~12 instructions each: the 4-bit sweep evaluates a row per 13
+// loaded dwords, and its epilogue cost as much as its dot products).  Every use is an UPPER bound inflated by 1.000001 (an ulp
+// is 1.2e-7) or enters f, whose evaluation error term is raised from 6e-7 to 1e-6 for the rsq's ulp.  ifpd >= 1 / |post_div|.
+template <int MODE>
+__device__ __forceinline__ void bc_score_interval_f32_hw(float s0, float s1, float delta0, float delta1, float post_div, float ifpd, float& U, float& L) {
+  if (MODE == 0) {
+    const float a = fabsf(s1) + delta1;
+    const float c = 1.f - a * a;
+    const bool bad = !(s0 == s0) || !(s1 == s1) || !(c > 1e-3f);
+    const float cc = bad ? 1.f : c;
+    const float rc2 = __builtin_amdgcn_rcpf(cc) * 1.000001f;              // >= 1/c
+    const float rc = __builtin_amdgcn_sqrtf(rc2) * 1.000001f;            // >= 1/sqrt(c)
+    const float g = 1.f - s1 * s1;
+    const float f = s0 * __builtin_amdgcn_rsqf(bad ? 1.f : g);
+    const float e = (delta0 * rc + (fabsf(s0) + delta0) * a * delta1 * rc * rc2) * 1.003f + fabsf(f) * (6.1e-8f * rc2 + 1e-6f) + 2e-7f;
+    U = bad ? INFINITY : f + e;
+    L = bad ? -INFINITY : f - e;
+  } else {
+    const bool bad = !(s0 == s0);
+    const float f = s0 * __builtin_amdgcn_rcpf(post_div);                // within 2 ulp of s0 / post_div: the 1e-6 |f| below
+    const float e = (delta0 * 1.002f + 3e-7f * fabsf(s0)) * ifpd + 1e-6f * fabsf(f) + 1e-30f;
+    U = bad ? INFINITY : f + e;
+    L = bad ? -INFINITY : f - e;
+  }
+}
+
 // ------------------------------------------------------------------ builders
 // quantise one unit row's element with scale code c (scale = c / 1024)
 __device__ __forceinline__ int bc_i4_digit(double u, double iscale) {
@@ -105,24 +155,31 @@ __device__ __forceinline__ int bc_i4_digit(double u, double iscale) {
   return q > 7 ? 7 : (q < -7 ? -7 : q);
 }
 
-// Loop over a row's elements: unrolled to SMAX with a `k < S` predicate when the values sit in registers (SMAX > 0; a runtime
-// index would send the register array to scratch), a plain loop otherwise.
-#define BC_I4_FOR_K(SMAX, S, body)                                   \
-  if (SMAX > 0) {                                                    \
-    _Pragma("unroll") for (int k = 0; k < (SMAX > 0 ? SMAX : 1); ++k) \
-      if (k < S) { body }                                            \
-  } else {                                                           \
-    for (int k = 0; k < S; ++k) { body }                             \
+// The 4-bit mirror: one block per 256-row tile, thread = row.
+//   Phase A, the scale: a heuristic search over eight candidates (the smallest code that never clips, times 1 .. 0.3) for the
+//     one with the least squared error -- evaluated on the row's INT8 digits (25 coalesced dwords per row instead of a hundred
+//     doubles; their 0.6 % error is irrelevant for a heuristic: ANY scale is valid, the bound only needs the error measured).
+//   Phase B, digits and delta: ONE streaming pass over the fp64 row, u = Phi / ||Phi|| as in k_build_i8: q = clamp(rint(u /
+//     scale)), delta^2 += (q scale - u)^2 in fp64; delta rounded UP to its 8-bit code.
+// (First version: the row held in 208 registers, the search on fp64 -> fp32 conversions: 334 VGPRs, one wave per SIMD, 13 ms at
+// N = 10M against 1.9 ms for the int8 mirror; this one streams.)
+__global__ __launch_bounds__(256) void k_build_i4(const double* __restrict__ tiles, const double* __restrict__ norms, long long n_rows,
+                                                 int S, int SP8, const int* __restrict__ u8, const bc_hq2* __restrict__ rowq, int SP4, int G4,
+                                                 int* __restrict__ u4, unsigned short* __restrict__ rowq4) {
+  const long long t = blockIdx.x;
+  const long long r = t * BC_ITILE + threadIdx.x;
+  const bc_hq2 rq8 = rowq[r];
+  const float sc8 = (float)rq8[0], d8 = (float)rq8[1];
+  const bool dead = d8 < 0.f, unc = d8 != d8;
+  int* q = u4 + bc_lay_i4_word(t, 0, threadIdx.x, SP8);
+  if (dead || unc) {                                   // (per-lane branch: such rows are rare)
+    for (int g = 0; g < SP8; ++g) q[(size_t)g * BC_ITILE] = 0;
+    rowq4[r] = (unsigned short)((dead ? BC_I4_DEAD : BC_I4_UNCERTAIN) << 8);
+    return;
   }
-
-// The scale search (fp32: a heuristic, any scale is valid) and the final measurement (fp64) for one row whose unit values
-// come from `getu(k)`.  Returns the packed 16-bit word; `scale_out` is the chosen scale (0: nothing to store).
-template <int SMAX, typename F>
-__device__ __forceinline__ unsigned short bc_i4_choose(F getu, int S, bool live, bool has_nan, double mx, double& scale_out) {
-  scale_out = 0.;
-  if (!live) return (unsigned short)(BC_I4_DEAD << 8);
-  if (has_nan || !(mx > 0.)) return (unsigned short)(BC_I4_UNCERTAIN << 8);
-  int cb = (int)ceil(mx * (1024. / 7.));            // the smallest code that never clips
+  // ---- phase A
+  const int* src = u8 + bc_lay_i8_word(t, 0, threadIdx.x, SP4);
+  int cb = (int)ceilf(127.f * sc8 * (1024.f / 7.f));    // |u| <= 127 scale8
   cb = cb < 1 ? 1 : (cb > 253 ? 253 : cb);
   int bestc = cb;
   float beste = INFINITY;
@@ -130,93 +187,50 @@ __device__ __forceinline__ unsigned short bc_i4_choose(F getu, int S, bool live,
   for (int f = 0; f < 8; ++f) {
     int c = (int)((float)cb * (1.f - 0.1f * (float)f) + 0.5f);       // cb x {1, .9, .8, .7, .6, .5, .4, .3}
     c = c < 1 ? 1 : c;
-    const float sc = (float)c * (1.f / 1024.f), isc = 1024.f / (float)c;
-    float e = 0.f;
-    BC_I4_FOR_K(SMAX, S, {
-      const float u = (float)getu(k);
-      float q = rintf(u * isc);
-      q = q > 7.f ? 7.f : (q < -7.f ? -7.f : q);
-      const float d = q * sc - u;
-      e = fmaf(d, d, e);
-    })
+    const float sc = (float)c * (1.f / 1024.f);
+    const float ratio = sc8 * (1024.f / (float)c);       // int8 digit -> units of the 4-bit step
+    float e0 = 0.f, e1 = 0.f;
+    for (int g = 0; g < G4; ++g) {
+      const int w = src[(size_t)g * BC_ITILE];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = (float)((w << (24 - 8 * j)) >> 24) * ratio;     // the element in 4-bit steps
+        float qq = rintf(x);
+        qq = qq > 7.f ? 7.f : (qq < -7.f ? -7.f : qq);
+        const float d = qq - x;
+        if (j & 1) e1 = fmaf(d, d, e1); else e0 = fmaf(d, d, e0);
+      }
+    }
+    const float e = (e0 + e1) * sc * sc;
     if (e < beste) { beste = e; bestc = c; }
   }
+  // ---- phase B
   const double scale = (double)bestc * (1. / 1024.);
   const double iscale = 1024. / (double)bestc;
+  const double inr = 1. / norms[r];                     // (live: r < n_rows and a non-zero norm; one reciprocal per row, see k_build_i8)
+  const double* p = tiles + bc_lay_phi_elem(r, 0, S);
   double err2 = 0.;
-  BC_I4_FOR_K(SMAX, S, {
-    const double u = getu(k);
-    const double d = (double)bc_i4_digit(u, iscale) * scale - u;
-    err2 = fma(d, d, err2);
-  })
+  for (int g = 0; g < SP8; ++g) {
+    unsigned w = 0;
+    double u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * g + j;
+      u[j] = k < S ? p[(size_t)k * BC_TILE] * inr : 0.;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int qi = bc_i4_digit(u[j], iscale);          // (padding: u = 0 -> digit 0, no error)
+      const double d = (double)qi * scale - u[j];
+      err2 = fma(d, d, err2);
+      w |= ((unsigned)qi & 0xfu) << (4 * j);
+    }
+    q[(size_t)g * BC_ITILE] = (int)w;
+  }
   const double dd = sqrt(err2) * (1. + 1e-6) + 1e-12;
-  const int dc = (int)ceil(dd * 512.);               // delta = dc / 512 >= dd
-  if (!(dc <= 250)) return (unsigned short)(BC_I4_UNCERTAIN << 8);
-  scale_out = scale;
-  return (unsigned short)(bestc | (dc << 8));
-}
-
-// one block per 256-row tile, thread = row.  SMAX > 0: S <= SMAX and the row's values are loaded ONCE into registers (all loads
-// in flight, as k_build_i8_r); SMAX == 0: any S, every pass re-reads the row from Phi (L2-resident: 100 KB per 128-row tile).
-template <int SMAX>
-__global__ __launch_bounds__(256) void k_build_i4(const double* __restrict__ tiles, const double* __restrict__ norms, long long n_rows,
-                                                 int S, int SP8, int* __restrict__ u4, unsigned short* __restrict__ rowq4) {
-  const long long t = blockIdx.x;
-  const long long r = t * BC_ITILE + threadIdx.x;
-  const bool live = r < n_rows && norms[r < n_rows ? r : 0] != 0.;
-  const double inr = live ? 1. / norms[r] : 0.;       // (one reciprocal per row: see k_build_i8)
-  const long long rr = bc_lay_i8_src_row(r, n_rows);  // (rows past the end read row 0 and are dead)
-  const double* p = tiles + bc_lay_phi_elem(rr, 0, S);
-  double ur[SMAX > 0 ? SMAX : 1];
-  if (SMAX > 0) {
-#pragma unroll
-    for (int k = 0; k < (SMAX > 0 ? SMAX : 1); ++k) ur[k] = (k < S && n_rows > 0) ? p[(size_t)k * BC_TILE] * inr : 0.;
-  }
-  auto getu = [&](int k) -> double { return SMAX > 0 ? ur[SMAX > 0 ? k : 0] : p[(size_t)k * BC_TILE] * inr; };
-  double mx = 0.;
-  bool has_nan = false;
-  if (live) {
-    BC_I4_FOR_K(SMAX, S, {
-      const double u = getu(k);
-      has_nan |= !(fabs(u) <= 1.7976931348623157e308);
-      mx = fmax(mx, fabs(u));
-    })
-  }
-  double scale;
-  const unsigned short code = bc_i4_choose<SMAX>(getu, S, live, has_nan, mx, scale);
-  const double iscale = scale > 0. ? 1. / scale : 0.;
-  int* q = u4 + bc_lay_i4_word(t, 0, threadIdx.x, SP8);
-  if (SMAX > 0) {
-#pragma unroll
-    for (int g = 0; g < (SMAX + 7) / 8; ++g) {
-      if (g < SP8) {
-        unsigned w = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 8 * g + j;
-          if (k < (SMAX > 0 ? SMAX : 1)) {
-            const int d = bc_i4_digit(ur[k < (SMAX > 0 ? SMAX : 1) ? k : 0], iscale);
-            w |= (k < S && scale > 0.) ? ((unsigned)d & 0xfu) << (4 * j) : 0u;
-          }
-        }
-        q[(size_t)g * BC_ITILE] = (int)w;
-      }
-    }
-    for (int g = (SMAX + 7) / 8; g < SP8; ++g) q[(size_t)g * BC_ITILE] = 0;
-  } else {
-    for (int g = 0; g < SP8; ++g) {
-      unsigned w = 0;
-      if (scale > 0.) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 8 * g + j;
-          if (k < S) w |= ((unsigned)bc_i4_digit(getu(k), iscale) & 0xfu) << (4 * j);
-        }
-      }
-      q[(size_t)g * BC_ITILE] = (int)w;
-    }
-  }
-  rowq4[r] = code;
+  const int dc = (int)ceil(dd * 512.);                   // delta = dc / 512 >= dd
+  // (a NaN / inf element makes the int8 row "uncertain" already; should the measured error not fit the code, the row is uncertain too)
+  rowq4[r] = (dc <= 250) ? (unsigned short)(bestc | (dc << 8)) : (unsigned short)(BC_I4_UNCERTAIN << 8);
 }
 
 // row-major copy of the int8 mirror: one block per 256-row tile, thread = row
@@ -238,6 +252,17 @@ __global__ __launch_bounds__(256) void k_build_r8(const int* __restrict__ u8, co
   }
 }
 
+// diagnostic build (-DBC_I4_STAMPS, tools/build_variant.sh): s_memtime of every block's thread 0 at the phase boundaries
+#ifdef BC_I4_STAMPS
+__device__ unsigned long long g_i4_stamps[1024][8];
+#define I4STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_i4_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int bc_debug_i4_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_i4_stamps), sizeof(g_i4_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define I4STAMP(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ levels 1 + 2
 template <int MODE, int U>
 __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
@@ -253,21 +278,43 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
   __shared__ unsigned long long s_best;                // (ordered int8 lower bound << 32 | row): the block's strongest row
   __shared__ int2 s_out[BC_BLK_NC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  I4STAMP(0);
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0;
   if (skip) return;
   const int SP8 = a.sp8;
   // the first tile's loads and the seed rows' numbers do not depend on the prologue: in flight before it
   long long t = (long long)blockIdx.x * 4 + wave;
+  const long long tstride = (long long)gridDim.x * 4;
+  // the seed rows' numbers first.  (seed_early, opt-in: their int8 records requested between the first and the second batch, so
+  // that they land with the stream instead of costing the prologue a dependent round trip -- measured SLOWER, bc_prefilter.hip)
+  const long long hot_row = a.hot[threadIdx.x];                                              // (BC_I4_SEEDS == blockDim.x)
+  const long long ring_row = (threadIdx.x < BC_I4_HOT) ? a.hot[BC_I4_SEEDS + threadIdx.x] : -1;
   bc_i4 x[U], y[U];
-  uint2 rq = make_uint2(0xffffffffu, 0xffffffffu);    // (dead)
+  bc_i4 sw[8];                                          // this thread's seed record (rb == 128: the usual case)
+  const bool seed_early = a.rb == 128 && a.seed_early != 0;
+  uint2 rq = make_uint2(0xffffffffu, 0xffffffffu), rq_next = rq;    // (dead)
   if (t < a.ptiles) {
+    rq = reinterpret_cast<const uint2*>(a.rowq4 + t * BC_ITILE)[lane];
     const bc_i4* __restrict__ p0 = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)t * SP8 * BC_ITILE) + lane;
 #pragma unroll
     for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p0 + (size_t)u * 64);
-    rq = reinterpret_cast<const uint2*>(a.rowq4 + t * BC_ITILE)[lane];
   }
-  const long long hot_row = a.hot[threadIdx.x];                                              // (BC_I4_SEEDS == blockDim.x)
-  const long long ring_row = (threadIdx.x < BC_I4_HOT) ? a.hot[BC_I4_SEEDS + threadIdx.x] : -1;
+  if (seed_early) {
+    const bc_i4* __restrict__ ps = reinterpret_cast<const bc_i4*>(a.r8 + (size_t)(hot_row >= 0 ? hot_row : 0) * 128);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sw[u] = ps[u];
+  }
+  if (t < a.ptiles) {
+    // ... and the second batch: two batches per wave cover the prologue's two dependent round trips
+    const long long t2 = (U >= SP8) ? t + tstride : t;
+    const int g2 = (U >= SP8) ? 0 : U;
+    if (t2 < a.ptiles) {
+      if (g2 == 0) rq_next = reinterpret_cast<const uint2*>(a.rowq4 + t2 * BC_ITILE)[lane];
+      const bc_i4* __restrict__ p1 = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)t2 * SP8 * BC_ITILE) + (size_t)g2 * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p1 + (size_t)u * 64);
+    }
+  }
   // ---- prologue: both digit records into LDS
   for (int g = threadIdx.x; g < SP8; g += blockDim.x)
     *reinterpret_cast<bc_i4*>(&dig4[g][0]) = reinterpret_cast<const bc_i4*>(a.qv4)[g];
@@ -279,13 +326,16 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
   const float fvs0 = hf[0], fvs1 = hf[1], fev0 = hf[2], fev1 = hf[3], fvn = hf[4];
   const bool vbad = hf[5] != 0.f;
   const float fpd = (float)a.post_div;
+  const float ifpd = __frcp_rn(fabsf(fpd)) * 1.000001f;
   __syncthreads();
+  I4STAMP(6);
   // ---- seeds: the int8 lower bound of a row under the NEW vectors is a lower bound of the best exact score
   {
     float seed = -INFINITY;
     if (hot_row >= 0) {
       float Us, Ls;
-      bc_r8_interval<MODE>(a.r8 + (size_t)hot_row * a.rb, dig8, hdr8, a.g4, a.rb, fpd, Us, Ls);
+      if (seed_early) bc_r8_interval_regs<MODE>(sw, dig8, hdr8, a.g4, fpd, Us, Ls);
+      else bc_r8_interval<MODE>(a.r8 + (size_t)hot_row * a.rb, dig8, hdr8, a.g4, a.rb, fpd, Us, Ls);
       if (Ls == Ls) seed = Ls;
     }
     if (ring_row >= 0) {                               // (wave 0 only)
@@ -298,8 +348,8 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
   }
   __syncthreads();
   const float theta0 = fmaxf(fmaxf(sl[0], sl[1]), fmaxf(sl[2], sl[3]));
+  I4STAMP(1);
 
-  const long long tstride = (long long)gridDim.x * 4;
   float wave_l = -INFINITY;                            // best 4-bit lower bound of the tiles this wave has finished
   int np = 0;                                          // rows parked by this wave
   // ---- level 2: the parked rows, one per lane, from their int8 records
@@ -331,38 +381,8 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
     __builtin_amdgcn_wave_barrier();
     np = 0;
   };
-  for (; t < a.ptiles; t += tstride) {
-    const bc_i4* __restrict__ p = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)t * SP8 * BC_ITILE) + lane;
-    int acc[4][NV];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int c = 0; c < NV; ++c) acc[j][c] = 0;
-    const uint2 cq = rq;                               // this tile's codes x 4 rows
-    for (int g0 = 0; g0 < SP8; g0 += U) {
-      const bool more = g0 + U < SP8;
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p + (size_t)(g0 + U + u) * 64);
-      } else if (t + tstride < a.ptiles) {
-        const long long tn = t + tstride;
-        const bc_i4* __restrict__ pn = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)tn * SP8 * BC_ITILE) + lane;
-#pragma unroll
-        for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(pn + (size_t)u * 64);
-        rq = reinterpret_cast<const uint2*>(a.rowq4 + tn * BC_ITILE)[lane];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bc_i4 dg = *reinterpret_cast<const bc_i4*>(&dig4[g0 + u][0]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int c = 0; c < NV; ++c) acc[j][c] = __builtin_amdgcn_sdot8(x[u][j], dg[c], acc[j][c], false);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = y[u];
-    }
-    // ---- per-row intervals (4 rows per lane)
+  // ---- per-row intervals of a finished tile (4 rows per lane), branch-free: dead / uncertain rows are patched in at the end
+  auto epilogue = [&](long long tt, const uint2 cq, const int (&acc)[4][NV]) __attribute__((always_inline)) {
     const unsigned codes[4] = {cq.x & 0xffffu, cq.x >> 16, cq.y & 0xffffu, cq.y >> 16};
     const float theta = fmaxf(theta0, wave_l);
     float Ub[4];
@@ -371,26 +391,22 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned dc = codes[j] >> 8;
-      Ub[j] = -INFINITY;
-      if (dc != BC_I4_DEAD) {
-        float Lb;
-        if (vbad || dc == BC_I4_UNCERTAIN) {
-          Ub[j] = INFINITY;
-          Lb = -INFINITY;
-        } else {
-          const float sc = (float)(codes[j] & 0xffu) * (1.f / 1024.f), dr = (float)dc * (1.f / 512.f);      // exact
-          // u^.v^ : exact integers (|16 A0 + A1| < 2^24), scaled in fp32 (relative error < 2e-7, covered by the 4e-7 terms)
-          const float s0 = sc * fvs0 * (16.f * (float)acc[j][0] + (float)acc[j][1]);
-          const float s1 = (MODE == 0) ? sc * fvs1 * (16.f * (float)acc[j][NV - 2] + (float)acc[j][NV - 1]) : 0.f;
-          const float delta0 = (dr * fvn + (1.f + dr) * fev0) * 1.00001f + 4e-7f * fabsf(s0) + 1e-12f;
-          const float delta1 = (MODE == 0) ? (dr * fvn + (1.f + dr) * fev1) * 1.00001f + 4e-7f * fabsf(s1) + 1e-12f : 0.f;
-          bc_score_interval_f32<MODE>(s0, s1, delta0, delta1, fpd, Ub[j], Lb);
-        }
-        tl = fmaxf(tl, Lb);
-        any |= Ub[j] >= theta;
-      }
+      const float sc = (float)(codes[j] & 0xffu) * (1.f / 1024.f), dr = (float)dc * (1.f / 512.f);      // exact
+      // u^.v^ : exact integers (|16 A0 + A1| < 2^24), scaled in fp32 (relative error < 2e-7, covered by the 4e-7 terms)
+      const float s0 = sc * fvs0 * (16.f * (float)acc[j][0] + (float)acc[j][1]);
+      const float s1 = (MODE == 0) ? sc * fvs1 * (16.f * (float)acc[j][NV - 2] + (float)acc[j][NV - 1]) : 0.f;
+      const float delta0 = (dr * fvn + (1.f + dr) * fev0) * 1.00001f + 4e-7f * fabsf(s0) + 1e-12f;
+      const float delta1 = (MODE == 0) ? (dr * fvn + (1.f + dr) * fev1) * 1.00001f + 4e-7f * fabsf(s1) + 1e-12f : 0.f;
+      float Uj, Lj;
+      bc_score_interval_f32_hw<MODE>(s0, s1, delta0, delta1, fpd, ifpd, Uj, Lj);
+      const bool dead = dc == BC_I4_DEAD, unc = vbad || dc == BC_I4_UNCERTAIN;
+      Uj = dead ? -INFINITY : (unc ? INFINITY : Uj);
+      Lj = (dead || unc) ? -INFINITY : Lj;
+      Ub[j] = Uj;
+      tl = fmaxf(tl, Lj);
+      any |= Uj >= theta;                              // (-inf >= theta only when theta is -inf: filtered below)
     }
-    // ---- rows whose upper bound reaches theta (a lower bound of the best exact score) are parked for level 2
+    // rows whose upper bound reaches theta (a lower bound of the best exact score) are parked for level 2
     if (__ballot(any) != 0ull) {
       const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -399,15 +415,74 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
         const int cnt = __popcll(m);
         if (cnt != 0) {                                // (wave-uniform)
           if (np + cnt > BC_I4_PARK) refine();         // (cnt <= 64 <= BC_I4_PARK)
-          if ((m >> lane) & 1ull) park[wave][np + __popcll(m & below)] = (int)(t * BC_ITILE + 4 * lane + j);
+          // (Tried: touching the row's int8 record here, so that level 2 finds it in the L2 -- loads return in order, so the
+          // cold touch holds up the next batch: stream phase 131k -> 178k cycles.)
+          if ((m >> lane) & 1ull) park[wave][np + __popcll(m & below)] = (int)(tt * BC_ITILE + 4 * lane + j);
           np += cnt;
         }
       }
     }
     wave_l = fmaxf(wave_l, bc_wave_max_f32_all(tl));
+  };
+  // ---- the stream, as a sequence of batches (tile, first k-group) consumed from two register buffers in turn: while one is
+  // consumed (and, at a tile's end, its rows are evaluated) the other one's loads are in flight; nothing is copied
+  auto issue = [&](bc_i4 (&buf)[U], long long tt, int g0) __attribute__((always_inline)) {
+    const bc_i4* __restrict__ p = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)tt * SP8 * BC_ITILE) + (size_t)g0 * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+  };
+  int acc[4][NV];
+  auto zero = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc[j][c] = 0;
+  };
+  auto dots = [&](const bc_i4 (&buf)[U], int g0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bc_i4 dg = *reinterpret_cast<const bc_i4*>(&dig4[g0 + u][0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < NV; ++c) acc[j][c] = __builtin_amdgcn_sdot8(buf[u][j], dg[c], acc[j][c], false);
+    }
+  };
+  zero();
+  long long tc = t;                                    // the batch being consumed: tile, first k-group
+  int gc = 0;
+  bool primed = true;                                  // (the second batch is already in flight)
+  while (tc < a.ptiles) {
+    // --- half 1: consume x, y in flight
+    long long tn = tc;
+    int gn = gc + U;
+    if (gn >= SP8) { gn = 0; tn = tc + tstride; }
+    if (tn < a.ptiles && !primed) {
+      if (gn == 0) rq_next = reinterpret_cast<const uint2*>(a.rowq4 + tn * BC_ITILE)[lane];
+      issue(y, tn, gn);
+    }
+    primed = false;
+    dots(x, gc);
+    if (gc + U >= SP8) { epilogue(tc, rq, acc); zero(); rq = rq_next; }
+    tc = tn; gc = gn;
+    if (tc >= a.ptiles) break;
+    // --- half 2: consume y, x in flight
+    tn = tc;
+    gn = gc + U;
+    if (gn >= SP8) { gn = 0; tn = tc + tstride; }
+    if (tn < a.ptiles) {
+      if (gn == 0) rq_next = reinterpret_cast<const uint2*>(a.rowq4 + tn * BC_ITILE)[lane];
+      issue(x, tn, gn);
+    }
+    dots(y, gc);
+    if (gc + U >= SP8) { epilogue(tc, rq, acc); zero(); rq = rq_next; }
+    tc = tn; gc = gn;
   }
+  I4STAMP(2);
   if (np > 0) refine();
+  I4STAMP(3);
   __syncthreads();
+  I4STAMP(4);
   // ---- the block's list: the rows in play whose int8 upper bound reaches the block's best int8 lower bound
   const int n = s_n;
   const unsigned long long bk = s_best;
@@ -438,4 +513,5 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
     if (bk != 0ull && blockIdx.x < BC_I4_SEEDS) a.hot[blockIdx.x] = (long long)(unsigned)(bk & 0xffffffffull);
     if (s_refined > 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 12), (unsigned long long)s_refined);
   }
+  I4STAMP(5);
 }

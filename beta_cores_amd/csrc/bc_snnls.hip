@@ -1155,8 +1155,9 @@ extern "C" int bc_snnls_destroy(bc_snnls* h) {
 }
 
 // Two-level pre-filter (bc_prefilter_i4.h) wanted?  BC_PREFILTER=4 forces it, =8 keeps the one-level int8 sweep; by default it
-// is used from BC_TWO_LEVEL_MIN_ROWS rows (where the halved stream outweighs the refine kernel's launch).  S <= 256.
-#define BC_TWO_LEVEL_MIN_ROWS (1LL << 62)
+// is used from BC_TWO_LEVEL_MIN_ROWS rows: measured per step at S = 100 (tools/two_level_probe.py, us, two-level / one-level):
+// 1.25M rows 43.4 / 42.5, 2.5M 53.6 / 62, 5M 72.5 / 102, 10M 114 / 177.  S <= 256.
+#define BC_TWO_LEVEL_MIN_ROWS 2000000LL
 static bool bc_want_two_level(int preq, long long n_rows, int s) {
   if (s > 256 || n_rows <= 0) return false;
   if (preq == 4) return true;

@@ -44,6 +44,13 @@ def make(form):
         os.environ.pop('BC_PREFILTER', None)
 
 
+for form in ('8', '4', '8', '4'):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sv = make(form)
+    torch.cuda.synchronize()
+    print('solver create, BC_PREFILTER=%s: %.2f ms' % (form, 1e3 * (time.perf_counter() - t0)), flush=True)
+    del sv
 sv = make('4')
 print('form', sv._eng.prefilter_form, 'rows', N, flush=True)
 prev = (0, 0, 0)
