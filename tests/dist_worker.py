@@ -37,7 +37,7 @@ def main():
     mode, out = sys.argv[1], sys.argv[2]
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    if mode in ('gpu_nccl1', 'gpu_nccl1_torch', 'gpu_nccl1_overflow', 'gpu_nccl1_bcores'):
+    if mode in ('gpu_nccl1', 'gpu_nccl1_torch', 'gpu_nccl1_overflow', 'gpu_nccl1_overflow4', 'gpu_nccl1_bcores'):
         import torch
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
@@ -74,13 +74,13 @@ def main():
         idx, val = s.sparse_weights()
         res['idx'], res['val'], res['err'] = idx, val, np.array(s.error())
         res['w_dense'] = s.weights()
-    elif mode in ('gpu_overflow', 'gpu_nccl1_overflow'):
+    elif mode in ('gpu_overflow', 'gpu_nccl1_overflow', 'gpu_overflow4', 'gpu_nccl1_overflow4'):
         # a pre-filter whose candidate lists overflow (200 exact copies of one row, capacity 2): the step is marked on
         # the device and redone with the exact sweep -- through the host-driven exchange (two ranks, one GPU, gloo)
         # and inside bc_snnls_build with the RCCL all-gather in the loop (one rank)
-        os.environ['BC_PREFILTER'] = '8'
+        os.environ['BC_PREFILTER'] = '4' if mode.endswith('4') else '8'      # (4: the two-level form, same mirror behind a 4-bit level)
         os.environ['BC_PREFILTER_CAP'] = '2'
-        if mode == 'gpu_nccl1_overflow':
+        if mode.startswith('gpu_nccl1_overflow'):
             import torch
             os.environ['BC_FORCE_EXCHANGE'] = '1'
             stream = torch.cuda.Stream()
@@ -96,8 +96,10 @@ def main():
         for nm, cls in (('giga', bc.snnls.GIGA), ('fw', bc.snnls.FrankWolfe)):
             s = cls(phi[lo:hi].T, b, comm=comm, row_offset=lo)
             assert s._eng.prefilter == 8
-            if mode == 'gpu_nccl1_overflow':
+            if mode.startswith('gpu_nccl1_overflow'):
                 assert s._eng.native_exchange
+            if mode.endswith('4'):
+                assert s._eng.prefilter_form == 3
             s.build(12)
             s.build(8)
             idx, val = s.sparse_weights()

@@ -43,7 +43,7 @@ t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() +
 cases = bad = 0
 falls = 0
 while time.time() < t_end:
-    n = int(10 ** rng.uniform(0, 5.3)); s = rng.randint(1, 131); kind = rng.randint(6)
+    n = int(10 ** rng.uniform(0, 5.3)); s = rng.randint(1, 131) if rng.rand() < 0.85 else rng.randint(131, 270); kind = rng.randint(6)
     phi = make(rng, n, s, kind)
     if not np.isfinite(phi).all() or (np.linalg.norm(phi, axis=1) == 0).any():
         continue
@@ -53,7 +53,7 @@ while time.time() < t_end:
         ref = run(cls, phi, steps, 0)
     except ValueError:
         continue
-    for pref in (8, 'lists', 'bb', 16, 32):
+    for pref in (8, 'lists', 'bb', 4, 16, 32):
         got = run(cls, phi, steps, pref)
         ok = all(np.array_equal(a, b) for a, b in zip(ref[0], got[0])) and np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2]) and ref[3] == got[3]
         falls += got[4][2]
@@ -61,5 +61,5 @@ while time.time() < t_end:
             bad += 1
             print('MISMATCH n=%d s=%d kind=%d alg=%s steps=%d pref=%s' % (n, s, kind, cls.__name__, steps, pref), ref[0][0][:10], got[0][0][:10])
     cases += 1
-print('fuzz: %d problems x 5 forms (int8 two-pass, + block lists, branch-and-bound; fp16; fp32), %d mismatches, %d fp64 fallbacks' % (cases, bad, falls))
+print('fuzz: %d problems x 6 forms (int8 two-pass, + block lists, branch-and-bound, two-level 4-bit + int8; fp16; fp32), %d mismatches, %d fp64 fallbacks' % (cases, bad, falls))
 sys.exit(1 if bad else 0)

@@ -108,7 +108,7 @@ def test_native_colsum_matches_local_sum(tmp_path):
     assert np.array_equal(r0['colsum_native'], r0['colsum_local'])
 
 
-@pytest.mark.parametrize('mode,world', [('gpu_overflow', 2), ('gpu_nccl1_overflow', 1)])
+@pytest.mark.parametrize('mode,world', [('gpu_overflow', 2), ('gpu_nccl1_overflow', 1), ('gpu_overflow4', 2), ('gpu_nccl1_overflow4', 1)])
 def test_prefilter_overflow_across_ranks(tmp_path, mode, world):
     """A pre-filter overflow on ANY rank makes every rank redo that step with the exact fp64 sweep (the marker
     travels in the gathered records): results equal the single-rank fp64-sweep run, in the fused loop over both

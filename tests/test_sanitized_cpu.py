@@ -23,6 +23,15 @@ def build(tmp_path, src, extra=()):
     return exe
 
 
+def build_cxx(tmp_path, src, extra=()):
+    exe = str(tmp_path / (os.path.splitext(src)[0] + '_san'))
+    cmd = ['g++', '-std=c++17', '-O1', '-mfma', '-ffp-contract=off', '-Wall', '-Werror', '-Wno-unused-function', '-Wno-unknown-pragmas'] + SAN + list(extra) + \
+          ['-I', os.path.join(ROOT, 'beta_cores_amd', 'csrc'), os.path.join(ROOT, 'tests', src), '-o', exe, '-lm']
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
 def run_clean(exe, args, timeout=600):
     res = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=timeout, env=ENV)
     assert 'AddressSanitizer' not in res.stderr and 'runtime error' not in res.stderr, res.stderr[-3000:]
@@ -33,6 +42,13 @@ def test_k1_math_bodies_under_asan_ubsan(tmp_path):
     """bc_k1_math.h incl. NaNs with payloads: their mantissa bits must not index past the 257-entry log table."""
     res = run_clean(build(tmp_path, 'k1_math_harness.c'), ['200000'])
     assert res.returncode == 0 and 'special ok' in res.stdout, res.stdout + res.stderr
+
+
+def test_sweep_vector_quantisers_under_asan_ubsan(tmp_path):
+    """bc_i4_quant.h / bc_i8_quant.h compiled for the host: digit ranges, Q = 16 d0 + d1 (128 d0 + d1), the half-step error of
+    every element and the header bounds the sweeps' intervals rest on -- 4 000 random vectors, S = 1..260, both modes."""
+    res = run_clean(build_cxx(tmp_path, 'i4_quant_harness.cpp'), ['2000'])
+    assert res.returncode == 0 and res.stdout.startswith('ok 4000'), res.stdout + res.stderr
 
 
 def test_np_sum_restatement_under_asan_ubsan(tmp_path):
