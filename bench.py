@@ -871,6 +871,17 @@ def main():
         detail.update({'solver_init': init_parts, 'step_stages': step_diag, 'setup_s': t_setup, 'posterior_gram_cold_wall_ms': 1e3 * t_post,
                        'posterior_gram': k4e})
 
+    # ---------------- the host path (hilbert.py:11 takes an ndarray): upload + K1 pipelined, wall time to the first iteration.
+    # (Before the legs that run NumPy / BLAS on the host: after them the runtime's pinning of the pageable 10 GB source takes
+    # 0.5-1 s longer on some boxes -- 1 026 against 191 ms for the same construction, profiles/r05_notes.md.)
+    Z_host = None
+    if rank == 0 and world == 1 and not args.no_host:
+        Z_host = Z.cpu().numpy()
+        fh = from_host_leg(bc, ctx, barrier, Z_host, theta, S, model, cls, f_tr, args)
+        out['roofline']['from_host'] = fh
+        # the survey's M = 100 run: steps 2..100 of the coreset built from the host array (list lengths 1..100, wall clock)
+        out['ms_per_step_M100'] = sig((fh['M100_ms'] - fh['first_iter_ms']) / 99.0)
+
     # ---------------- the SURVEY 8(d) formulation, driver-timed too: the exact fp64 sweep (8*N*S + 8*N bytes per step)
     if rank == 0 and world == 1 and not args.no_extra:
         f64 = fp64_sweep_leg(bc, ctx, alg, cls, barrier, n_local, S, args)
@@ -912,15 +923,6 @@ def main():
                 kernels.append(kentry('K1 store-free beta-%s N=%d D=%d' % (e['model'].split('/')[0], e['N'], e['D']), e['k1_store_free_kernel_ms'],
                                       e['roofline_hbm']['bytes_per_launch'], 2.0 * e['N'] * e['D'] * e['S'], e['gradients']))
         detail['cpu_loops'] = cpu_loops
-
-    # ---------------- the host path (hilbert.py:11 takes an ndarray): upload + K1 pipelined, wall time to the first iteration
-    Z_host = None
-    if rank == 0 and world == 1 and not args.no_host:
-        Z_host = Z.cpu().numpy()
-        fh = from_host_leg(bc, ctx, barrier, Z_host, theta, S, model, cls, f_tr, args)
-        out['roofline']['from_host'] = fh
-        # the survey's M = 100 run: steps 2..100 of the coreset built from the host array (list lengths 1..100, wall clock)
-        out['ms_per_step_M100'] = sig((fh['M100_ms'] - fh['first_iter_ms']) / 99.0)
 
     # ---------------- CPU baseline (rank 0, N=1 launch only): the NumPy oracle
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -584,9 +584,6 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
     fa.sp4 = p->sp4;
     fa.g4 = p->g4;
     fa.rb = p->rb;
-    // (measured: 122.6-124.1 us per step with the early request against 113.3-117.0 without, N = 10M -- 489 blocks asking for the
-    // same 288 lines at once, in front of their second batch; kept for A/B)
-    fa.seed_early = getenv("BC_I4_SEED_EARLY") ? atoi(getenv("BC_I4_SEED_EARLY")) : 0;
 #define BC_I4_LAUNCH(MODE, UU) hipLaunchKernelGGL((k_sweep_i4<MODE, UU>), dim3(p->grid1), dim3(256), 0, ctx->stream, fa)
 #define BC_I4_BY_U(MODE)                                                                          \
     switch (p->i4_u) {                                                                            \

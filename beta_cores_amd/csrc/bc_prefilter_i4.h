@@ -59,7 +59,6 @@ struct I4Args {
   long long ptiles;
   double post_div;
   int s, sp8, sp4, g4, rb;       // sp4: k-groups of the int8 digit record; g4 = ceil(S / 4); rb: bytes of an int8 record
-  int seed_early;                // request the seeds' int8 records between the first two batches (A/B: BC_I4_SEED_EARLY)
 };
 
 __device__ __forceinline__ int bc_f32_ord(float f) {        // order-preserving map float -> int (for LDS atomicMax)
@@ -67,28 +66,6 @@ __device__ __forceinline__ int bc_f32_ord(float f) {        // order-preserving 
   return b >= 0 ? b : b ^ 0x7fffffff;
 }
 __device__ __forceinline__ float bc_ord_f32(int o) { return __builtin_bit_cast(float, o >= 0 ? o : o ^ 0x7fffffff); }
-
-// The same for a record of exactly 128 bytes that the caller already holds in registers (requested early: the seeds).
-template <int MODE>
-__device__ __forceinline__ void bc_r8_interval_regs(const bc_i4 (&w)[8], const int (*dig8)[4], const float* hdr, int g4, float fpd, float& U, float& L) {
-  int a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int g = 4 * u + j;
-      if (g < g4) {
-        const bc_i4 dg = *reinterpret_cast<const bc_i4*>(&dig8[g][0]);
-        a0 = __builtin_amdgcn_sdot4(w[u][j], dg[0], a0, false);
-        a1 = __builtin_amdgcn_sdot4(w[u][j], dg[1], a1, false);
-        if (MODE == 0) a2 = __builtin_amdgcn_sdot4(w[u][j], dg[2], a2, false);
-      }
-    }
-  const bc_hq2 rq = __builtin_bit_cast(bc_hq2, w[7][3]);
-  const float sc = (float)rq[0], dl = (float)rq[1];
-  if (dl < 0.f) { U = -INFINITY; L = -INFINITY; return; }      // dead row
-  bc_i8_row_bounds<MODE>(sc, dl, a0, a1, a2, hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] != 0.f, fpd, U, L);
-}
 
 // (U, L) of one row from its int8 record, against the int8 digit table in LDS.  hdr = the record's six header floats.
 template <int MODE>
@@ -285,57 +262,56 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
   // the first tile's loads and the seed rows' numbers do not depend on the prologue: in flight before it
   long long t = (long long)blockIdx.x * 4 + wave;
   const long long tstride = (long long)gridDim.x * 4;
-  // the seed rows' numbers first.  (seed_early, opt-in: their int8 records requested between the first and the second batch, so
-  // that they land with the stream instead of costing the prologue a dependent round trip -- measured SLOWER, bc_prefilter.hip)
+  // the seed rows' numbers first
   const long long hot_row = a.hot[threadIdx.x];                                              // (BC_I4_SEEDS == blockDim.x)
   const long long ring_row = (threadIdx.x < BC_I4_HOT) ? a.hot[BC_I4_SEEDS + threadIdx.x] : -1;
   bc_i4 x[U], y[U];
-  bc_i4 sw[8];                                          // this thread's seed record (rb == 128: the usual case)
-  const bool seed_early = a.rb == 128 && a.seed_early != 0;
   uint2 rq = make_uint2(0xffffffffu, 0xffffffffu), rq_next = rq;    // (dead)
-  if (t < a.ptiles) {
-    rq = reinterpret_cast<const uint2*>(a.rowq4 + t * BC_ITILE)[lane];
-    const bc_i4* __restrict__ p0 = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)t * SP8 * BC_ITILE) + lane;
-#pragma unroll
-    for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p0 + (size_t)u * 64);
-  }
-  if (seed_early) {
-    const bc_i4* __restrict__ ps = reinterpret_cast<const bc_i4*>(a.r8 + (size_t)(hot_row >= 0 ? hot_row : 0) * 128);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) sw[u] = ps[u];
-  }
-  if (t < a.ptiles) {
-    // ... and the second batch: two batches per wave cover the prologue's two dependent round trips
-    const long long t2 = (U >= SP8) ? t + tstride : t;
-    const int g2 = (U >= SP8) ? 0 : U;
-    if (t2 < a.ptiles) {
-      if (g2 == 0) rq_next = reinterpret_cast<const uint2*>(a.rowq4 + t2 * BC_ITILE)[lane];
-      const bc_i4* __restrict__ p1 = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)t2 * SP8 * BC_ITILE) + (size_t)g2 * 64 + lane;
-#pragma unroll
-      for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p1 + (size_t)u * 64);
-    }
-  }
-  // ---- prologue: both digit records into LDS
-  for (int g = threadIdx.x; g < SP8; g += blockDim.x)
-    *reinterpret_cast<bc_i4*>(&dig4[g][0]) = reinterpret_cast<const bc_i4*>(a.qv4)[g];
-  for (int g = threadIdx.x; g < a.sp4; g += blockDim.x)
-    *reinterpret_cast<bc_i4*>(&dig8[g][0]) = reinterpret_cast<const bc_i4*>(a.qv8)[g];
-  if (threadIdx.x < 8) hdr8[threadIdx.x] = reinterpret_cast<const float*>(a.qv8 + 4 * a.sp4)[threadIdx.x];
-  if (threadIdx.x == 0) { s_n = 0; s_best = 0ull; s_umax = bc_f32_ord(-INFINITY); s_on = 0; s_refined = 0; }
+  // the digit records are requested BEFORE the tiles (loads return in order): the barrier that publishes them in LDS then
+  // waits for 2 KB, not for the wave's first 26 KB -- it is an LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier; a
+  // __syncthreads() carries a vmcnt(0)), and the seeds' records are requested ~10 us earlier, right behind the tiles
+  bc_i4 d4v = {0, 0, 0, 0}, d8v = {0, 0, 0, 0};
+  float h8v = 0.f;
+  if ((int)threadIdx.x < SP8) d4v = reinterpret_cast<const bc_i4*>(a.qv4)[threadIdx.x];             // (SP8 <= 48, sp4 <= 72 < blockDim)
+  if ((int)threadIdx.x < a.sp4) d8v = reinterpret_cast<const bc_i4*>(a.qv8)[threadIdx.x];
+  if (threadIdx.x < 8) h8v = reinterpret_cast<const float*>(a.qv8 + 4 * a.sp4)[threadIdx.x];
   const float* hf = reinterpret_cast<const float*>(a.qv4 + 4 * SP8);
   const float fvs0 = hf[0], fvs1 = hf[1], fev0 = hf[2], fev1 = hf[3], fvn = hf[4];
   const bool vbad = hf[5] != 0.f;
+  // (unconditional, clamped to a valid tile: inside an `if` the compiler can no longer count the loads behind the digit
+  // records and waits for everything before it touches them)
+  {
+    const long long ta = t < a.ptiles ? t : 0;
+    const long long t2r = (U >= SP8) ? t + tstride : t;
+    const int g2 = (U >= SP8) ? 0 : U;
+    const long long tb = t2r < a.ptiles ? t2r : 0;
+    const uint2 rqa = reinterpret_cast<const uint2*>(a.rowq4 + ta * BC_ITILE)[lane];
+    const uint2 rqb = reinterpret_cast<const uint2*>(a.rowq4 + tb * BC_ITILE)[lane];
+    const bc_i4* __restrict__ p0 = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)ta * SP8 * BC_ITILE) + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p0 + (size_t)u * 64);
+    // ... and the second batch: two batches per wave cover the prologue
+    const bc_i4* __restrict__ p1 = reinterpret_cast<const bc_i4*>(a.u4 + (size_t)tb * SP8 * BC_ITILE) + (size_t)g2 * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(p1 + (size_t)u * 64);
+    if (t < a.ptiles) rq = rqa;
+    if (g2 == 0 && t2r < a.ptiles) rq_next = rqb;
+  }
+  // ---- prologue: both digit records into LDS
+  if ((int)threadIdx.x < SP8) *reinterpret_cast<bc_i4*>(&dig4[threadIdx.x][0]) = d4v;
+  if ((int)threadIdx.x < a.sp4) *reinterpret_cast<bc_i4*>(&dig8[threadIdx.x][0]) = d8v;
+  if (threadIdx.x < 8) hdr8[threadIdx.x] = h8v;
+  if (threadIdx.x == 0) { s_n = 0; s_best = 0ull; s_umax = bc_f32_ord(-INFINITY); s_on = 0; s_refined = 0; }
   const float fpd = (float)a.post_div;
   const float ifpd = __frcp_rn(fabsf(fpd)) * 1.000001f;
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // LDS-only barrier: the tiles stay in flight
   I4STAMP(6);
   // ---- seeds: the int8 lower bound of a row under the NEW vectors is a lower bound of the best exact score
   {
     float seed = -INFINITY;
     if (hot_row >= 0) {
       float Us, Ls;
-      if (seed_early) bc_r8_interval_regs<MODE>(sw, dig8, hdr8, a.g4, fpd, Us, Ls);
-      else bc_r8_interval<MODE>(a.r8 + (size_t)hot_row * a.rb, dig8, hdr8, a.g4, a.rb, fpd, Us, Ls);
+      bc_r8_interval<MODE>(a.r8 + (size_t)hot_row * a.rb, dig8, hdr8, a.g4, a.rb, fpd, Us, Ls);
       if (Ls == Ls) seed = Ls;
     }
     if (ring_row >= 0) {                               // (wave 0 only)

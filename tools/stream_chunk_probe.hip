@@ -29,12 +29,12 @@ __global__ __launch_bounds__(256) void k_read(const i4* __restrict__ p, size_t n
 }
 
 int main() {
-  const size_t n_kb = 1016000;          // ~1.04 GB
+  const size_t n_kb = 527280;           // ~0.54 GB (the 4-bit mirror at N = 10M)
   i4* p; int* out;
   hipMalloc(&p, n_kb * 1024); hipMalloc(&out, 4);
   hipMemset(p, 1, n_kb * 1024);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  const int chunks[] = {25, 50, 100, 200, 400, 25, 100};
+  const int chunks[] = {13, 25, 26, 52, 13, 104, 25};
   for (int ci = 0; ci < 7; ++ci) {
     for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_read, dim3(512), dim3(256), 0, 0, p, n_kb, chunks[ci], out);
     hipEventRecord(a);
