@@ -256,7 +256,8 @@ int bc_snnls_create(bc_ctx* ctx, bc_phi* phi, const double* b, int alg, double n
 int bc_snnls_destroy(bc_snnls* h);
 /* *on = 0, or the storage precision (8 / 16 / 32 bits per element) of the mirror of Phi this solver's sweeps
  * stream through the reduced-precision pre-filter (bc_prefilter.hip): int8 for shards of >= 163840 rows by
- * default; BC_PREFILTER=0 / 8 / 16 / 32 in the environment forces it.  Selections and weights are identical either way
+ * default -- from 2 000 000 rows behind a 4-bit first level (form 3 below; *on still says 8: the int8 digits are what bounds the
+ * rows it passes on) --; BC_PREFILTER=0 / 4 / 8 / 16 / 32 in the environment forces it.  Selections and weights are identical either way
  * (candidates are rescored from the fp64 Phi with the arithmetic of the fp64 sweep). */
 int bc_snnls_prefilter_active(const bc_snnls* h, int* on);
 /* *form = 0: fp64 sweeps; 1: two-pass pre-filter (reduced-precision sweep, then one block rescoring the candidates from the
