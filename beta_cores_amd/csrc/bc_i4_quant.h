@@ -7,7 +7,7 @@
 //   | v^ - v |_2 <= sqrt(S) * vstep / 2.
 // Unlike the int8 record (bc_i8_quant.h) GIGA's second vector gets both digits too: with the 4-bit rows' delta ~ 0.1 the
 // slope term of the interval, (|s0| + d0) a d1 / c^(3/2), is no longer negligible and a one-digit v1 (vstep = max / 7) tripled
-// the first level's candidates (scratch/sim_two_level.py).
+// the first level's candidates (tools/sim_two_level.py).
 //
 // Record layout (ints): [SP8][4] packed digits of k-group g (samples 8g .. 8g+7, sample 8g+j in bits 4j .. 4j+3)
 //   = {v0 d0, v0 d1, v1 d0, v1 d1}, then BC_I4Q_HDR floats: fvs0, fvs1 (steps), fev0, fev1 (||v^ - v|| bounds, rounded up),
