@@ -263,8 +263,9 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
   long long t = (long long)blockIdx.x * 4 + wave;
   const long long tstride = (long long)gridDim.x * 4;
   // the seed rows' numbers first
-  const long long hot_row = a.hot[threadIdx.x];                                              // (BC_I4_SEEDS == blockDim.x)
-  const long long ring_row = (threadIdx.x < BC_I4_HOT) ? a.hot[BC_I4_SEEDS + threadIdx.x] : -1;
+  // one seed per thread: the strongest rows of the first 224 sweep blocks and the ring's 32 (a second evaluation by wave 0 for
+  // the ring kept the whole block at its second barrier: every wave now does exactly one)
+  const long long hot_row = a.hot[threadIdx.x < BC_I4_SEEDS - BC_I4_HOT ? threadIdx.x : threadIdx.x + BC_I4_HOT];      // (BC_I4_SEEDS == blockDim.x)
   bc_i4 x[U], y[U];
   uint2 rq = make_uint2(0xffffffffu, 0xffffffffu), rq_next = rq;    // (dead)
   // the digit records are requested BEFORE the tiles (loads return in order): the barrier that publishes them in LDS then
@@ -313,11 +314,6 @@ __global__ __launch_bounds__(256) void k_sweep_i4(I4Args a) {
       float Us, Ls;
       bc_r8_interval<MODE>(a.r8 + (size_t)hot_row * a.rb, dig8, hdr8, a.g4, a.rb, fpd, Us, Ls);
       if (Ls == Ls) seed = Ls;
-    }
-    if (ring_row >= 0) {                               // (wave 0 only)
-      float Us, Ls;
-      bc_r8_interval<MODE>(a.r8 + (size_t)ring_row * a.rb, dig8, hdr8, a.g4, a.rb, fpd, Us, Ls);
-      if (Ls == Ls) seed = fmaxf(seed, Ls);
     }
     seed = bc_wave_max_f32_all(seed);
     if (lane == 0) sl[wave] = seed;
