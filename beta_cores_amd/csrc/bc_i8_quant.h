@@ -22,18 +22,34 @@ struct bc_i8q_scalars {
   bool vbad;
 };
 
+// (Round 5: ONE fp64 division per vector -- r = 1 / max|v| -- instead of two (step = max / 16256, then 1 / step): a division is a
+// ~500-cycle dependent sequence and the single-block step kernels paid eight of them per step for the two digit records
+// (tools/fin_stamps.py).  step = max * fl(1 / 16256) and inv = 16256 * r: inv * step = 1 to within 4e-16, and the digit rint(val * inv)
+// is still the nearest integer of a value within 1e-12 of val / step -- the bound below only needs that.)
 __device__ __forceinline__ bc_i8q_scalars bc_i8q_steps(double vmax0, double vmax1) {
   bc_i8q_scalars q;
   // a NaN / inf in v makes every score NaN in the fp64 kernel: hand all rows over (delta = inf in the sweep)
   q.vbad = !(vmax0 < INFINITY) || !(vmax1 < INFINITY) || vmax0 != vmax0 || vmax1 != vmax1;
-  q.vstep0 = vmax0 / 16256.;          // v0: 14 bits + sign in two digits
-  q.vstep1 = vmax1 / 127.;            // v1: one digit
-  // digits are rint(val * inv): against rint(val / step) the product carries one more rounding (relative 2^-53), i.e. the
-  // digit is the nearest integer of a value within 1e-12 of val / step -- |Q step - val| <= step / 2 * (1 + 1e-11), far
-  // inside the 1.00001 the sweep's error bound is inflated by
-  q.inv0 = (q.vstep0 > 0. && !q.vbad) ? 1. / q.vstep0 : 0.;
-  q.inv1 = (q.vstep1 > 0. && !q.vbad) ? 1. / q.vstep1 : 0.;
+  q.vstep0 = vmax0 * (1. / 16256.);   // v0: 14 bits + sign in two digits
+  q.vstep1 = vmax1 * (1. / 127.);     // v1: one digit
+  // digits are rint(val * inv): |Q step - val| <= step / 2 * (1 + 1e-11), far inside the 1.00001 the sweep's error bound is
+  // inflated by
+  const double r0 = (vmax0 > 0. && !q.vbad) ? 1. / vmax0 : 0., r1 = (vmax1 > 0. && !q.vbad) ? 1. / vmax1 : 0.;
+  q.inv0 = (q.vstep0 > 0.) ? 16256. * r0 : 0.;      // (a denormal max whose step underflows to 0: no digits, as before)
+  q.inv1 = (q.vstep1 > 0.) ? 127. * r1 : 0.;
   return q;
+}
+
+// the digits of ONE element: (d0, d1) of the score vector's value, e of the second vector's (GIGA)
+__device__ __forceinline__ void bc_i8q_elem0(double val, const bc_i8q_scalars& q, int& d0, int& d1) {
+  int Q = (int)rint(val * q.inv0);
+  Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
+  d0 = (int)rint((double)Q * 0.0078125);       // Q / 128, exact
+  d1 = Q - 128 * d0;
+}
+__device__ __forceinline__ int bc_i8q_elem1(double val, const bc_i8q_scalars& q) {
+  const int Q = (int)rint(val * q.inv1);
+  return Q > 127 ? 127 : (Q < -127 ? -127 : Q);
 }
 
 // the four packed words of k-group g (samples 4g .. 4g+3)
@@ -44,21 +60,11 @@ __device__ __forceinline__ void bc_i8q_group(const double* __restrict__ v, int S
   for (int j = 0; j < 4; ++j) {
     const int k = 4 * g + j;
     if (k < S && !q.vbad) {
-#pragma unroll
-      for (int vv = 0; vv < (MODE == 0 ? 2 : 1); ++vv) {
-        const double val = (MODE == 0) ? v[2 * k + vv] : v[k];
-        int Q = (int)rint(val * (vv == 0 ? q.inv0 : q.inv1));
-        if (vv == 0) {
-          Q = Q > 16256 ? 16256 : (Q < -16256 ? -16256 : Q);
-          const int d0 = (int)rint((double)Q * 0.0078125);       // Q / 128, exact
-          const int d1 = Q - 128 * d0;
-          w[0] |= ((unsigned)d0 & 0xffu) << (8 * j);
-          w[1] |= ((unsigned)d1 & 0xffu) << (8 * j);
-        } else {
-          Q = Q > 127 ? 127 : (Q < -127 ? -127 : Q);
-          w[2] |= ((unsigned)Q & 0xffu) << (8 * j);
-        }
-      }
+      int d0, d1;
+      bc_i8q_elem0((MODE == 0) ? v[2 * k] : v[k], q, d0, d1);
+      w[0] |= ((unsigned)d0 & 0xffu) << (8 * j);
+      w[1] |= ((unsigned)d1 & 0xffu) << (8 * j);
+      if (MODE == 0) w[2] |= ((unsigned)bc_i8q_elem1(v[2 * k + 1], q) & 0xffu) << (8 * j);
     }
   }
 }
@@ -70,7 +76,7 @@ struct bc_i8q_hdr {
 
 // fp32 copies, each rounded UP where it enters a bound
 __device__ __forceinline__ bc_i8q_hdr bc_i8q_header(const bc_i8q_scalars& q, int S, double vn) {
-  const double rs = sqrt((double)S) * 0.5;
+  const double rs = (double)sqrtf((float)S) * (0.5 * (1. + 1e-6));      // >= sqrt(S) / 2 (an fp64 sqrt is another ~500 cycles)
   bc_i8q_hdr h;
   h.fvn = __double2float_ru(vn);
   h.fev0 = __double2float_ru(rs * q.vstep0);

@@ -266,9 +266,13 @@ __device__ void dev_xw_err(const SnnlsDev& P, SnnlsState& S, double* red) {
 // taken while the elements are in registers, and the digits' pass reads them back from a 4 KB LDS copy (S <= BC_VQ_MAX;
 // larger S re-reads v from global memory).
 #define BC_VQ_MAX 256
+#ifndef BC_QD_INTS
+#define BC_QD_INTS 512
+#endif
 template <int ALG>
 __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
   __shared__ double vq[2 * BC_VQ_MAX];
+  __shared__ int qd[BC_QD_INTS];           // LDS image of the two digit records (S <= ~256)
   const int s = P.s;
   if (threadIdx.x < BC_WAVE) {
     const int lane = threadIdx.x;
@@ -328,11 +332,17 @@ __device__ void dev_prep(const SnnlsDev& P, SnnlsState& S, double* red) {
       const double* vsrc = lds_copy ? vq : P.v;
       m0 = bc_wave_max_all(m0);
       m1 = bc_wave_max_all(m1);
-      if (ALG == BC_ALG_GIGA) bc_i8q_wave<0>(vsrc, s, P.sp4, 1., P.qv, lane, m0, m1);
-      else bc_i8q_wave<1>(vsrc, s, P.sp4, vnorm, P.qv, lane, m0, m1);
-      if (P.qv4 != nullptr) {
-        if (ALG == BC_ALG_GIGA) bc_i4q_wave<0>(vsrc, s, P.sp8, 1., P.qv4, lane, m0, m1);
-        else bc_i4q_wave<1>(vsrc, s, P.sp8, vnorm, P.qv4, lane, m0, m1);
+      if (4 * (P.sp4 + P.sp8) <= BC_QD_INTS) {
+        // one element per lane, both records in one pass (bc_i4_quant.h: bc_q_wave_both)
+        if (ALG == BC_ALG_GIGA) bc_q_wave_both<0>(vsrc, s, P.sp4, P.sp8, 1., P.qv, P.qv4, lane, m0, m1, qd);
+        else bc_q_wave_both<1>(vsrc, s, P.sp4, P.sp8, vnorm, P.qv, P.qv4, lane, m0, m1, qd);
+      } else {
+        if (ALG == BC_ALG_GIGA) bc_i8q_wave<0>(vsrc, s, P.sp4, 1., P.qv, lane, m0, m1);
+        else bc_i8q_wave<1>(vsrc, s, P.sp4, vnorm, P.qv, lane, m0, m1);
+        if (P.qv4 != nullptr) {
+          if (ALG == BC_ALG_GIGA) bc_i4q_wave<0>(vsrc, s, P.sp8, 1., P.qv4, lane, m0, m1);
+          else bc_i4q_wave<1>(vsrc, s, P.sp8, vnorm, P.qv4, lane, m0, m1);
+        }
       }
     }
   }

@@ -87,13 +87,13 @@ def test_bench_sweep_modes_agree():
     b = run_bench('--no-cpu', env={'BC_PREFILTER': '8'})
     assert a['coreset'] == b['coreset']            # same size, same error, same number of failed steps
     assert a['config']['sweep'] == 'fp64' and b['config']['sweep'].startswith('int8')
-    # the default at this size: the two-level form (a 4-bit first level; csrc/bc_prefilter_i4.h), named in the line with its bytes
-    c = run_bench('--no-cpu', '--no-extra', '--no-host')
+    # the two-level form (a 4-bit first level; csrc/bc_prefilter_i4.h: the default from 2M rows, forced here), named in the line
+    # with its bytes: S = 40 -> five dwords of eight nibbles + a 16-bit code per row
+    c = run_bench('--no-cpu', '--no-extra', '--no-host', env={'BC_PREFILTER': '4'})
     assert c['coreset'] == a['coreset'] and c['config']['sweep'].startswith('4-bit') and c['prefilter']['form'] == 3
     lv = c['prefilter']['levels']
-    assert lv['l1_sweeps'] >= c['steps'] and 0 < lv['rows_passed_on'] < 0.04 * lv['l1_sweeps'] * c['config']['N']
-    assert c['roofline']['kernel'].startswith('k_sweep_i4') and abs(c['roofline']['bytes_per_launch'] - 54.0 * c['config']['N']) < 1
-    assert c['value'] > 1.25 * b['value']          # (8 750 against 5 700 it/s)
+    assert lv['l1_sweeps'] >= c['steps'] and 0 < lv['rows_passed_on'] == lv['rows_refined_int8']
+    assert c['roofline']['kernel'].startswith('k_sweep_i4') and abs(c['roofline']['bytes_per_launch'] - 22.0 * c['config']['N']) < 1
 
 
 def test_bench_spawns_its_own_ranks():
