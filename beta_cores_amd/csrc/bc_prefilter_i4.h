@@ -6,7 +6,7 @@
 //            (bc_score_interval_f32), wider deltas.  A row is passed on when its upper bound reaches
 //            theta = max(theta0, the best lower bound the wave has seen so far); both are lower bounds of the best exact
 //            score, so the row the fp64 sweep returns -- and every row tied with it -- is always passed on.  theta0 comes from
-//            SEEDS: the strongest row of each of the first 256 sweep blocks of the last two-level step (rows spread over the
+//            SEEDS: the strongest row of each of the first 224 sweep blocks of the last two-level step (rows spread over the
 //            top of the score distribution) and a ring of the rows that reached the exact rescoring lately, evaluated against
 //            the NEW vectors from their int8 records by every block in its prologue (one row per thread; the first tile's
 //            loads are in flight meanwhile).  Scores move slowly between steps, so theta0 is usually within a few percent of
