@@ -1435,7 +1435,7 @@ static bool fused_rescore_ok(const bc_snnls* h) {
   const size_t lds = ((size_t)5 * h->d.s + h->d.rec_len + 2 * (size_t)(h->nnz_upper + 1)) * sizeof(double);
   // static LDS of the fused kernel (rescoring strips 32 KB, current / best row 16 KB, tile list 4 KB, ...) + the dynamic part
   // must fit the device's per-block limit (160 KB on gfx950; the two-launch path is taken otherwise)
-  return lds <= BC_RS_MAX_DYN_LDS && lds + 62 * 1024 <= (size_t)h->ctx->max_lds;      // (61.5 KB static, of which 4 KB dev_prep copy of the sweep vectors)
+  return lds <= BC_RS_MAX_DYN_LDS && lds + 64 * 1024 <= (size_t)h->ctx->max_lds;      // (63.5 KB static, of which 4 KB dev_prep copy of the sweep vectors and 2 KB image of the digit records)
 }
 
 static int launch_sweep(bc_snnls* h, bool with_record, bool allow_fused) {
