@@ -22,7 +22,7 @@ while time.time() < t_end:
     giga = rng.rand() < 0.6
     cls, ref_cls = (bc.snnls.GIGA, RefGIGA) if giga else (bc.snnls.FrankWolfe, RefFrankWolfe)
     steps = min(n, rng.randint(1, 30))
-    pref = rng.choice([0, 8, 16])
+    pref = rng.choice([0, 4, 8, 16])        # (4: the two-level form, csrc/bc_prefilter_i4.h)
     os.environ['BC_PREFILTER'] = str(pref)
     os.environ['BC_FINISH_NOPF'] = str(rng.randint(2))
     a = cls(phi.T, phi.sum(axis=0)); a.build(steps)
