@@ -74,8 +74,9 @@ struct RescoreArgs {
   double post_div;
   int s, cap, nblk, ptile;
   int tile_rounds;           // tiles per sweep wave = ceil(ptiles / (4 * nblk)): block b swept tiles 4b+w + 4*nblk*i
-  // two-level form (bc_prefilter_i4.h): the block lists come from the refine kernel -- there are no tiles behind them, a block
-  // that could not keep its list means "redo the step exactly" -- and ctrl[8] says whether the first level's list overflowed
+  // two-level form (bc_prefilter_i4.h): the block lists come from the sweep's second level -- there are no tiles behind them; a
+  // block with more rows in play than its list holds left them in the spill list, one that could not keep them at all means
+  // "redo the step exactly"
   int two_level;
   const int2* spill;         // two-level form: pairs of the blocks whose list says -1 (count in ctrl[14], reset here)
   int spill_cap;
@@ -230,12 +231,10 @@ struct RescorePre {
   int nc[BC_RS_BLK_PER];
   float bu[BC_RS_BLK_PER];
   int2 c[BC_RS_BLK_PER][BC_RS_BLK_NC];
-  int l1_ovf;                // two-level form: the first level's list overflowed (ctrl[8])
 };
 
 __device__ __forceinline__ RescorePre bc_rescore_prefetch(const RescoreArgs& a) {
   RescorePre p;
-  p.l1_ovf = a.two_level ? a.ctrl[8] : 0;
   // (clamped indices instead of branches: every thread loads, nothing separates the requests -- with the loads inside
   // `if`s the compiler waited for the first bound before it issued the rest)
 #pragma unroll
@@ -358,7 +357,7 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
   if (a.two_level) {
     // the lists ARE the candidates.  A block in play whose list says -1 left its pairs in the spill list (scanned below);
     // -2 (it could not keep them at all) cannot be walked: the step is redone with the exact sweep
-    overflow = mine.l1_ovf != 0 || !lists;
+    overflow = !lists;
   } else if (nbl <= 64 && a.tile_cand) {
     merged = true;
     const int per = 4 * a.tile_rounds, total = nbl * per;
