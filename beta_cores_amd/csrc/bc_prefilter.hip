@@ -87,7 +87,9 @@ struct bc_pref {
   int2* spill = nullptr;           // [cap] pairs of blocks with more than BC_BLK_NC rows in play
   long long* cand = nullptr;  // [cap] candidate LOCAL rows
   int* ctrl = nullptr;        // [1] the last rescoring overflowed, [3] overflows so far,
-                              // [4..5] sweeps so far (u64), [6..7] candidates rescored so far (u64)
+                              // [4..5] sweeps so far (u64), [6..7] candidates rescored so far (u64); two-level form: [9] position
+                              // in the seeds' ring, [12..13] rows passed on by the first level so far (u64), [14] pairs in the spill
+                              // list of the sweep in flight; branch-and-bound form: [16..17] its shared bound
   int cap = 4096;
   long long ptiles = 0;
   int grid = 1;
@@ -681,7 +683,7 @@ int bc_pref_launch_sweep(bc_pref* p, int mode, const double* v_dev, const double
   r.two_level = two ? 1 : 0;
   r.spill = p->spill;
   r.spill_cap = 4096;
-  r.hot = p->two ? p->hot + BC_I4_SEEDS : nullptr;      // (the ring behind the refine blocks' slots)
+  r.hot = p->two ? p->hot + BC_I4_SEEDS : nullptr;      // (the ring behind the sweep blocks' slots)
   if (two) {
     // the two-level sweep's block lists; there are no tiles behind them
     r.blk_l = p->l2_blk_l;

@@ -35,7 +35,7 @@
 #define BC_I4_MAXG8 72       // k-groups of 4 of the int8 digit table (seeds, level 2): S <= 256 plus padding
 #define BC_I4_PARK 128       // rows a wave parks in LDS before it appends them to the global list
 #define BC_I4_HOT 32         // seeds: ring of rows that were in play lately (local row numbers, -1: empty) ...
-#define BC_I4_SEEDS 256      // ... behind one slot per refine block (its strongest row): hot[BC_I4_SEEDS + BC_I4_HOT]
+#define BC_I4_SEEDS 256      // ... behind one slot per sweep block (its strongest row; the last BC_I4_HOT slots are not read): hot[BC_I4_SEEDS + BC_I4_HOT]
 #define BC_I4_DEAD 255       // delta code of a dead row (padding or zero norm)
 #define BC_I4_UNCERTAIN 254  // delta code of a row the bound cannot cover (NaN / inf in it, or delta too large for the code)
 #define BC_L2_LCAP 512       // rows in play a block can hold before it gives up (-> exact redo); rows that cannot reach the

@@ -135,7 +135,7 @@ def test_candidate_overflow_falls_back_to_fp64(bc, cap, prec):
     else:
         # b = 1 is orthogonal to every (centred) row: all 3000 scores tie at rounding noise.  The two-pass form's lists hold 4096
         # candidates; a branch-and-bound block rescores at most 48 rows per sweep and hands such a step to the exact sweep, and
-        # so does a refine block of the two-level form that is left with more than eight rows in play
+        # so does the two-level form once its blocks are left with more rows in play than their lists and the spill list hold
         assert s._eng.prefilter_fallbacks() >= 1
         with prefilter(prec):
             s = bc.snnls.GIGA(phi2.T, phi2.sum(axis=0))
