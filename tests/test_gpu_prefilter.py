@@ -282,6 +282,35 @@ def test_two_level_watch_puts_the_first_level_aside_where_it_does_not_select(bc)
     assert np.array_equal(sv._eng.trace()[0], ref._eng.trace()[0])
 
 
+@pytest.mark.parametrize('alg', ['giga', 'fw'])
+def test_two_level_form_across_reset_and_repeated_build_calls(bc, alg):
+    """The two-level form keeps state between sweeps (the seeds of its first level, the host's watch): a solver that is built in
+    several calls, reset and built again must return what a fresh fp64-sweep solver returns every time."""
+    rng = np.random.RandomState(31)
+    phi = correlated(rng, 50000, 64)
+    cls = bc.snnls.GIGA if alg == 'giga' else bc.snnls.FrankWolfe
+
+    def fresh(steps):
+        with prefilter(0):
+            r = cls(phi.T, phi.sum(axis=0))
+        r.build(steps)
+        return r._eng.trace()[0], r._eng.sparse_weights(), r.error()
+
+    with prefilter(4):
+        sv = cls(phi.T, phi.sum(axis=0))
+    assert sv._eng.prefilter_form == 3
+    for k in (1, 1, 5, 13):                              # 20 steps in four calls (the first sweep of a solver is the int8 one)
+        sv.build(k)
+    t, w, e = fresh(20)
+    assert np.array_equal(sv._eng.trace()[0], t) and np.array_equal(sv._eng.sparse_weights()[0], w[0])
+    assert np.array_equal(sv._eng.sparse_weights()[1], w[1]) and sv.error() == e
+    sv.reset()                                           # the seeds now describe the END of the previous run: still valid bounds
+    sv.build(12)
+    t, w, e = fresh(12)
+    assert np.array_equal(sv._eng.trace()[0], t) and np.array_equal(sv._eng.sparse_weights()[1], w[1]) and sv.error() == e
+    assert sv._eng.prefilter_levels()[0] >= 4            # (on 50 000 rows the host's watch may put the first level aside after a few calls)
+
+
 def _fuzz_problem(rng, n, s, kind):
     if kind == 0:
         phi = rng.randn(n, s)
