@@ -445,11 +445,14 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
         }
     }
   }
-  __syncthreads();
+  int ntl = 0;
+  if (!a.two_level) {                        // (block-uniform; the two-level form walked nothing: its counters are final since the last barrier)
+    __syncthreads();
+    ntl = tcnt;
+    if (threadIdx.x == 0 && !merged) bcnt = 0; // reused by the int8 branch below
+    __syncthreads();
+  }
   FSTAMP(11);
-  const int ntl = tcnt;
-  if (threadIdx.x == 0 && !merged) bcnt = 0; // reused by the int8 branch below
-  __syncthreads();
   overflow = overflow || ntl > (a.u16 ? BC_RS_TILE_LIMIT16 : 1024);      // too many tiles in play
   if (a.two_level) {
     overflow = overflow || ocnt > 0;
