@@ -308,12 +308,15 @@ __device__ __forceinline__ int bc_rescore_block(const RescoreArgs& a, long long 
     // (almost every thread finds nothing: one branch-free pass decides whether it has anything to do at all)
     // (Tried and dropped: the thread that finds a candidate touching its fp64 row right away, to start the ~2 us TLB miss of
     // that first access into the 8 GB Phi early -- __syncthreads() carries a vmcnt(0), so the next barrier waits for the touch.)
+    // (a float reaches the double lmax exactly when it reaches lmax rounded UP to a float: the sixteen comparisons of this
+    // pre-check run in fp32)
+    const float lmf = __double2float_ru(lmax);
     bool any = false;
 #pragma unroll
     for (int q = 0; q < BC_RS_BLK_PER; ++q) {
-      any |= mine.nc[q] < 0 && mine.bu[q] != -INFINITY && (double)mine.bu[q] >= lmax;
+      any |= mine.nc[q] < 0 && mine.bu[q] != -INFINITY && mine.bu[q] >= lmf;
 #pragma unroll
-      for (int e = 0; e < BC_RS_BLK_NC; ++e) any |= e < mine.nc[q] && (double)__int_as_float(mine.c[q][e].x) >= lmax;
+      for (int e = 0; e < BC_RS_BLK_NC; ++e) any |= e < mine.nc[q] && __int_as_float(mine.c[q][e].x) >= lmf;
     }
     if (any) {
 #pragma unroll
