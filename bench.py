@@ -10,6 +10,12 @@ A "step" = one greedy iteration of SparseNNLS.build (select + reweight + monoton
 over Phi resident in HBM.  The one-off K1 projection is timed separately and reported
 as points*dims/s.  Prints ONE JSON line on rank 0 -- kept short (~5 KB) so that the driver's
 record holds all of it; the evidence sits inside the two objects that record keeps whole:
+  roofline            the dominant kernel of a step: the sweep.  From 2M rows per shard that is `k_sweep_i4` (two-level pre-filter:
+                      a 4-bit mirror of the normalised rows streamed at half a byte per element, the rows it cannot exclude
+                      re-bounded from int8 records in the same launch, the handful left rescored in fp64 -- the row returned is the
+                      fp64 sweep's); `achieved` = its algorithmic bytes (54 B per row at S = 100) / its average launch time (HIP
+                      events on the launch stream), `traffic` = HBM bytes per launch from the PMC passes under profiles/;
+                      `prefilter` = {form, sweeps, rows rescored exactly, fallbacks, levels: rows the 4-bit level passed on}
   roofline.kernels    one entry per timed kernel (avg ms by HIP events, GB / GF per launch, fractions of the HBM / fp64-MFMA peaks)
   roofline.loops      the beta-Cores gradient loops of configs 2, 3 (logistic + Laplace sampler) and 4, per-phase split
   roofline.from_host  ndarray -> resident rows / first iteration / M = 100 coreset (upload + K1 pipelined); never part of `value`
